@@ -1,0 +1,188 @@
+/*
+ * rebvio_hip.h — C-ABI of the MI355X (gfx950) backend for rebvio's per-frame edge-detection +
+ * edge-tracking hot path. Plain C types, caller-allocated outputs, int status (0 = ok, <0 = error,
+ * see rebvio_hip_last_error). No exceptions cross this boundary. One context per camera stream and
+ * GPU; a context is not thread-safe, but its detect-side entries (detect*) and track-side entries
+ * run on two private HIP streams and overlap on the device, mirroring the reference's two workers
+ * (rebvio/src/rebvio.cpp:28-29).
+ *
+ * Each entry names the reference interface it replaces (paths relative to the reference repo).
+ * The C++ classes in include/rebvio/ (EdgeDetector, EdgeMap, Core, Rebvio) are thin hosts over this
+ * ABI; INTEGRATION.md shows the binding.
+ */
+#ifndef REBVIO_HIP_H_
+#define REBVIO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REBVIO_HIP_ABI_VERSION 1
+
+/* Host mirror of one keyline: field-for-field rebvio::types::KeyLine
+ * (rebvio/include/rebvio/types/keyline.hpp:24-40), 84 bytes. Device storage is SoA. */
+typedef struct rebvio_hip_keyline {
+  float pos[2];
+  float pos_img[2];
+  float match_pos_img[2];
+  float gradient[2];
+  float match_gradient[2];
+  float gradient_norm;
+  float match_gradient_norm;
+  float rho;
+  float sigma_rho;
+  int id;
+  int id_prev;
+  int id_next;
+  int match_id;
+  int match_id_forward;
+  int match_id_keyframe;
+  unsigned int matches;
+} rebvio_hip_keyline;
+
+/* Camera constants (camera.hpp:61-72), EdgeDetectorConfig (edge_detector.hpp:19-32), CoreConfig
+ * (core.hpp:82-95), EdgeMapConfig (edge_map.hpp:19-26), gyro noise of ImuStateConfig
+ * (types/imu.hpp:158-159). */
+typedef struct rebvio_hip_params {
+  int rows, cols;
+  float fm, cx, cy;
+  int keylines_ref, keylines_max;
+  float pos_neg_threshold, dog_threshold, threshold, gain, max_threshold, min_threshold;
+  float search_range, reweight_distance, match_treshold;
+  unsigned int min_match_threshold, iterations, global_min_matches_threshold;
+  float pixel_uncertainty, quantile_cutoff;
+  int quantile_num_bins;
+  float reshape_q_abs;
+  float pixel_uncertainty_match, match_threshold_norm, match_threshold_angle, regularization_threshold;
+  float gyro_std_dev, gyro_bias_std_dev;
+  int device_id;  /* HIP device ordinal for this camera stream */
+  int map_pool;   /* edge maps kept alive at once (>= 3: old, new, in-flight detect); 0 = default */
+} rebvio_hip_params;
+
+typedef struct rebvio_hip_ctx rebvio_hip_ctx;
+typedef struct rebvio_hip_map rebvio_hip_map;
+
+/* Result of one frame-pair step (rebvio.cpp:142-259 without accelerometer/SAB fusion). */
+typedef struct rebvio_hip_pair_out {
+  float Vg[3];
+  float P_Vg[9];
+  float F;
+  float Xv[6];
+  float W_Xv[36];
+  float Xgv[6];
+  float V[3];
+  float R[9];
+  float P_V[9];
+  float sigma_rho_min;
+  int ext_ok;
+  int klm_num;
+  int kf_matches;
+  int reg_num;
+  int lm_accept_mask;
+  int status; /* 0 ok, 1 minimization NaN, 2 insufficient matches */
+} rebvio_hip_pair_out;
+
+int rebvio_hip_abi_version(void);
+const char* rebvio_hip_last_error(void);
+
+/* Defaults of the reference's config structs and Camera() for a rows x cols sensor. */
+void rebvio_hip_default_params(rebvio_hip_params* p, int rows, int cols);
+
+/* Replaces the constructors EdgeDetector(camera, config) (edge_detector.cpp:17-26), ScaleSpace /
+ * FastGaussian (scale_space.cpp:14-41,184-190), Core(camera, config) + DistanceField (core.cpp:17-24,
+ * core.hpp:22-28): allocates every device buffer once. */
+int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out);
+void rebvio_hip_destroy(rebvio_hip_ctx* ctx);
+
+/* ScaleSpace::build (scale_space.cpp:203-208) on a host fp32 image (0..765); any output may be NULL.
+ * Test/diagnostic entry: detect() runs the same kernels without the downloads. */
+int rebvio_hip_scale_space(rebvio_hip_ctx* ctx, const float* img_host, float* scale0, float* scale1, float* dog,
+                           float* mag);
+
+/* EdgeDetector::detect (edge_detector.cpp:30-43): threshold servo, buildEdgeMap, joinEdges,
+ * tuneThreshold. The image is the undistorted fp32 frame the reference passes in types::Image
+ * (rebvio.cpp:43-47). Returns a pooled map (release with rebvio_hip_map_release). Asynchronous: the
+ * keyline count is fetched by rebvio_hip_map_size. */
+int rebvio_hip_detect(rebvio_hip_ctx* ctx, const float* img_host, size_t pitch_bytes, uint64_t ts_us,
+                      rebvio_hip_map** out);
+/* Same, for a u8 frame already resident in device memory: fuses convertTo(CV_32F, 3.0) (rebvio.cpp:43)
+ * into the first scan kernel. `frame_dev` is a device pointer to rows*cols bytes, dense. */
+int rebvio_hip_detect_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_map** out);
+/* config_->threshold after the servo and auto_threshold_ (edge_detector.hpp:84,91). Synchronises. */
+int rebvio_hip_detector_state(rebvio_hip_ctx* ctx, float* threshold, float* auto_threshold, int* keylines_count);
+
+/* EdgeMap accessors (edge_map.hpp:40-75). size/threshold synchronise with the detect stream. */
+int rebvio_hip_map_size(rebvio_hip_map* m);
+float rebvio_hip_map_threshold(rebvio_hip_map* m);
+uint64_t rebvio_hip_map_ts(rebvio_hip_map* m);
+/* Lazy host mirror of keylines() / mask() (edge_map.hpp:50,75): AoS keylines (may be NULL) and the
+ * dense image-index -> keyline-index table (may be NULL; -1 = none). */
+int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int* mask);
+/* Test hook: overwrite the device keylines (count must equal the map size). */
+int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines, int n);
+void rebvio_hip_map_release(rebvio_hip_map* m);
+
+/* Core::buildDistanceField / DistanceField::build (core.cpp:33-37, core.hpp:37-59). */
+int rebvio_hip_build_distance_field(rebvio_hip_ctx* ctx, rebvio_hip_map* m);
+/* DistanceField::operator[] for all cells (core.hpp:61): ids (-1 = none) and distances (valid where id >= 0). */
+int rebvio_hip_distance_field(rebvio_hip_ctx* ctx, int* id_out, int* dist_out);
+
+/* EdgeMap::rotateKeylines (edge_map.cpp:58-71); R row-major 3x3. */
+int rebvio_hip_rotate(rebvio_hip_ctx* ctx, rebvio_hip_map* m, const float R[9]);
+/* EdgeMap::estimateQuantile (edge_map.cpp:39-56). */
+int rebvio_hip_quantile(rebvio_hip_ctx* ctx, rebvio_hip_map* m, float percentile, int num_bins, float* out);
+/* Core::tryVel (core.cpp:78-148). `residuals` (host, map-size floats) is read and updated like the
+ * reference's `_residuals`; out10 = score, JtJ(0,0),(1,1),(2,2),(0,1),(0,2),(1,2), JtF[0..2]. */
+int rebvio_hip_try_vel(rebvio_hip_ctx* ctx, rebvio_hip_map* m, const float vel[3], float sigma_rho_min,
+                       float* residuals, float out10[10]);
+/* Core::minimizeVel (core.cpp:150-189) with the Levenberg-Marquardt loop kept on the device.
+ * vel is in/out; Rvel = invert(JtJ); returns score in *F. */
+int rebvio_hip_minimize_vel(rebvio_hip_ctx* ctx, rebvio_hip_map* m, float vel[3], float Rvel[9], float* F,
+                            int* accept_mask, float* sigma_rho_min);
+/* EdgeMap::forwardMatch (edge_map.cpp:73-99): old_map->forwardMatch(new_map). */
+int rebvio_hip_forward_match(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, rebvio_hip_map* new_map);
+/* Core::extRotVel (core.cpp:191-261) on the distance field's map. JtJ 6x6 row-major, JtF[6], X[6]. */
+int rebvio_hip_ext_rot_vel(rebvio_hip_ctx* ctx, const float vel[3], float Wx[36], float JtF[6], float X[6], int* ok);
+/* EdgeMap::directedMatch (edge_map.cpp:186-218): new_map->directedMatch(old_map, ...). */
+int rebvio_hip_directed_match(rebvio_hip_ctx* ctx, rebvio_hip_map* new_map, rebvio_hip_map* old_map, const float vel[3],
+                              const float Rvel[9], const float Rback[9], float max_radius, int* matches,
+                              int* kf_matches);
+/* EdgeMap::regularize1Iter (edge_map.cpp:220-259). */
+int rebvio_hip_regularize(rebvio_hip_ctx* ctx, rebvio_hip_map* m, int* count);
+/* Core::updateInverseDepth (core.cpp:417-456) on the distance field's map. */
+int rebvio_hip_update_inverse_depth(rebvio_hip_ctx* ctx, const float vel[3]);
+
+/* Gyro-bias state of the frame-pair glue (types/imu.hpp:180-183) back to its initial value. */
+void rebvio_hip_reset_state(rebvio_hip_ctx* ctx);
+/* One frame pair, rebvio.cpp:142-259 (accelerometer/SAB branch excluded): distance field of new_map
+ * (if not yet built), rotate, minimizeVel, forwardMatch, extRotVel, gyroBiasCorrection, rotate,
+ * directedMatch, regularize1Iter, updateInverseDepth. R_prior = IMU inter-frame rotation or NULL. */
+int rebvio_hip_track_pair(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, rebvio_hip_map* new_map, const float* R_prior,
+                          float frame_dt, rebvio_hip_pair_out* out);
+
+/* Streaming driver used by bench/Rebvio: detect(frame) on the detect stream overlapped with
+ * track(previous pair) on the track stream. `out` describes the pair (previous, this) and is filled
+ * when the call returns (status -1 for the very first frame). */
+int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_dev, uint64_t ts_us,
+                                    rebvio_hip_pair_out* out, int* keylines);
+int rebvio_hip_flush(rebvio_hip_ctx* ctx);
+
+/* Per-kernel device timing of the last N launches of each kernel, measured with HIP events on the
+ * stream the kernel runs on. names: '\n'-separated. Used by bench.py's roofline leg. */
+int rebvio_hip_profile_enable(rebvio_hip_ctx* ctx, int on);
+int rebvio_hip_profile_select(rebvio_hip_ctx* ctx, const char* only_kernel); /* NULL/"" = every kernel */
+int rebvio_hip_profile_reset(rebvio_hip_ctx* ctx);
+int rebvio_hip_profile_read(rebvio_hip_ctx* ctx, char* names, size_t names_cap, double* avg_us, int* calls, int cap);
+
+/* Device memory helpers so that hosts without a HIP runtime binding (ctypes, cgo) can stage frames. */
+int rebvio_hip_device_alloc(rebvio_hip_ctx* ctx, size_t bytes, void** out);
+int rebvio_hip_device_free(rebvio_hip_ctx* ctx, void* p);
+int rebvio_hip_device_upload(rebvio_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,290 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE — see oracle/rebvio_oracle.h).
+
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KEYLINE_DTYPE = np.dtype([
+    ("pos", "<f4", (2,)), ("pos_img", "<f4", (2,)), ("match_pos_img", "<f4", (2,)), ("gradient", "<f4", (2,)),
+    ("match_gradient", "<f4", (2,)), ("gradient_norm", "<f4"), ("match_gradient_norm", "<f4"), ("rho", "<f4"),
+    ("sigma_rho", "<f4"), ("id", "<i4"), ("id_prev", "<i4"), ("id_next", "<i4"), ("match_id", "<i4"),
+    ("match_id_forward", "<i4"), ("match_id_keyframe", "<i4"), ("matches", "<u4")])
+assert KEYLINE_DTYPE.itemsize == 84
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int), ("cols", C.c_int), ("fm", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("keylines_ref", C.c_int), ("keylines_max", C.c_int),
+        ("pos_neg_threshold", C.c_float), ("dog_threshold", C.c_float), ("threshold", C.c_float), ("gain", C.c_float),
+        ("max_threshold", C.c_float), ("min_threshold", C.c_float),
+        ("search_range", C.c_float), ("reweight_distance", C.c_float), ("match_treshold", C.c_float),
+        ("min_match_threshold", C.c_uint), ("iterations", C.c_uint), ("global_min_matches_threshold", C.c_uint),
+        ("pixel_uncertainty", C.c_float), ("quantile_cutoff", C.c_float), ("quantile_num_bins", C.c_int),
+        ("reshape_q_abs", C.c_float),
+        ("pixel_uncertainty_match", C.c_float), ("match_threshold_norm", C.c_float), ("match_threshold_angle", C.c_float),
+        ("regularization_threshold", C.c_float),
+        ("gyro_std_dev", C.c_float), ("gyro_bias_std_dev", C.c_float)]
+
+
+class PairOut(C.Structure):
+    _fields_ = [
+        ("Vg", C.c_float * 3), ("P_Vg", C.c_float * 9), ("F", C.c_float), ("Xv", C.c_float * 6), ("W_Xv", C.c_float * 36),
+        ("Xgv", C.c_float * 6), ("V", C.c_float * 3), ("R", C.c_float * 9), ("P_V", C.c_float * 9),
+        ("sigma_rho_min", C.c_float), ("ext_ok", C.c_int), ("klm_num", C.c_int), ("kf_matches", C.c_int),
+        ("reg_num", C.c_int), ("lm_accept_mask", C.c_int), ("status", C.c_int)]
+
+
+def build(native: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile) and return the .so path."""
+    target = ["native"] if native else []
+    subprocess.run(["make", "-s", "-C", _HERE] + target, check=True)
+    sub = "_build/native" if native else "_build"
+    return os.path.join(_HERE, sub, "librebvio_oracle.so")
+
+
+_lib = None
+
+
+def lib(path: str | None = None):
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.path.join(_HERE, "_build", "librebvio_oracle.so")
+    if not os.path.exists(p):
+        p = build()
+    L = C.CDLL(p)
+    fp = C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int)
+    vp = C.c_void_p
+    sig = {
+        "orc_default_params": (None, [C.POINTER(Params), C.c_int, C.c_int]),
+        "orc_create": (vp, [C.POINTER(Params)]),
+        "orc_destroy": (None, [vp]),
+        "orc_scale_space": (None, [vp, fp, fp, fp, fp, fp]),
+        "orc_integral_image": (None, [C.c_int, C.c_int, fp, fp]),
+        "orc_box_average": (None, [C.c_int, C.c_int, C.c_int, fp, fp]),
+        "orc_filter_width": (C.c_int, [vp, C.c_int, C.c_int]),
+        "orc_detect": (vp, [vp, fp, C.c_uint64]),
+        "orc_detector_threshold": (C.c_float, [vp]),
+        "orc_detector_auto_threshold": (C.c_float, [vp]),
+        "orc_detector_mask": (None, [vp, ip]),
+        "orc_map_size": (C.c_int, [vp]),
+        "orc_map_threshold": (C.c_float, [vp]),
+        "orc_map_set_threshold": (None, [vp, C.c_float]),
+        "orc_map_get_keylines": (None, [vp, vp]),
+        "orc_map_set_keylines": (None, [vp, vp, C.c_int]),
+        "orc_map_get_mask": (None, [vp, ip]),
+        "orc_map_clone": (vp, [vp]),
+        "orc_map_free": (None, [vp]),
+        "orc_build_distance_field": (None, [vp, vp]),
+        "orc_distance_field": (None, [vp, ip, ip]),
+        "orc_rotate_keylines": (None, [vp, vp, fp]),
+        "orc_estimate_quantile": (C.c_float, [vp, C.c_float, C.c_int]),
+        "orc_try_vel": (C.c_float, [vp, vp, fp, C.c_float, fp, fp, fp]),
+        "orc_minimize_vel": (C.c_float, [vp, vp, fp, fp, ip, fp]),
+        "orc_forward_match": (C.c_int, [vp, vp]),
+        "orc_ext_rot_vel": (C.c_int, [vp, fp, fp, fp, fp]),
+        "orc_directed_match": (C.c_int, [vp, vp, vp, fp, fp, fp, ip, C.c_float]),
+        "orc_regularize": (C.c_int, [vp]),
+        "orc_update_inverse_depth": (None, [vp, fp]),
+        "orc_reset_state": (None, [vp]),
+        "orc_track_pair": (C.c_int, [vp, vp, vp, fp, C.c_float, C.POINTER(PairOut)]),
+        "orc_ls4_reset": (None, [vp]),
+        "orc_estimate_ls4_acceleration": (None, [vp, fp, fp, fp, C.c_float]),
+        "orc_so3_exp": (None, [fp, fp]),
+        "orc_sym6_solve": (None, [fp, fp, fp]),
+        "orc_run_stream": (C.c_double, [vp, C.POINTER(C.c_uint8), ip, C.c_int, C.c_int, ip, ip, fp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    if path is None:
+        _lib = L
+    return L
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_params(rows: int, cols: int, **over) -> Params:
+    p = Params()
+    lib().orc_default_params(C.byref(p), rows, cols)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Map:
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def __del__(self):
+        if self.h:
+            self.L.orc_map_free(self.h)
+            self.h = None
+
+    def size(self):
+        return self.L.orc_map_size(self.h)
+
+    @property
+    def threshold(self):
+        return self.L.orc_map_threshold(self.h)
+
+    @threshold.setter
+    def threshold(self, t):
+        self.L.orc_map_set_threshold(self.h, float(t))
+
+    def keylines(self) -> np.ndarray:
+        out = np.zeros(self.size(), KEYLINE_DTYPE)
+        if out.size:
+            self.L.orc_map_get_keylines(self.h, out.ctypes.data)
+        return out
+
+    def set_keylines(self, kl: np.ndarray):
+        kl = np.ascontiguousarray(kl, KEYLINE_DTYPE)
+        self.L.orc_map_set_keylines(self.h, kl.ctypes.data, len(kl))
+
+    def mask(self, rows, cols) -> np.ndarray:
+        out = np.empty((rows, cols), np.int32)
+        self.L.orc_map_get_mask(self.h, out.ctypes.data_as(C.POINTER(C.c_int)))
+        return out
+
+    def clone(self) -> "Map":
+        return Map(self.L, self.L.orc_map_clone(self.h))
+
+
+class Oracle:
+    """Thin object wrapper over the C API."""
+
+    def __init__(self, params: Params, path: str | None = None):
+        self.L = lib(path)
+        self.p = params
+        self.rows, self.cols = params.rows, params.cols
+        self.h = self.L.orc_create(C.byref(params))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    # --- detection -------------------------------------------------------------------------
+    def scale_space(self, img):
+        img, pi = _f(img)
+        outs = [np.empty((self.rows, self.cols), np.float32) for _ in range(4)]
+        self.L.orc_scale_space(self.h, pi, *[o.ctypes.data_as(C.POINTER(C.c_float)) for o in outs])
+        return dict(scale0=outs[0], scale1=outs[1], dog=outs[2], mag=outs[3])
+
+    def detect(self, img, ts_us=0) -> Map:
+        img, pi = _f(img)
+        assert img.shape == (self.rows, self.cols)
+        return Map(self.L, self.L.orc_detect(self.h, pi, ts_us))
+
+    def detect_u8(self, frame_u8, ts_us=0) -> Map:
+        return self.detect(frame_u8.astype(np.float32) * np.float32(3.0), ts_us)
+
+    @property
+    def threshold(self):
+        return self.L.orc_detector_threshold(self.h)
+
+    @property
+    def auto_threshold(self):
+        return self.L.orc_detector_auto_threshold(self.h)
+
+    # --- tracking --------------------------------------------------------------------------
+    def build_distance_field(self, m: Map):
+        self.L.orc_build_distance_field(self.h, m.h)
+
+    def distance_field(self):
+        ids = np.empty((self.rows, self.cols), np.int32)
+        dist = np.empty((self.rows, self.cols), np.int32)
+        ip = C.POINTER(C.c_int)
+        self.L.orc_distance_field(self.h, ids.ctypes.data_as(ip), dist.ctypes.data_as(ip))
+        return ids, dist
+
+    def rotate(self, m: Map, R):
+        R, pr = _f(np.asarray(R).reshape(9))
+        self.L.orc_rotate_keylines(self.h, m.h, pr)
+
+    def quantile(self, m: Map, pct=0.9, bins=100):
+        return self.L.orc_estimate_quantile(m.h, pct, bins)
+
+    def try_vel(self, m: Map, vel, sigma_rho_min, residuals):
+        vel, pv = _f(vel)
+        assert residuals.dtype == np.float32 and residuals.flags.c_contiguous
+        JtJ = np.zeros(9, np.float32)
+        JtF = np.zeros(3, np.float32)
+        fp = C.POINTER(C.c_float)
+        s = self.L.orc_try_vel(self.h, m.h, pv, sigma_rho_min, residuals.ctypes.data_as(fp), JtJ.ctypes.data_as(fp),
+                               JtF.ctypes.data_as(fp))
+        return s, JtJ.reshape(3, 3), JtF
+
+    def minimize_vel(self, m: Map, vel0=(0, 0, 0)):
+        vel = np.array(vel0, np.float32)
+        Rvel = np.zeros(9, np.float32)
+        mask = C.c_int(0)
+        srm = C.c_float(0)
+        fp = C.POINTER(C.c_float)
+        F = self.L.orc_minimize_vel(self.h, m.h, vel.ctypes.data_as(fp), Rvel.ctypes.data_as(fp), C.byref(mask), C.byref(srm))
+        return dict(F=F, vel=vel, Rvel=Rvel.reshape(3, 3), accept_mask=mask.value, sigma_rho_min=srm.value)
+
+    def forward_match(self, old: Map, new: Map):
+        return self.L.orc_forward_match(old.h, new.h)
+
+    def ext_rot_vel(self, vel):
+        vel, pv = _f(vel)
+        Wx = np.zeros(36, np.float32)
+        X = np.zeros(6, np.float32)
+        JtF = np.zeros(6, np.float32)
+        fp = C.POINTER(C.c_float)
+        ok = self.L.orc_ext_rot_vel(self.h, pv, Wx.ctypes.data_as(fp), X.ctypes.data_as(fp), JtF.ctypes.data_as(fp))
+        return dict(ok=ok, Wx=Wx.reshape(6, 6), X=X, JtF=JtF)
+
+    def directed_match(self, new: Map, old: Map, vel, Rvel, Rback, max_radius=40.0):
+        vel, pv = _f(vel)
+        Rvel, prv = _f(np.asarray(Rvel).reshape(9))
+        Rback, prb = _f(np.asarray(Rback).reshape(9))
+        kf = C.c_int(0)
+        n = self.L.orc_directed_match(self.h, new.h, old.h, pv, prv, prb, C.byref(kf), max_radius)
+        return n, kf.value
+
+    def regularize(self, m: Map):
+        return self.L.orc_regularize(m.h)
+
+    def update_inverse_depth(self, vel):
+        vel, pv = _f(vel)
+        self.L.orc_update_inverse_depth(self.h, pv)
+
+    def reset_state(self):
+        self.L.orc_reset_state(self.h)
+
+    def track_pair(self, old: Map, new: Map, R_prior=None, frame_dt=0.05) -> PairOut:
+        out = PairOut()
+        pr = None
+        if R_prior is not None:
+            R_prior, pr = _f(np.asarray(R_prior).reshape(9))
+        self.L.orc_track_pair(self.h, old.h, new.h, pr, frame_dt, C.byref(out))
+        return out
+
+    def run_stream(self, frames_u8: np.ndarray, idx: np.ndarray, threads=1):
+        frames_u8 = np.ascontiguousarray(frames_u8, np.uint8)
+        idx = np.ascontiguousarray(idx, np.int32)
+        n = len(idx)
+        kc = np.zeros(n, np.int32)
+        mc = np.zeros(n, np.int32)
+        pose = np.zeros((n, 6), np.float32)
+        ip = C.POINTER(C.c_int)
+        secs = self.L.orc_run_stream(self.h, frames_u8.ctypes.data_as(C.POINTER(C.c_uint8)), idx.ctypes.data_as(ip), n, threads,
+                                     kc.ctypes.data_as(ip), mc.ctypes.data_as(ip), pose.ctypes.data_as(C.POINTER(C.c_float)))
+        return dict(seconds=secs, keyline_counts=kc, match_counts=mc, pose=pose)

@@ -1,0 +1,1512 @@
+/*
+ * rebvio_oracle.cpp — CPU oracle (TEST INFRASTRUCTURE ONLY; see rebvio_oracle.h).
+ *
+ * Scalar, sequential restatement of the reference hot path with the reference's evaluation
+ * order and its float/double promotion rules. Build with -ffp-contract=off (no FMA fusing) so
+ * results are machine independent and bit-comparable with the HIP parity path.
+ *
+ * PARITY UNPINNED (no reference golden vectors exist for this path).
+ *
+ * Decisions for undefined behaviour in the reference, applied here AND in the
+ * HIP kernels:
+ *   - float->int conversions of NaN / out-of-range values follow x86 cvttss2si/cvttsd2si
+ *     (result INT_MIN), which is what the reference does de facto on its only platform;
+ *   - tryVel: `fi` on calculatefJ's two early-return paths (core.cpp:49-60) is the value last
+ *     written by an earlier matched keyline of the same tryVel call (0 before the first);
+ *   - tuneThreshold on an empty map keeps the previous auto threshold; the histogram read one
+ *     past the end (edge_detector.cpp:183) is read as 0 (it cannot change the result);
+ *   - TooN pieces (absent submodule, unpinned) are restated from TooN's published algorithms:
+ *     dot products accumulate from 0 in index order, mixed float/double makeVector promotes to
+ *     double, determinant by pivoted elimination, LDL^T Cholesky, Rodrigues SO3::exp;
+ *     SVD<6>::backsub (LAPACK gesvd) is replaced by a Jacobi eigen-solve with the same 1e9
+ *     condition cut -> compared with tolerance only.
+ */
+#include "rebvio_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr float RHO_MAX = 20.0;   // types/keyline.hpp:17
+constexpr float RHO_MIN = 1e-3;   // types/keyline.hpp:18
+constexpr float RHO_INIT = 1.0;   // types/keyline.hpp:19
+constexpr int PLANE_FIT = 2;      // edge_detector.hpp:22
+constexpr int NUM_BINS = 100;     // edge_detector.hpp:29
+constexpr int MAX_IMAGE_VALUE = 765;  // edge_detector.cpp:21
+
+// x86 cvttss2si / cvttsd2si: NaN and out-of-range give the "integer indefinite" value.
+inline int cvtt(float v) {
+  if (!(v >= -2147483648.0f && v < 2147483648.0f)) return INT_MIN;
+  return (int)v;
+}
+inline int cvtt(double v) {
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return INT_MIN;
+  return (int)v;
+}
+
+// ---- TooN-style small dense helpers (float, accumulate from 0 in index order) ----------------
+struct M3 {
+  float a[3][3];
+};
+inline M3 m3_identity() {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = (i == j) ? 1.0f : 0.0f;
+  return r;
+}
+inline M3 m3_from(const float* p) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = p[i * 3 + j];
+  return r;
+}
+inline void m3_to(const M3& m, float* p) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) p[i * 3 + j] = m.a[i][j];
+}
+inline M3 m3_T(const M3& m) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = m.a[j][i];
+  return r;
+}
+inline M3 m3_mul(const M3& x, const M3& y) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float s = 0;
+      for (int k = 0; k < 3; ++k) s += x.a[i][k] * y.a[k][j];
+      r.a[i][j] = s;
+    }
+  return r;
+}
+inline void m3_vec(const M3& m, const float v[3], float out[3]) {
+  float t[3];
+  for (int i = 0; i < 3; ++i) {
+    float s = 0;
+    for (int k = 0; k < 3; ++k) s += m.a[i][k] * v[k];
+    t[i] = s;
+  }
+  out[0] = t[0];
+  out[1] = t[1];
+  out[2] = t[2];
+}
+inline M3 m3_add(const M3& x, const M3& y) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = x.a[i][j] + y.a[i][j];
+  return r;
+}
+inline M3 m3_sub(const M3& x, const M3& y) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = x.a[i][j] - y.a[i][j];
+  return r;
+}
+inline M3 m3_scale(const M3& x, float s) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = x.a[i][j] * s;
+  return r;
+}
+
+// TooN::determinant for N>2: Gaussian elimination with partial pivoting (TooN determinant.h).
+template <int N>
+float det_elim(const float* A_) {
+  float A[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) A[i][j] = A_[i * N + j];
+  float det = 1;
+  for (int i = 0; i < N; ++i) {
+    int argmax = i;
+    float mx = std::fabs(A[i][i]);
+    for (int ii = i + 1; ii < N; ++ii)
+      if (std::fabs(A[ii][i]) > mx) {
+        mx = std::fabs(A[ii][i]);
+        argmax = ii;
+      }
+    float pivot = A[argmax][i];
+    if (argmax != i) {
+      det *= -1;
+      for (int ii = i; ii < N; ++ii) std::swap(A[i][ii], A[argmax][ii]);
+    }
+    det *= A[i][i];
+    if (det == 0) return 0;
+    for (int u = i + 1; u < N; ++u) {
+      float factor = A[u][i] / pivot;
+      for (int uu = i; uu < N; ++uu) A[u][uu] = A[u][uu] - factor * A[i][uu];
+    }
+  }
+  return det;
+}
+
+// types::invert (types/definitions.hpp:40-53): adjugate / determinant.
+inline M3 m3_invert(const M3& in) {
+  M3 o;
+  const float(*m)[3] = in.a;
+  o.a[0][0] = m[1][1] * m[2][2] - m[1][2] * m[2][1];
+  o.a[0][1] = m[0][2] * m[2][1] - m[0][1] * m[2][2];
+  o.a[0][2] = m[0][1] * m[1][2] - m[0][2] * m[1][1];
+  o.a[1][0] = m[1][2] * m[2][0] - m[1][0] * m[2][2];
+  o.a[1][1] = m[0][0] * m[2][2] - m[0][2] * m[2][0];
+  o.a[1][2] = m[0][2] * m[1][0] - m[0][0] * m[1][2];
+  o.a[2][0] = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+  o.a[2][1] = m[0][1] * m[2][0] - m[0][0] * m[2][1];
+  o.a[2][2] = m[0][0] * m[1][1] - m[0][1] * m[1][0];
+  float d = det_elim<3>(&in.a[0][0]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o.a[i][j] = o.a[i][j] / d;
+  return o;
+}
+
+// TooN SO3::exp (so3.h rodrigues_so3_exp), precision float.
+inline M3 so3_exp(const float w[3]) {
+  const float one_6th = 1.0 / 6.0;
+  const float one_20th = 1.0 / 20.0;
+  float theta_sq = 0;
+  for (int i = 0; i < 3; ++i) theta_sq += w[i] * w[i];
+  float A, B;
+  if (theta_sq < 1e-8) {
+    A = 1.0 - one_6th * theta_sq;
+    B = 0.5;
+  } else if (theta_sq < 1e-6) {
+    B = 0.5 - 0.25 * one_6th * theta_sq;
+    A = 1.0 - theta_sq * one_6th * (1.0 - one_20th * theta_sq);
+  } else {
+    const float theta = std::sqrt(theta_sq);
+    const float inv_theta = 1.0 / theta;
+    A = std::sin(theta) * inv_theta;
+    B = (1 - std::cos(theta)) * (inv_theta * inv_theta);
+  }
+  M3 R;
+  {
+    const float wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+    R.a[0][0] = 1.0 - B * (wy2 + wz2);
+    R.a[1][1] = 1.0 - B * (wx2 + wz2);
+    R.a[2][2] = 1.0 - B * (wx2 + wy2);
+  }
+  {
+    const float a = A * w[2], b = B * (w[0] * w[1]);
+    R.a[0][1] = b - a;
+    R.a[1][0] = b + a;
+  }
+  {
+    const float a = A * w[1], b = B * (w[0] * w[2]);
+    R.a[0][2] = b + a;
+    R.a[2][0] = b - a;
+  }
+  {
+    const float a = A * w[0], b = B * (w[1] * w[2]);
+    R.a[1][2] = b - a;
+    R.a[2][1] = b + a;
+  }
+  return R;
+}
+
+// TooN Cholesky<N> (LDL^T, Cholesky.h) get_inverse().
+template <int N>
+void cholesky_inverse(const float* A, float* inv) {
+  float L[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) L[i][j] = A[i * N + j];
+  for (int col = 0; col < N; ++col) {
+    float inv_diag = 1;
+    for (int row = col; row < N; ++row) {
+      float val = L[row][col];
+      for (int col2 = 0; col2 < col; ++col2) val -= L[col2][col] * L[row][col2];
+      if (row == col) {
+        L[row][col] = val;
+        if (val == 0) break;
+        inv_diag = 1 / val;
+      } else {
+        L[col][row] = val;
+        L[row][col] = val * inv_diag;
+      }
+    }
+  }
+  for (int c = 0; c < N; ++c) {
+    float y[N], res[N];
+    for (int i = 0; i < N; ++i) {
+      float val = (i == c) ? 1.0f : 0.0f;
+      for (int j = 0; j < i; ++j) val -= L[i][j] * y[j];
+      y[i] = val;
+    }
+    for (int i = 0; i < N; ++i) y[i] /= L[i][i];
+    for (int i = N - 1; i >= 0; --i) {
+      float val = y[i];
+      for (int j = i + 1; j < N; ++j) val -= L[j][i] * res[j];
+      res[i] = val;
+    }
+    for (int i = 0; i < N; ++i) inv[i * N + c] = res[i];
+  }
+}
+
+// Replacement for TooN::SVD<6,6,float>::backsub on a symmetric matrix: cyclic Jacobi in double,
+// singular values below max/1e9 dropped (TooN condition_no).
+template <int N>
+void sym_pinv_solve(const float* A_, const float* b_, float* x_) {
+  double A[N][N], V[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      A[i][j] = 0.5 * ((double)A_[i * N + j] + (double)A_[j * N + i]);
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        if (A[p][q] == 0.0) continue;
+        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        double t = ((theta >= 0) ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < N; ++k) {
+          double akp = A[k][p], akq = A[k][q];
+          A[k][p] = cs * akp - sn * akq;
+          A[k][q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < N; ++k) {
+          double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = cs * apk - sn * aqk;
+          A[q][k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < N; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = cs * vkp - sn * vkq;
+          V[k][q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  double dmax = 0;
+  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(A[i][i]));
+  double x[N];
+  for (int i = 0; i < N; ++i) x[i] = 0;
+  for (int k = 0; k < N; ++k) {
+    double lam = A[k][k];
+    if (!(std::fabs(lam) * 1e9 > dmax)) continue;
+    double proj = 0;
+    for (int i = 0; i < N; ++i) proj += V[i][k] * (double)b_[i];
+    proj /= lam;
+    for (int i = 0; i < N; ++i) x[i] += V[i][k] * proj;
+  }
+  bool bad = false;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j)
+      if (std::isnan(A_[i * N + j])) bad = true;
+  for (int i = 0; i < N; ++i) x_[i] = bad ? std::numeric_limits<float>::quiet_NaN() : (float)x[i];
+}
+
+// ---- scale space (scale_space.cpp) -------------------------------------------------------------
+struct BoxGaussian {
+  int n = 3;
+  float sigma = 0, sigma_true = 0;
+  int widths[3] = {0, 0, 0};
+  std::vector<float> divisors[3];
+};
+
+// FastGaussian::precomputeDivisors (scale_space.cpp:130-171)
+void make_divisors(int rows, int cols, int d, std::vector<float>& div) {
+  div.assign((size_t)rows * cols, 0.f);
+  const int d2 = d / 2;
+  const float a = (float)d * d;
+  auto at = [&](int r, int c) -> float& { return div[(size_t)r * cols + c]; };
+  for (int row = 0; row < d2 + 1; ++row) {
+    for (int col = 0; col < d2 + 1; ++col) at(row, col) = (col + d2 + 1) * (row + d2 + 1);
+    for (int col = d2 + 1; col < cols - d2; ++col) at(row, col) = (float)d * (row + d2 + 1);
+    for (int col = cols - d2; col < cols; ++col) at(row, col) = (cols - col + d2) * (row + d2 + 1);
+  }
+  for (int row = d2 + 1; row < rows - d2; ++row) {
+    for (int col = 0; col < d2 + 1; ++col) at(row, col) = (col + d2 + 1) * (float)d;
+    for (int col = d2 + 1; col < cols - d2; ++col) at(row, col) = a;
+    for (int col = cols - d2; col < cols; ++col) at(row, col) = (cols - col + d2) * (float)d;
+  }
+  for (int row = rows - d2; row < rows; ++row) {
+    for (int col = 0; col < d2 + 1; ++col) at(row, col) = (rows - row + d2) * (col + d2 + 1);
+    for (int col = d2 + 1; col < cols - d2; ++col) at(row, col) = (rows - row + d2) * (float)d;
+    for (int col = cols - d2; col < cols; ++col) at(row, col) = (rows - row + d2) * (cols - col + d2);
+  }
+  for (size_t i = 0; i < div.size(); ++i) div[i] = 1.0 / div[i];
+}
+
+// FastGaussian::FastGaussian (scale_space.cpp:14-41)
+void make_filter(BoxGaussian& f, int rows, int cols, float sigma, int n) {
+  f.n = n;
+  f.sigma = sigma;
+  float w_ideal = sqrt(12.0 * sigma * sigma / float(n + 1));
+  int w_l = int(w_ideal);
+  if (int(w_l / 2) * 2 == w_l) --w_l;
+  int m = std::round((3 * n + 4 * n * w_l + n * w_l * w_l - 12 * sigma * sigma) / (4 + 4 * w_l));
+  int i;
+  for (i = 0; i < m; i++) f.widths[i] = w_l;
+  for (; i < n; i++) f.widths[i] = w_l + 2;
+  f.sigma_true = sqrt((m * w_l * w_l + (n - m) * (w_l + 2.0) * (w_l + 2.0) - n) / 12.0);
+  for (int k = 0; k < n; ++k) make_divisors(rows, cols, f.widths[k], f.divisors[k]);
+}
+
+// FastGaussian::createIntegralImage (scale_space.cpp:48-67)
+void integral_image(int rows, int cols, const float* in, float* ii) {
+  for (int row = 0; row < rows; ++row) {
+    float* o = ii + (size_t)row * cols;
+    const float* p = in + (size_t)row * cols;
+    o[0] = p[0];
+    for (int col = 1; col < cols; ++col) o[col] = o[col - 1] + p[col];
+  }
+  for (int row = 1; row < rows; ++row) {
+    const float* prev = ii + (size_t)(row - 1) * cols;
+    float* o = ii + (size_t)row * cols;
+    for (int col = 0; col < cols; ++col) o[col] += prev[col];
+  }
+}
+
+// FastGaussian::average (scale_space.cpp:69-128): nine regions, operand orders kept.
+void box_average(int rows, int cols, int d, const float* ii, const float* div, float* out) {
+  const int d2 = d / 2;
+  const float a = 1.0 / (d * d);
+  auto II = [&](int r) { return ii + (size_t)r * cols; };
+  for (int row = 0; row < d2 + 1; ++row) {
+    const float* dv = div + (size_t)row * cols;
+    const float* p = II(row + d2);
+    float* o = out + (size_t)row * cols;
+    for (int col = 0; col < d2 + 1; ++col) o[col] = p[col + d2] * dv[col];
+    for (int col = d2 + 1; col < cols - d2; ++col) o[col] = (p[col + d2] - p[col - d2 - 1]) * dv[col];
+    for (int col = cols - d2; col < cols; ++col) o[col] = (p[cols - 1] - p[col - d2 - 1]) * dv[col];
+  }
+  for (int row = d2 + 1; row < rows - d2; ++row) {
+    const float* dv = div + (size_t)row * cols;
+    const float* p1 = II(row + d2);
+    const float* p2 = II(row - d2 - 1);
+    float* o = out + (size_t)row * cols;
+    for (int col = 0; col < d2 + 1; ++col) o[col] = (p1[col + d2] - p2[col + d2]) * dv[col];
+    for (int col = d2 + 1; col < cols - d2; ++col) {
+      int c1 = col + d2, c2 = col - d2 - 1;
+      o[col] = (p1[c1] - p1[c2] - p2[c1] + p2[c2]) * a;
+    }
+    for (int col = cols - d2; col < cols; ++col) {
+      int c1 = cols - 1, c2 = col - d2 - 1;
+      o[col] = (p1[c1] - p1[c2] - p2[c1] + p2[c2]) * dv[col];
+    }
+  }
+  for (int row = rows - d2; row < rows; ++row) {
+    const float* dv = div + (size_t)row * cols;
+    const float* p1 = II(rows - 1);
+    const float* p2 = II(row - d2 - 1);
+    float* o = out + (size_t)row * cols;
+    for (int col = 0; col < d2 + 1; ++col) o[col] = (p1[col + d2] - p2[col + d2]) * dv[col];
+    for (int col = d2 + 1; col < cols - d2; ++col) {
+      int c1 = col + d2, c2 = col - d2 - 1;
+      o[col] = (p1[c1] - p2[c1] - p1[c2] + p2[c2]) * dv[col];
+    }
+    for (int col = cols - d2; col < cols; ++col) {
+      int c1 = cols - 1, c2 = col - d2 - 1;
+      o[col] = (p1[c1] - p2[c1] - p1[c2] + p2[c2]) * dv[col];
+    }
+  }
+}
+
+}  // namespace
+
+// ---- containers ---------------------------------------------------------------------------------
+struct orc_map {
+  int rows = 0, cols = 0;
+  uint64_t ts_us = 0;
+  float threshold = -1.0f;  // edge_map.cpp:17
+  unsigned matches = 0;
+  std::vector<orc_keyline> kl;
+  std::vector<int> mask;  // dense image-index -> keyline-index (the reference keeps a hash map, edge_map.hpp:131)
+};
+
+struct orc_ctx {
+  orc_params p;
+  BoxGaussian filter[2];
+  std::vector<float> scale[2], dog, mag, tmp_a, tmp_b;
+  // EdgeDetector state (edge_detector.hpp:84-92)
+  float det_threshold;  // config_->threshold (servo state)
+  int keylines_count = 0;
+  float auto_threshold;
+  std::vector<int> det_mask;
+  // DistanceField (core.hpp:73-78)
+  std::vector<int> df_id, df_dist;
+  orc_map* df_map = nullptr;
+  unsigned frame_count = 0;
+  // glue state (imu.hpp:171-187)
+  float Bg[3];
+  M3 W_Bg, RGBias, RGyro;
+  // estimateLs4Acceleration statics (core.cpp:287-293), per instance here
+  float ls4_V[3], ls4_V0[3], ls4_V1[3], ls4_V2[3], ls4_V3[3], ls4_T[5], ls4_Dt[4];
+};
+
+namespace {
+
+void smooth(orc_ctx* c, BoxGaussian& f, const float* in, std::vector<float>& out) {
+  // FastGaussian::smooth (scale_space.cpp:173-182)
+  const int R = c->p.rows, C = c->p.cols;
+  c->tmp_a.resize((size_t)R * C);
+  c->tmp_b.resize((size_t)R * C);
+  out.resize((size_t)R * C);
+  integral_image(R, C, in, c->tmp_a.data());
+  for (int i = 0; i < f.n - 1; ++i) {
+    box_average(R, C, f.widths[i], c->tmp_a.data(), f.divisors[i].data(), c->tmp_b.data());
+    integral_image(R, C, c->tmp_b.data(), c->tmp_a.data());
+  }
+  box_average(R, C, f.widths[f.n - 1], c->tmp_a.data(), f.divisors[f.n - 1].data(), out.data());
+}
+
+void scale_space_build(orc_ctx* c, const float* img) {
+  // ScaleSpace::build (scale_space.cpp:203-233)
+  const int R = c->p.rows, C = c->p.cols;
+  smooth(c, c->filter[0], img, c->scale[0]);
+  smooth(c, c->filter[1], img, c->scale[1]);
+  for (int row = 0; row < R; ++row)
+    for (int col = 0; col < C; ++col) {
+      size_t i = (size_t)row * C + col;
+      c->dog[i] = c->scale[1][i] - c->scale[0][i];
+    }
+  for (int row = 1; row < R - 1; ++row) {
+    const float* ic = &c->scale[0][(size_t)row * C];
+    const float* il = &c->scale[0][(size_t)(row - 1) * C];
+    const float* iu = &c->scale[0][(size_t)(row + 1) * C];
+    float* m = &c->mag[(size_t)row * C];
+    for (int col = 1; col < C - 1; ++col) {
+      float dx = ic[col + 1] - ic[col - 1];
+      float dy = iu[col] - il[col];
+      m[col] = dx * dx + dy * dy;
+    }
+  }
+}
+
+inline orc_keyline make_keyline(float px, float py, float gx, float gy, float ix, float iy) {
+  // KeyLine ctor (types/keyline.hpp:42-59)
+  orc_keyline k;
+  k.pos[0] = px; k.pos[1] = py;
+  k.pos_img[0] = ix; k.pos_img[1] = iy;
+  k.match_pos_img[0] = ix; k.match_pos_img[1] = iy;
+  k.gradient[0] = gx; k.gradient[1] = gy;
+  k.match_gradient[0] = 0; k.match_gradient[1] = 0;
+  k.gradient_norm = std::sqrt(gx * gx + gy * gy);
+  k.match_gradient_norm = 0.0;
+  k.rho = 1.0;
+  k.sigma_rho = 20.0;
+  k.id = -1; k.id_prev = -1; k.id_next = -1;
+  k.match_id = -1; k.match_id_forward = -1; k.match_id_keyframe = -1;
+  k.matches = 0;
+  return k;
+}
+
+// EdgeDetector::buildEdgeMap (edge_detector.cpp:45-123)
+orc_map* build_edge_map(orc_ctx* c, const float* img, uint64_t ts) {
+  const orc_params& P = c->p;
+  const int R = P.rows, C = P.cols;
+  scale_space_build(c, img);
+  orc_map* map = new orc_map;
+  map->rows = R; map->cols = C; map->ts_us = ts;
+  map->kl.reserve(P.keylines_max);
+  c->keylines_count = 0;
+
+  // Pinv = invert(Phi^T Phi) * Phi^T (edge_detector.cpp:55-68)
+  static_assert(PLANE_FIT == 2, "window is 5x5");
+  float Phi[25][3];
+  for (int row = -PLANE_FIT, k = 0; row <= PLANE_FIT; ++row)
+    for (int col = -PLANE_FIT; col <= PLANE_FIT; ++col, ++k) {
+      Phi[k][0] = col; Phi[k][1] = row; Phi[k][2] = 1;
+    }
+  M3 PtP;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float s = 0;
+      for (int k = 0; k < 25; ++k) s += Phi[k][i] * Phi[k][j];
+      PtP.a[i][j] = s;
+    }
+  M3 inv = m3_invert(PtP);
+  float Pinv[3][25];
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 25; ++k) {
+      float s = 0;
+      for (int j = 0; j < 3; ++j) s += inv.a[i][j] * Phi[k][j];
+      Pinv[i][k] = s;
+    }
+
+  float pn_threshold = float((2.0 * PLANE_FIT + 1.0) * (2.0 * PLANE_FIT + 1.0)) * P.pos_neg_threshold;
+  float thr = c->det_threshold;
+  float gradient_threshold_squared = (thr * MAX_IMAGE_VALUE * P.dog_threshold) * (thr * MAX_IMAGE_VALUE * P.dog_threshold);
+  float mag_threshold = (thr * MAX_IMAGE_VALUE) * (thr * MAX_IMAGE_VALUE);
+
+  int* mask = c->det_mask.data();
+  for (int row = PLANE_FIT; row < R - PLANE_FIT; ++row) {
+    int* km = mask + (size_t)row * C;
+    const float* mg = &c->mag[(size_t)row * C];
+    for (int col = PLANE_FIT; col < C - PLANE_FIT; ++col) {
+      int idx = col + row * C;
+      km[col] = -1;
+      if (mg[col] < mag_threshold) continue;
+
+      int pn = 0;
+      float Y[25];
+      for (int r = -PLANE_FIT, k = 0; r <= PLANE_FIT; ++r) {
+        const float* dp = &c->dog[(size_t)(row + r) * C];
+        for (int cc = -PLANE_FIT; cc <= PLANE_FIT; ++cc, ++k) {
+          float dog = dp[col + cc];
+          Y[k] = dog;
+          pn = (dog > 0.0) ? pn + 1 : pn - 1;
+        }
+      }
+      if (fabs((double)pn) > pn_threshold) continue;
+
+      float theta[3];
+      for (int i = 0; i < 3; ++i) {
+        float s = 0;
+        for (int k = 0; k < 25; ++k) s += Pinv[i][k] * Y[k];
+        theta[i] = s;
+      }
+      float tmp = theta[2] / (theta[0] * theta[0] + theta[1] * theta[1]);
+      float xs = -theta[0] * tmp;
+      float ys = -theta[1] * tmp;
+      if (fabs((double)xs) > 0.5 || fabs((double)ys) > 0.5) continue;
+      if (theta[0] * theta[0] + theta[1] * theta[1] < gradient_threshold_squared) continue;
+
+      float px = float(col) + xs, py = float(row) + ys;
+      map->kl.push_back(make_keyline(px, py, theta[0], theta[1], px - P.cx, py - P.cy));
+      km[col] = c->keylines_count;
+      if (++c->keylines_count >= P.keylines_max) {
+        int boundary = R * C;
+        for (++idx; idx < boundary; ++idx) mask[idx] = -1;
+        return map;
+      }
+    }
+  }
+  return map;
+}
+
+// EdgeDetector::nextKeylineIdx (edge_detector.cpp:138-165)
+int next_keyline_idx(const orc_ctx* c, const orc_map* map, int x, int y, int idx) {
+  const int C = c->p.cols;
+  const int* mask = c->det_mask.data();
+  auto M = [&](int yy, int xx) { return mask[(size_t)yy * C + xx]; };
+  float tx = -map->kl[idx].gradient[1];
+  float ty = map->kl[idx].gradient[0];
+  int i;
+  if (ty > 0.0) {
+    if (tx > 0.0) {
+      if ((i = M(y, x + 1)) >= 0) return i;
+      if ((i = M(y + 1, x)) >= 0) return i;
+      if ((i = M(y + 1, x + 1)) >= 0) return i;
+    } else {
+      if ((i = M(y, x - 1)) >= 0) return i;
+      if ((i = M(y + 1, x)) >= 0) return i;
+      if ((i = M(y + 1, x - 1)) >= 0) return i;
+    }
+  } else {
+    if (tx < 0.0) {
+      if ((i = M(y, x - 1)) >= 0) return i;
+      if ((i = M(y - 1, x)) >= 0) return i;
+      if ((i = M(y - 1, x - 1)) >= 0) return i;
+    } else {
+      if ((i = M(y, x + 1)) >= 0) return i;
+      if ((i = M(y - 1, x)) >= 0) return i;
+      if ((i = M(y - 1, x + 1)) >= 0) return i;
+    }
+  }
+  return -1;
+}
+
+// EdgeDetector::joinEdges (edge_detector.cpp:125-136)
+void join_edges(orc_ctx* c, orc_map* map) {
+  for (int idx = 0; idx < (int)map->kl.size(); ++idx) {
+    orc_keyline& k = map->kl[idx];
+    int x = cvtt(k.pos[0] + 0.5);
+    int y = cvtt(k.pos[1] + 0.5);
+    int id_next = next_keyline_idx(c, map, x, y, idx);
+    if (id_next < 0) continue;
+    map->kl[id_next].id_prev = idx;
+    k.id_next = id_next;
+  }
+}
+
+// EdgeDetector::tuneThreshold (edge_detector.cpp:167-186)
+void tune_threshold(orc_ctx* c, orc_map* map) {
+  const int n = (int)map->kl.size();
+  if (n == 0) {  // reference dereferences element 0 of an empty vector: keep previous value
+    map->threshold = c->auto_threshold;
+    return;
+  }
+  float max_dog = map->kl[0].gradient_norm;
+  float min_dog = max_dog;
+  for (int idx = 1; idx < n; ++idx) {
+    const orc_keyline& k = map->kl[idx];
+    if (max_dog < k.gradient_norm) max_dog = k.gradient_norm;
+    if (min_dog > k.gradient_norm) min_dog = k.gradient_norm;
+  }
+  int histogram[NUM_BINS + 1] = {0};  // +1: the reference reads one past the end
+  for (int idx = 0; idx < n; ++idx) {
+    int i = cvtt(NUM_BINS * (max_dog - map->kl[idx].gradient_norm) / (max_dog - min_dog));
+    i = (i > NUM_BINS - 1) ? NUM_BINS - 1 : i;
+    i = (i < 0) ? 0 : i;
+    ++histogram[i];
+  }
+  int i = 0;
+  for (int a = 0; i < NUM_BINS && a < c->p.keylines_max; i++, a += histogram[i]);
+  c->auto_threshold = max_dog - float(i * (max_dog - min_dog)) / float(NUM_BINS);
+  map->threshold = c->auto_threshold;
+}
+
+inline int get_index(const orc_params& P, float frow, float fcol) {
+  // EdgeMap::getIndex / DistanceField::getIndex (edge_map.hpp:119-124, core.hpp:66-71);
+  // rows_/cols_ are unsigned there, so negative ints fail the first comparison.
+  int row = cvtt(std::round(frow));
+  int col = cvtt(std::round(fcol));
+  if ((unsigned)row >= (unsigned)P.rows || row < 0 || (unsigned)col >= (unsigned)P.cols || col < 0) return -1;
+  return row * P.cols + col;
+}
+
+// EdgeMap::searchMatch (edge_map.cpp:101-184) on `old_map`, for keyline `kq` of the other map.
+int search_match(const orc_ctx* c, const orc_map* old_map, const orc_keyline& kq, const float vel[3],
+                 const M3& Rvel, const M3& Rback, float max_radius) {
+  const orc_params& P = c->p;
+  const float cang_min_edge = std::cos(P.match_threshold_angle * M_PI / 180.0);
+
+  float v3[3] = {kq.pos_img[0], kq.pos_img[1], P.fm};
+  float p_m3[3];
+  m3_vec(Rback, v3, p_m3);
+  float pmx = p_m3[0] * P.fm / p_m3[2];
+  float pmy = p_m3[1] * P.fm / p_m3[2];
+  float k_rho = kq.rho * P.fm / p_m3[2];
+
+  float pi0x = pmx + P.cx;
+  float pi0y = pmy + P.cy;
+
+  float t_x = -(vel[0] * P.fm - vel[2] * pmx);
+  float t_y = -(vel[1] * P.fm - vel[2] * pmy);
+  float norm_t = std::sqrt(t_x * t_x + t_y * t_y);
+
+  float DrDv[3] = {P.fm, P.fm, -(pmx + pmy)};
+  float rowv[3];
+  for (int j = 0; j < 3; ++j) {
+    float s = 0;
+    for (int k = 0; k < 3; ++k) s += DrDv[k] * Rvel.a[k][j];
+    rowv[j] = s;
+  }
+  float sigma2_t = 0;
+  for (int j = 0; j < 3; ++j) sigma2_t += rowv[j] * DrDv[j];
+
+  float dq_min = 0.0, dq_max = 0.0, dq_rho = 0.0;
+  int t_steps = 0;
+  if (norm_t > 1e-6) {
+    t_x /= norm_t;
+    t_y /= norm_t;
+    dq_rho = norm_t * k_rho;
+    dq_min = std::max(float(0.0), norm_t * (k_rho - kq.sigma_rho)) - P.pixel_uncertainty_match;
+    dq_max = std::min(max_radius, norm_t * (k_rho + kq.sigma_rho)) + P.pixel_uncertainty_match;
+    if (dq_rho > dq_max) {
+      dq_rho = 0.5 * (dq_max + dq_min);
+      t_steps = cvtt(dq_rho + 0.5);
+    } else {
+      t_steps = cvtt(std::max(dq_max - dq_rho, dq_rho - dq_min));
+    }
+  } else {
+    t_x = kq.gradient[0];
+    t_y = kq.gradient[1];
+    norm_t = kq.gradient_norm;
+    t_x /= norm_t;
+    t_y /= norm_t;
+    norm_t = 1.0;
+    dq_min = -max_radius - P.pixel_uncertainty_match;
+    dq_max = max_radius + P.pixel_uncertainty_match;
+    dq_rho = 0.0;
+    t_steps = cvtt(dq_max);
+  }
+
+  float tn = dq_rho;
+  float tp = dq_rho + 1;
+  for (int t_i = 0; t_i < t_steps; ++t_i, ++tp, --tn) {
+    for (int i_idx = 0; i_idx < 2; ++i_idx) {
+      float t;
+      if (i_idx) {
+        t = tp;
+        if (t > dq_max) continue;
+      } else {
+        t = tn;
+        if (t < dq_min) continue;
+      }
+      int idx = get_index(P, t_y * t + pi0y, t_x * t + pi0x);
+      if (idx < 0) continue;
+      int cand = old_map->mask[idx];
+      if (cand < 0) continue;
+      const orc_keyline& k = old_map->kl[cand];
+      float cang = (k.gradient[0] * kq.gradient[0] + k.gradient[1] * kq.gradient[1]) / (k.gradient_norm * kq.gradient_norm);
+      if (cang < cang_min_edge || std::fabs(k.gradient_norm / kq.gradient_norm - 1.0) > P.match_threshold_norm) continue;
+      float v_rho_dr = (P.pixel_uncertainty_match * P.pixel_uncertainty_match + k.sigma_rho * k.sigma_rho * norm_t * norm_t +
+                        sigma2_t * k.rho * k.rho);
+      if ((t - norm_t * k.rho) * (t - norm_t * k.rho) > v_rho_dr) continue;
+      return cand;
+    }
+  }
+  return -1;
+}
+
+// Core::tryVel + calculatefJ + testfk (core.cpp:39-148)
+float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float vel[3], float sigma_rho_min,
+              float* residuals) {
+  const orc_params& P = c->p;
+  const orc_map* nm = c->df_map;
+  float score = 0.0;
+  float J00 = 0, J11 = 0, J22 = 0, J01 = 0, J02 = 0, J12 = 0, F0 = 0, F1 = 0, F2 = 0;
+  float fi = 0.0f;  // reference leaves this uninitialised: carry-forward semantics (header note)
+  const unsigned min_matches = std::min(P.min_match_threshold, c->frame_count);
+  for (int idx = 0; idx < (int)map->kl.size(); ++idx) {
+    orc_keyline& k = map->kl[idx];
+    k.match_id_forward = -1;
+    if (map->threshold > 0.0 && k.gradient_norm < map->threshold) continue;
+    if (k.sigma_rho > sigma_rho_min || k.matches < min_matches) continue;
+
+    float weight = 1.0;
+    if (residuals[idx] > P.reweight_distance) weight = P.reweight_distance / residuals[idx];
+
+    float z_p = 1.0 / k.rho + vel[2];
+    float f;
+    if (z_p <= 0.0) {
+      f = (1.0 / k.sigma_rho) * P.search_range * weight;
+      score += f * f;
+      continue;
+    }
+    float rho_p = 1.0 / z_p;
+    float p_x = rho_p * (vel[0] * P.fm - vel[2] * k.pos_img[0]) + k.pos_img[0];
+    float p_y = rho_p * (vel[1] * P.fm - vel[2] * k.pos_img[1]) + k.pos_img[1];
+    float p_xc = p_x + P.cx;
+    float p_yc = p_y + P.cy;
+    int x = cvtt(p_xc + 0.5);
+    int y = cvtt(p_yc + 0.5);
+    if (x < 1 || y < 1 || (unsigned)x >= (unsigned)P.cols - 1 || (unsigned)y >= (unsigned)P.rows - 1) {
+      f = (1.0 / k.sigma_rho) * P.search_range * weight;
+      score += f * f;
+      continue;
+    }
+    float df_dx, df_dy;
+    {  // calculatefJ
+      int f_inx = y * P.cols + x;
+      int id = c->df_id[f_inx];
+      bool matched = false;
+      if (id >= 0) {
+        const orc_keyline& kn = nm->kl[id];
+        float norm_squared = k.gradient_norm * k.gradient_norm;  // testfk(kn, k, thr): _keyline2 = k
+        float dot_product = kn.gradient[0] * k.gradient[0] + kn.gradient[1] * k.gradient[1];
+        if (!(std::fabs(dot_product - norm_squared) > P.match_treshold * norm_squared)) {
+          float dx = p_xc - kn.pos[0];
+          float dy = p_yc - kn.pos[1];
+          float gnx = kn.gradient[0] / kn.gradient_norm;
+          float gny = kn.gradient[1] / kn.gradient_norm;
+          fi = (dx * gnx + dy * gny);
+          df_dx = gnx / k.sigma_rho;
+          df_dy = gny / k.sigma_rho;
+          k.match_id_forward = id;
+          f = fi / k.sigma_rho;
+          matched = true;
+        }
+      }
+      if (!matched) {
+        df_dx = 0.0;
+        df_dy = 0.0;
+        f = P.search_range / k.sigma_rho;
+      }
+    }
+    f *= weight;
+    score += f * f;
+    float jx = rho_p * P.fm * df_dx * weight;
+    float jy = rho_p * P.fm * df_dy * weight;
+    float jz = -rho_p * (p_x * df_dx + p_y * df_dy) * weight;
+    J00 += jx * jx; J11 += jy * jy; J22 += jz * jz;
+    J01 += jx * jy; J02 += jx * jz; J12 += jy * jz;
+    F0 += jx * f; F1 += jy * f; F2 += jz * f;
+    residuals[idx] = std::fabs(fi);
+  }
+  JtJ[0] = J00; JtJ[1] = J01; JtJ[2] = J02;
+  JtJ[3] = J01; JtJ[4] = J11; JtJ[5] = J12;
+  JtJ[6] = J02; JtJ[7] = J12; JtJ[8] = J22;
+  JtF[0] = F0; JtF[1] = F1; JtF[2] = F2;
+  return score;
+}
+
+float estimate_quantile(const orc_map* m, float percentile, int num_bins) {
+  // EdgeMap::estimateQuantile (edge_map.cpp:39-56)
+  std::vector<int> histogram(num_bins, 0);
+  const int n = (int)m->kl.size();
+  for (int idx = 0; idx < n; ++idx) {
+    int i = cvtt(num_bins * (m->kl[idx].sigma_rho - RHO_MIN) / (RHO_MAX - RHO_MIN));
+    i = (i > num_bins - 1) ? (num_bins - 1) : i;
+    i = (i < 0) ? 0 : i;
+    ++histogram[i];
+  }
+  float sigma_rho = 1e3;
+  for (int i = 0, a = 0; i < num_bins; ++i) {
+    if (a > percentile * n) {
+      sigma_rho = float(i) * (RHO_MAX - RHO_MIN) / float(num_bins) + RHO_MIN;
+      break;
+    }
+    a += histogram[i];
+  }
+  return sigma_rho;
+}
+
+float minimize_vel(orc_ctx* c, orc_map* map, float vel[3], M3& Rvel, int* accept_mask, float* srm_out) {
+  // Core::minimizeVel (core.cpp:150-189)
+  const orc_params& P = c->p;
+  float sigma_rho_min = estimate_quantile(map, P.quantile_cutoff, P.quantile_num_bins);
+  if (srm_out) *srm_out = sigma_rho_min;
+  M3 JtJ, ApI, JtJnew;
+  float JtF[3], JtFnew[3], h[3], Vnew[3];
+  std::vector<float> residuals(map->kl.size() + 1, 0.0f);
+  float F = try_vel(c, map, &JtJ.a[0][0], JtF, vel, sigma_rho_min, residuals.data());
+  float v = 2.0;
+  float tau = 1e-3;
+  float mx = JtJ.a[0][0];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      if (JtJ.a[i][j] > mx) mx = JtJ.a[i][j];
+  float u = tau * mx;
+  float gain;
+  int mask = 0;
+  for (unsigned iter = 0; iter < P.iterations; ++iter) {
+    ApI = JtJ;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) ApI.a[i][j] = JtJ.a[i][j] + ((i == j) ? 1.0f * u : 0.0f * u);
+    float neg[3] = {-JtF[0], -JtF[1], -JtF[2]};
+    M3 inv = m3_invert(ApI);
+    m3_vec(inv, neg, h);
+    for (int i = 0; i < 3; ++i) Vnew[i] = vel[i] + h[i];
+    float Fnew = try_vel(c, map, &JtJnew.a[0][0], JtFnew, Vnew, sigma_rho_min, residuals.data());
+    double den = 0;
+    for (int i = 0; i < 3; ++i) den += (0.5 * h[i]) * (double)(u * h[i] - JtF[i]);
+    gain = (F - Fnew) / den;
+    if (gain > 0.0) {
+      F = Fnew;
+      for (int i = 0; i < 3; ++i) { vel[i] = Vnew[i]; JtF[i] = JtFnew[i]; }
+      JtJ = JtJnew;
+      u *= std::max(0.33, 1.0 - ((2.0 * gain - 1.0) * (2.0 * gain - 1.0) * (2.0 * gain - 1.0)));
+      v = 2.0;
+      mask |= (1 << iter);
+    } else {
+      u *= v;
+      v *= 2.0;
+    }
+  }
+  Rvel = m3_invert(JtJ);
+  if (accept_mask) *accept_mask = mask;
+  return F;
+}
+
+int forward_match(orc_map* old_map, orc_map* new_map) {
+  // EdgeMap::forwardMatch (edge_map.cpp:73-99)
+  unsigned num = 0;
+  for (int idx = 0; idx < (int)old_map->kl.size(); ++idx) {
+    const orc_keyline& k = old_map->kl[idx];
+    const int idx_f = k.match_id_forward;
+    if (idx_f < 0) continue;
+    orc_keyline& t = new_map->kl[idx_f];
+    if (t.match_id >= 0 && t.rho > k.rho) continue;
+    t.rho = k.rho;
+    t.sigma_rho = k.sigma_rho;
+    t.matches = k.matches + 1;
+    t.match_id = idx;
+    t.match_pos_img[0] = k.pos_img[0]; t.match_pos_img[1] = k.pos_img[1];
+    t.match_gradient[0] = k.gradient[0]; t.match_gradient[1] = k.gradient[1];
+    t.match_gradient_norm = k.gradient_norm;
+    t.match_id_keyframe = k.match_id_keyframe;
+    ++num;
+  }
+  new_map->matches = num;
+  return num;
+}
+
+// Core::extRotVel (core.cpp:191-261); sums in row order like Phi.T()*Phi.
+int ext_rot_vel(orc_ctx* c, const float vel[3], float Wx[36], float X[6], float JtF_out[6]) {
+  const orc_params& P = c->p;
+  const orc_map* m = c->df_map;
+  float JtJ[6][6] = {{0}};
+  float JtF[6] = {0};
+  for (int idx = 0; idx < (int)m->kl.size(); ++idx) {
+    const orc_keyline& k = m->kl[idx];
+    if (k.match_id < 0) continue;
+    float u_x = k.gradient[0] / k.gradient_norm;
+    float u_y = k.gradient[1] / k.gradient_norm;
+    float rho_t = 1.0 / (1.0 / k.rho + vel[2]);
+    float qt_x = k.match_pos_img[0] + rho_t * (vel[0] * P.fm - vel[2] * k.match_pos_img[0]);
+    float qt_y = k.match_pos_img[1] + rho_t * (vel[1] * P.fm - vel[2] * k.match_pos_img[1]);
+    float q_x = k.pos_img[0];
+    float q_y = k.pos_img[1];
+    float row[6];
+    row[0] = u_x * rho_t * P.fm;
+    row[1] = u_y * rho_t * P.fm;
+    row[2] = u_x * (-rho_t * q_x) + u_y * (-rho_t * q_y);
+    row[3] = -u_x * q_x * q_y / P.fm - u_y * (P.fm + q_y * q_y / P.fm);
+    row[4] = u_y * q_x * q_y / P.fm + u_x * (P.fm + q_x * q_x / P.fm);
+    row[5] = -u_x * q_y + u_y * q_x;
+    float Y = u_x * (q_x - qt_x) + u_y * (q_y - qt_y);
+    float dqvel = u_x * (vel[0] * P.fm - vel[2] * k.match_pos_img[0]) + u_y * (vel[1] * P.fm - vel[2] * k.match_pos_img[1]);
+    float s_y = std::sqrt(k.sigma_rho * k.sigma_rho * dqvel * dqvel + P.pixel_uncertainty * P.pixel_uncertainty);
+    float weight = 1.0;
+    if (std::fabs(Y) > P.reweight_distance) weight = std::fabs(Y) / P.reweight_distance;
+    float dv = s_y * weight;
+    for (int i = 0; i < 6; ++i) row[i] /= dv;
+    Y /= dv;
+    for (int i = 0; i < 6; ++i) {
+      for (int j = 0; j < 6; ++j) JtJ[i][j] += row[i] * row[j];
+      JtF[i] += row[i] * Y;
+    }
+  }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) Wx[i * 6 + j] = JtJ[i][j];
+  if (JtF_out)
+    for (int i = 0; i < 6; ++i) JtF_out[i] = JtF[i];
+  sym_pinv_solve<6>(Wx, JtF, X);
+  for (int i = 0; i < 6; ++i)
+    if (std::isnan(X[i])) return 0;
+  return 1;
+}
+
+int directed_match(orc_ctx* c, orc_map* nmap, orc_map* omap, const float vel_[3], const M3& Rvel_, const M3& Rback,
+                   int* kf_matches, float max_radius) {
+  // EdgeMap::directedMatch (edge_map.cpp:186-218)
+  nmap->matches = 0;
+  *kf_matches = 0;
+  float vel[3];
+  m3_vec(Rback, vel_, vel);
+  M3 Rvel = m3_mul(m3_mul(Rback, Rvel_), m3_T(Rback));
+  for (int idx = 0; idx < (int)nmap->kl.size(); ++idx) {
+    orc_keyline& k = nmap->kl[idx];
+    int im = search_match(c, omap, k, vel, Rvel, Rback, max_radius);
+    if (im < 0) continue;
+    const orc_keyline& mk = omap->kl[im];
+    k.rho = mk.rho;
+    k.sigma_rho = mk.sigma_rho;
+    k.match_id = im;
+    k.matches = mk.matches + 1;
+    k.match_pos_img[0] = mk.pos_img[0]; k.match_pos_img[1] = mk.pos_img[1];
+    k.match_gradient[0] = mk.gradient[0]; k.match_gradient[1] = mk.gradient[1];
+    k.match_gradient_norm = mk.gradient_norm;
+    k.match_id_keyframe = mk.match_id_keyframe;
+    if (k.match_id_keyframe >= 0) ++(*kf_matches);
+    ++nmap->matches;
+  }
+  return nmap->matches;
+}
+
+int regularize_1iter(const orc_ctx* c, orc_map* m, float thr) {
+  // EdgeMap::regularize1Iter (edge_map.cpp:220-259)
+  (void)c;
+  const int n = (int)m->kl.size();
+  int r_num = 0;
+  std::vector<float> r(n), s(n);
+  std::vector<char> set(n, 0);
+  for (int idx = 0; idx < n; ++idx) {
+    orc_keyline& k = m->kl[idx];
+    if (k.id_next < 0 || k.id_prev < 0) continue;
+    const orc_keyline& kn = m->kl[k.id_next];
+    const orc_keyline& kp = m->kl[k.id_prev];
+    if ((kn.rho - kp.rho) * (kn.rho - kp.rho) > (kn.sigma_rho * kn.sigma_rho + kp.sigma_rho * kp.sigma_rho)) continue;
+    float alpha = (kn.gradient[0] * kp.gradient[0] + kn.gradient[1] * kp.gradient[1]) / (kn.gradient_norm * kp.gradient_norm);
+    if (alpha < thr) continue;
+    alpha = (alpha - thr) / (1.0 - thr);
+    alpha /= std::fabs(kn.rho - kp.rho) / (kn.sigma_rho + kp.sigma_rho) + 1.0;
+    float wr = 1.0 / (k.sigma_rho * k.sigma_rho);
+    float wrn = alpha / (kn.sigma_rho * kn.sigma_rho);
+    float wrp = alpha / (kp.sigma_rho * kp.sigma_rho);
+    r[idx] = (k.rho * wr + kn.rho * wrn + kp.rho * wrp) / (wr + wrn + wrp);
+    s[idx] = (k.sigma_rho * wr + kn.sigma_rho * wrn + kp.sigma_rho * wrp) / (wr + wrn + wrp);
+    set[idx] = 1;
+    ++r_num;
+  }
+  for (int idx = 0; idx < n; ++idx)
+    if (set[idx]) {
+      m->kl[idx].rho = r[idx];
+      m->kl[idx].sigma_rho = s[idx];
+    }
+  return r_num;
+}
+
+void update_inverse_depth_arlu(const orc_params& P, orc_keyline& k, const float vel[3]) {
+  // Core::updateInverseDepthARLU (core.cpp:424-456)
+  float qx = k.pos_img[0], qy = k.pos_img[1];
+  float q0x = k.match_pos_img[0], q0y = k.match_pos_img[1];
+  float v_rho = k.sigma_rho * k.sigma_rho;
+  float ux = k.match_gradient[0] / k.match_gradient_norm;
+  float uy = k.match_gradient[1] / k.match_gradient_norm;
+  float Y = ux * (qx - q0x) + uy * (qy - q0y);
+  float H = ux * (vel[0] * P.fm - vel[2] * q0x) + uy * (vel[1] * P.fm - vel[2] * q0y);
+  float rho_p = 1.0 / (1.0 / k.rho + vel[2]);
+  float F = 1.0 / (1.0 + k.rho * vel[2]);
+  F *= F;
+  float p_p = F * v_rho * F + P.reshape_q_abs * P.reshape_q_abs;
+  float e = Y - H * rho_p;
+  float S = H * p_p * H + P.pixel_uncertainty * P.pixel_uncertainty;
+  float K = p_p * H * (1.0 / S);
+  k.rho = rho_p + K * e;
+  v_rho = (1.0 - K * H) * p_p;
+  k.sigma_rho = std::sqrt(v_rho);
+  if (k.rho < RHO_MIN) {
+    k.sigma_rho += RHO_MIN - k.rho;
+    k.rho = RHO_MIN;
+  } else if (k.rho > RHO_MAX) {
+    k.rho = RHO_MAX;
+  } else if (std::isnan(k.rho) || std::isnan(k.sigma_rho) || std::isinf(k.rho) || std::isinf(k.sigma_rho)) {
+    k.rho = RHO_INIT;
+    k.sigma_rho = RHO_MAX;
+  }
+}
+
+// Core::gyroBiasCorrection (core.cpp:264-284), dgbias == 0 on entry as in the reference.
+void gyro_bias_correction(float X[6], float Wx[36], M3& Wb, const M3& Rg, const M3& Rb, float dgbias_out[3]) {
+  float dgbias[3] = {0, 0, 0};
+  const M3 Wg = m3_invert(Rg);
+  Wb = m3_invert(m3_add(m3_invert(Wb), Rb));
+  float Wxb[36];
+  std::memcpy(Wxb, Wx, sizeof(Wxb));
+  M3 iWgWb = m3_invert(m3_add(Wg, Wb));
+  M3 add = m3_mul(Wg, m3_sub(m3_identity(), m3_mul(iWgWb, Wg)));
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Wxb[(3 + i) * 6 + 3 + j] += add.a[i][j];
+  float X1[6];
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+    for (int k = 0; k < 6; ++k) s += Wx[i * 6 + k] * X[k];
+    X1[i] = s;
+  }
+  {
+    float t[3];
+    M3 m = m3_mul(m3_mul(Wg, iWgWb), Wb);
+    m3_vec(m, dgbias, t);
+    for (int i = 0; i < 3; ++i) X1[3 + i] += t[i];
+  }
+  float inv[36];
+  cholesky_inverse<6>(Wxb, inv);
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+    for (int k = 0; k < 6; ++k) s += inv[i * 6 + k] * X1[k];
+    X[i] = s;
+  }
+  {
+    float a[3], b[3], sum[3];
+    float xw[3] = {X[3], X[4], X[5]};
+    m3_vec(Wg, xw, a);
+    m3_vec(Wb, dgbias, b);
+    for (int i = 0; i < 3; ++i) sum[i] = a[i] + b[i];
+    m3_vec(iWgWb, sum, dgbias);
+  }
+  Wb = m3_add(Wg, Wb);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Wx[(3 + i) * 6 + 3 + j] += Wg.a[i][j];
+  for (int i = 0; i < 3; ++i) dgbias_out[i] = dgbias[i];
+}
+
+}  // namespace
+
+// ---- C API ---------------------------------------------------------------------------------------
+extern "C" {
+
+void orc_default_params(orc_params* p, int rows, int cols) {
+  // camera.hpp:25-45 (EuRoC) scaled is NOT done here: caller sets fm/cx/cy; defaults are EuRoC's.
+  p->rows = rows; p->cols = cols;
+  float fx = 458.654, fy = 457.296;
+  p->fm = 0.5 * (fx + fy);
+  p->cx = 367.215; p->cy = 248.375;
+  p->keylines_ref = 12000; p->keylines_max = 16000;
+  p->pos_neg_threshold = 0.4; p->dog_threshold = 0.095259868922420;
+  p->threshold = 0.01; p->gain = 5e-7; p->max_threshold = 0.5; p->min_threshold = 0.005;
+  p->search_range = 40.0; p->reweight_distance = 2.0; p->match_treshold = 0.5;
+  p->min_match_threshold = 0; p->iterations = 5; p->global_min_matches_threshold = 500;
+  p->pixel_uncertainty = 1; p->quantile_cutoff = 0.9; p->quantile_num_bins = 100; p->reshape_q_abs = 1e-4;
+  p->pixel_uncertainty_match = 2.0; p->match_threshold_norm = 1.0; p->match_threshold_angle = 45.0;
+  p->regularization_threshold = 0.5;
+  p->gyro_std_dev = 1.6968e-04; p->gyro_bias_std_dev = 1.9393e-05;
+}
+
+void orc_reset_state(orc_ctx* c) {
+  c->Bg[0] = c->Bg[1] = c->Bg[2] = 0;
+  c->RGBias = m3_identity();
+  c->RGyro = m3_identity();
+  c->W_Bg = m3_invert(m3_scale(c->RGBias, 100.0f));  // imu.hpp:181
+  orc_ls4_reset(c);
+}
+
+orc_ctx* orc_create(const orc_params* p) {
+  orc_ctx* c = new orc_ctx;
+  c->p = *p;
+  const size_t n = (size_t)p->rows * p->cols;
+  make_filter(c->filter[0], p->rows, p->cols, 3.56359, 3);                           // scale_space.cpp:186
+  make_filter(c->filter[1], p->rows, p->cols, c->filter[0].sigma_true * 1.2599, 3);  // scale_space.cpp:186
+  c->dog.assign(n, 0.f);
+  c->mag.assign(n, 0.f);
+  c->det_threshold = p->threshold;
+  c->auto_threshold = p->threshold;  // edge_detector.cpp:20
+  c->det_mask.assign(n, -1);
+  c->df_id.assign(n, -1);
+  c->df_dist.assign(n, std::numeric_limits<int>::max());
+  orc_reset_state(c);
+  return c;
+}
+
+void orc_destroy(orc_ctx* c) { delete c; }
+
+void orc_scale_space(orc_ctx* c, const float* img, float* s0, float* s1, float* dog, float* mag) {
+  scale_space_build(c, img);
+  const size_t nb = (size_t)c->p.rows * c->p.cols * sizeof(float);
+  if (s0) std::memcpy(s0, c->scale[0].data(), nb);
+  if (s1) std::memcpy(s1, c->scale[1].data(), nb);
+  if (dog) std::memcpy(dog, c->dog.data(), nb);
+  if (mag) std::memcpy(mag, c->mag.data(), nb);
+}
+
+void orc_integral_image(int rows, int cols, const float* in, float* out) { integral_image(rows, cols, in, out); }
+
+void orc_box_average(int rows, int cols, int d, const float* ii, float* out) {
+  std::vector<float> div;
+  make_divisors(rows, cols, d, div);
+  box_average(rows, cols, d, ii, div.data(), out);
+}
+
+int orc_filter_width(orc_ctx* c, int filter, int pass) { return c->filter[filter].widths[pass]; }
+
+orc_map* orc_detect(orc_ctx* c, const float* img, uint64_t ts_us) {
+  // EdgeDetector::detect (edge_detector.cpp:30-43)
+  orc_params& P = c->p;
+  if (P.gain > 0) {
+    c->det_threshold -= P.gain * float(P.keylines_ref - c->keylines_count);
+    c->det_threshold = (c->det_threshold > P.max_threshold) ? P.max_threshold
+                       : ((c->det_threshold < P.min_threshold) ? P.min_threshold : c->det_threshold);
+  }
+  orc_map* map = build_edge_map(c, img, ts_us);
+  join_edges(c, map);
+  tune_threshold(c, map);
+  map->mask = c->det_mask;  // the map's own image-index -> keyline-index table (edge_detector.cpp:112)
+  return map;
+}
+
+float orc_detector_threshold(orc_ctx* c) { return c->det_threshold; }
+float orc_detector_auto_threshold(orc_ctx* c) { return c->auto_threshold; }
+void orc_detector_mask(orc_ctx* c, int* out) { std::memcpy(out, c->det_mask.data(), c->det_mask.size() * sizeof(int)); }
+
+int orc_map_size(orc_map* m) { return (int)m->kl.size(); }
+float orc_map_threshold(orc_map* m) { return m->threshold; }
+void orc_map_set_threshold(orc_map* m, float t) { m->threshold = t; }
+void orc_map_get_keylines(orc_map* m, orc_keyline* out) {
+  if (!m->kl.empty()) std::memcpy(out, m->kl.data(), m->kl.size() * sizeof(orc_keyline));
+}
+void orc_map_set_keylines(orc_map* m, const orc_keyline* in, int n) { m->kl.assign(in, in + n); }
+void orc_map_get_mask(orc_map* m, int* out) { std::memcpy(out, m->mask.data(), m->mask.size() * sizeof(int)); }
+orc_map* orc_map_clone(orc_map* m) { return new orc_map(*m); }
+void orc_map_free(orc_map* m) { delete m; }
+
+void orc_build_distance_field(orc_ctx* c, orc_map* map) {
+  // DistanceField::build (core.hpp:37-59)
+  const orc_params& P = c->p;
+  c->df_map = map;
+  const int size = P.rows * P.cols;
+  for (int i = 0; i < size; ++i) c->df_id[i] = -1;
+  for (int idx = 0; idx < (int)map->kl.size(); ++idx) {
+    const orc_keyline& k = map->kl[idx];
+    if (map->threshold > 0.0 && k.gradient_norm < map->threshold) continue;
+    for (int r = cvtt(-P.search_range); r < P.search_range; ++r) {
+      int fi = get_index(P, (k.gradient[1] / k.gradient_norm) * float(r) + k.pos[1],
+                         (k.gradient[0] / k.gradient_norm) * float(r) + k.pos[0]);
+      if (fi < 0) continue;
+      if (c->df_id[fi] >= 0 && c->df_dist[fi] < std::abs(r)) continue;
+      c->df_dist[fi] = std::abs(r);
+      c->df_id[fi] = idx;
+    }
+  }
+}
+
+void orc_distance_field(orc_ctx* c, int* id_out, int* dist_out) {
+  const size_t n = c->df_id.size();
+  if (id_out) std::memcpy(id_out, c->df_id.data(), n * sizeof(int));
+  if (dist_out) std::memcpy(dist_out, c->df_dist.data(), n * sizeof(int));
+}
+
+void orc_rotate_keylines(orc_ctx* c, orc_map* m, const float R_[9]) {
+  // EdgeMap::rotateKeylines (edge_map.cpp:58-71). makeVector(float,float,1.0) / (..,0.0) mix
+  // float and double arguments -> TooN's double overload -> the product is formed in double.
+  const float fm = c->p.fm;
+  for (orc_keyline& k : m->kl) {
+    double v[3] = {(double)(k.pos_img[0] / fm), (double)(k.pos_img[1] / fm), 1.0};
+    float q[3];
+    for (int i = 0; i < 3; ++i) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j) s += (double)R_[i * 3 + j] * v[j];
+      q[i] = (float)s;
+    }
+    if (fabs((double)q[2]) > 0.0) {
+      k.pos_img[0] = q[0] / q[2] * fm;
+      k.pos_img[1] = q[1] / q[2] * fm;
+      k.rho /= q[2];
+      k.sigma_rho /= q[2];
+    }
+    double g[3] = {(double)k.gradient[0], (double)k.gradient[1], 0.0};
+    for (int i = 0; i < 3; ++i) {
+      double s = 0;
+      for (int j = 0; j < 3; ++j) s += (double)R_[i * 3 + j] * g[j];
+      q[i] = (float)s;
+    }
+    k.gradient[0] = q[0];
+    k.gradient[1] = q[1];
+  }
+}
+
+float orc_estimate_quantile(orc_map* m, float percentile, int num_bins) { return estimate_quantile(m, percentile, num_bins); }
+
+float orc_try_vel(orc_ctx* c, orc_map* m, const float vel[3], float sigma_rho_min, float* residuals, float JtJ[9],
+                  float JtF[3]) {
+  return try_vel(c, m, JtJ, JtF, vel, sigma_rho_min, residuals);
+}
+
+float orc_minimize_vel(orc_ctx* c, orc_map* m, float vel[3], float Rvel[9], int* accept_mask, float* srm) {
+  M3 R;
+  float F = minimize_vel(c, m, vel, R, accept_mask, srm);
+  m3_to(R, Rvel);
+  return F;
+}
+
+int orc_forward_match(orc_map* o, orc_map* n) { return forward_match(o, n); }
+
+int orc_ext_rot_vel(orc_ctx* c, const float vel[3], float Wx[36], float X[6], float JtF_out[6]) {
+  return ext_rot_vel(c, vel, Wx, X, JtF_out);
+}
+
+int orc_directed_match(orc_ctx* c, orc_map* nm, orc_map* om, const float vel[3], const float Rvel[9], const float Rback[9],
+                       int* kf, float max_radius) {
+  return directed_match(c, nm, om, vel, m3_from(Rvel), m3_from(Rback), kf, max_radius);
+}
+
+int orc_regularize(orc_map* m) {
+  // config is default-constructed per map in the reference (edge_map.hpp:34): threshold 0.5
+  return regularize_1iter(nullptr, m, 0.5f);
+}
+
+void orc_update_inverse_depth(orc_ctx* c, const float vel[3]) {
+  // Core::updateInverseDepth (core.cpp:417-422)
+  orc_map* m = c->df_map;
+  for (orc_keyline& k : m->kl)
+    if (k.match_id >= 0) update_inverse_depth_arlu(c->p, k, vel);
+}
+
+int orc_track_pair(orc_ctx* c, orc_map* old_map, orc_map* new_map, const float* R_prior, float frame_dt, orc_pair_out* out) {
+  // Rebvio::stateEstimationProcess body (rebvio.cpp:135-259), accelerometer/SAB branch excluded.
+  const orc_params& P = c->p;
+  std::memset(out, 0, sizeof(*out));
+  M3 P_V = m3_scale(m3_identity(), std::numeric_limits<float>::max());
+  M3 R = m3_identity();
+
+  orc_build_distance_field(c, new_map);  // rebvio.cpp:142
+
+  if (R_prior) R = m3_from(R_prior);  // rebvio.cpp:163
+  {                                   // R.T() = SO3(Bg)*R.T()  (rebvio.cpp:164)
+    M3 RT = m3_mul(so3_exp(c->Bg), m3_T(R));
+    R = m3_T(RT);
+  }
+  {
+    float RT[9];
+    m3_to(m3_T(R), RT);
+    orc_rotate_keylines(c, old_map, RT);  // rebvio.cpp:165
+  }
+
+  float Vg[3] = {0, 0, 0};
+  M3 P_Vg;
+  out->F = minimize_vel(c, old_map, Vg, P_Vg, &out->lm_accept_mask, &out->sigma_rho_min);  // rebvio.cpp:169
+  forward_match(old_map, new_map);                                                            // rebvio.cpp:172
+
+  float Xv[6], W_Xv[36];
+  out->ext_ok = ext_rot_vel(c, Vg, W_Xv, Xv, nullptr);  // rebvio.cpp:177
+  float Xgv[6], W_Xgv[36];
+  std::memcpy(Xgv, Xv, sizeof(Xv));
+  std::memcpy(W_Xgv, W_Xv, sizeof(W_Xv));
+
+  // rebvio.cpp:186-191
+  float s_b = P.gyro_bias_std_dev * P.gyro_bias_std_dev * frame_dt * frame_dt;
+  float s_g = P.gyro_std_dev * P.gyro_std_dev * frame_dt * frame_dt;
+  c->RGBias = m3_scale(m3_identity(), 1.0f);
+  c->RGyro = m3_scale(m3_identity(), 1.0f);
+  for (int i = 0; i < 3; ++i) {
+    c->RGBias.a[i][i] = s_b;
+    c->RGyro.a[i][i] = s_g;
+  }
+  float dg[3];
+  gyro_bias_correction(Xgv, W_Xgv, c->W_Bg, c->RGyro, c->RGBias, dg);
+  for (int i = 0; i < 3; ++i) c->Bg[i] += dg[i];
+  float dVgv[3] = {Xgv[0], Xgv[1], Xgv[2]};
+  float dWgv[3] = {Xgv[3], Xgv[4], Xgv[5]};
+
+  // rebvio.cpp:195-203
+  M3 R0 = so3_exp(dWgv);
+  {
+    M3 RT = m3_mul(R0, m3_T(R));
+    R = m3_T(RT);
+  }
+  float Vgv[3];
+  m3_vec(R0, Vg, Vgv);
+  for (int i = 0; i < 3; ++i) Vgv[i] += dVgv[i];
+  float V[3] = {Vgv[0], Vgv[1], Vgv[2]};
+  float R_Xgv[36];
+  cholesky_inverse<6>(W_Xgv, R_Xgv);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) P_V.a[i][j] = R_Xgv[i * 6 + j];
+
+  M3 Rgva = R;  // rebvio.cpp:228
+  {
+    float R0a[9];
+    m3_to(R0, R0a);
+    orc_rotate_keylines(c, old_map, R0a);  // rebvio.cpp:232
+  }
+
+  for (int i = 0; i < 3; ++i) { out->Vg[i] = Vg[i]; out->V[i] = V[i]; }
+  m3_to(P_Vg, out->P_Vg);
+  std::memcpy(out->Xv, Xv, sizeof(Xv));
+  std::memcpy(out->W_Xv, W_Xv, sizeof(W_Xv));
+  std::memcpy(out->Xgv, Xgv, sizeof(Xgv));
+  m3_to(Rgva, out->R);
+  m3_to(P_V, out->P_V);
+
+  if (std::isnan(V[0]) || std::isnan(V[1]) || std::isnan(V[2])) {  // rebvio.cpp:236
+    out->status = 1;
+    return 1;
+  }
+  out->klm_num = directed_match(c, new_map, old_map, V, P_V, Rgva, &out->kf_matches, P.search_range);  // rebvio.cpp:245
+  if ((unsigned)out->klm_num < P.global_min_matches_threshold) {                                         // rebvio.cpp:247
+    out->status = 2;
+    return 2;
+  }
+  out->reg_num = orc_regularize(new_map);  // rebvio.cpp:256
+  orc_update_inverse_depth(c, V);          // rebvio.cpp:259
+  return 0;
+}
+
+void orc_ls4_reset(orc_ctx* c) {
+  for (int i = 0; i < 3; ++i) c->ls4_V[i] = c->ls4_V0[i] = c->ls4_V1[i] = c->ls4_V2[i] = c->ls4_V3[i] = 0;
+  for (int i = 0; i < 5; ++i) c->ls4_T[i] = 0;
+  for (int i = 0; i < 4; ++i) c->ls4_Dt[i] = 0;
+}
+
+void orc_estimate_ls4_acceleration(orc_ctx* c, const float vel[3], float acc[3], const float R_[9], float dt) {
+  // Core::estimateLs4Acceleration (core.cpp:285-333); the V[3] read out of bounds at core.cpp:321
+  // multiplies a term whose weights sum to zero -> replaced by 0.
+  M3 RT = m3_T(m3_from(R_));
+  m3_vec(RT, c->ls4_V2, c->ls4_V3);
+  m3_vec(RT, c->ls4_V1, c->ls4_V2);
+  m3_vec(RT, c->ls4_V0, c->ls4_V1);
+  m3_vec(RT, c->ls4_V, c->ls4_V0);
+  for (int i = 0; i < 3; ++i) c->ls4_V[i] = vel[i];
+  float* T = c->ls4_T;
+  float* Dt = c->ls4_Dt;
+  for (int i = 0; i < 3; ++i) Dt[i] = Dt[i + 1];
+  Dt[3] = dt;
+  T[0] = 0.0;
+  float mt = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    T[i + 1] = T[i] + Dt[i];
+    mt += T[i + 1];
+  }
+  mt /= 5.0;
+  float den = 0.0;
+  for (int i = 0; i < 5; ++i) den += (T[i] - mt) * (T[i] - mt);
+  for (int i = 0; i < 3; ++i) {
+    float vm = (c->ls4_V[i] + c->ls4_V0[i] + c->ls4_V1[i] + c->ls4_V2[i] + 0.0f) / 5.0;
+    float num = (c->ls4_V[i] - vm) * (T[4] - mt);
+    num += (c->ls4_V0[i] - vm) * (T[3] - mt);
+    num += (c->ls4_V1[i] - vm) * (T[2] - mt);
+    num += (c->ls4_V2[i] - vm) * (T[1] - mt);
+    num += (c->ls4_V3[i] - vm) * (T[0] - mt);
+    if (den > 0.0) acc[i] = num / den;
+  }
+}
+
+void orc_so3_exp(const float w[3], float R[9]) { m3_to(so3_exp(w), R); }
+void orc_sym6_solve(const float A[36], const float b[6], float x[6]) { sym_pinv_solve<6>(A, b, x); }
+
+double orc_run_stream(orc_ctx* c, const uint8_t* frames, const int* idx, int nframes, int threads, int* keyline_counts,
+                      int* match_counts, float* pose_out) {
+  const size_t npx = (size_t)c->p.rows * c->p.cols;
+  auto to_float = [&](int i, std::vector<float>& img) {
+    const uint8_t* src = frames + (size_t)idx[i] * npx;
+    img.resize(npx);
+    for (size_t k = 0; k < npx; ++k) img[k] = (float)src[k] * 3.0f;  // convertTo(CV_32F, 3.0) rebvio.cpp:43
+  };
+  auto track = [&](orc_map* o, orc_map* n, int i) {
+    orc_pair_out po;
+    orc_track_pair(c, o, n, nullptr, 0.05f, &po);
+    if (match_counts) match_counts[i] = po.klm_num;
+    if (pose_out) {
+      for (int k = 0; k < 3; ++k) pose_out[i * 6 + k] = po.Vg[k];
+      for (int k = 0; k < 3; ++k) pose_out[i * 6 + 3 + k] = po.Xgv[3 + k];
+    }
+  };
+  auto t0 = std::chrono::steady_clock::now();
+  if (threads <= 1) {
+    std::vector<float> img;
+    orc_map* prev = nullptr;
+    for (int i = 0; i < nframes; ++i) {
+      to_float(i, img);
+      orc_map* m = orc_detect(c, img.data(), (uint64_t)i * 50000);
+      if (keyline_counts) keyline_counts[i] = (int)m->kl.size();
+      if (prev) {
+        track(prev, m, i);
+        orc_map_free(prev);
+      }
+      prev = m;
+    }
+    if (prev) orc_map_free(prev);
+  } else {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<int, orc_map*>> q;
+    bool done = false;
+    std::thread det([&] {
+      std::vector<float> img;
+      for (int i = 0; i < nframes; ++i) {
+        to_float(i, img);
+        orc_map* m = orc_detect(c, img.data(), (uint64_t)i * 50000);
+        if (keyline_counts) keyline_counts[i] = (int)m->kl.size();
+        {
+          std::lock_guard<std::mutex> g(mu);
+          q.emplace_back(i, m);
+        }
+        cv.notify_one();
+      }
+      {
+        std::lock_guard<std::mutex> g(mu);
+        done = true;
+      }
+      cv.notify_one();
+    });
+    orc_map* prev = nullptr;
+    for (;;) {
+      std::pair<int, orc_map*> it;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return !q.empty() || done; });
+        if (q.empty()) break;
+        it = q.front();
+        q.pop_front();
+      }
+      if (prev) {
+        track(prev, it.second, it.first);
+        orc_map_free(prev);
+      }
+      prev = it.second;
+    }
+    det.join();
+    if (prev) orc_map_free(prev);
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+"""ctypes binding of the gfx950 backend's C-ABI (include/rebvio_hip.h).
+
+Plumbing only: this module loads `rebvio_amd/_build/librebvio_hip.so` and forwards calls. There is no CPU
+fallback anywhere: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "librebvio_hip.so")
+
+KEYLINE_DTYPE = np.dtype([
+    ("pos", "<f4", (2,)), ("pos_img", "<f4", (2,)), ("match_pos_img", "<f4", (2,)), ("gradient", "<f4", (2,)),
+    ("match_gradient", "<f4", (2,)), ("gradient_norm", "<f4"), ("match_gradient_norm", "<f4"), ("rho", "<f4"),
+    ("sigma_rho", "<f4"), ("id", "<i4"), ("id_prev", "<i4"), ("id_next", "<i4"), ("match_id", "<i4"),
+    ("match_id_forward", "<i4"), ("match_id_keyframe", "<i4"), ("matches", "<u4")])
+assert KEYLINE_DTYPE.itemsize == 84
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int), ("cols", C.c_int), ("fm", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("keylines_ref", C.c_int), ("keylines_max", C.c_int),
+        ("pos_neg_threshold", C.c_float), ("dog_threshold", C.c_float), ("threshold", C.c_float), ("gain", C.c_float),
+        ("max_threshold", C.c_float), ("min_threshold", C.c_float),
+        ("search_range", C.c_float), ("reweight_distance", C.c_float), ("match_treshold", C.c_float),
+        ("min_match_threshold", C.c_uint), ("iterations", C.c_uint), ("global_min_matches_threshold", C.c_uint),
+        ("pixel_uncertainty", C.c_float), ("quantile_cutoff", C.c_float), ("quantile_num_bins", C.c_int),
+        ("reshape_q_abs", C.c_float),
+        ("pixel_uncertainty_match", C.c_float), ("match_threshold_norm", C.c_float), ("match_threshold_angle", C.c_float),
+        ("regularization_threshold", C.c_float),
+        ("gyro_std_dev", C.c_float), ("gyro_bias_std_dev", C.c_float),
+        ("device_id", C.c_int), ("map_pool", C.c_int)]
+
+
+class PairOut(C.Structure):
+    _fields_ = [
+        ("Vg", C.c_float * 3), ("P_Vg", C.c_float * 9), ("F", C.c_float), ("Xv", C.c_float * 6), ("W_Xv", C.c_float * 36),
+        ("Xgv", C.c_float * 6), ("V", C.c_float * 3), ("R", C.c_float * 9), ("P_V", C.c_float * 9),
+        ("sigma_rho_min", C.c_float), ("ext_ok", C.c_int), ("klm_num", C.c_int), ("kf_matches", C.c_int),
+        ("reg_num", C.c_int), ("lm_accept_mask", C.c_int), ("status", C.c_int)]
+
+
+# every symbol include/rebvio_hip.h declares: (restype, argtypes)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+SIGNATURES = {
+    "rebvio_hip_abi_version": (C.c_int, []),
+    "rebvio_hip_last_error": (C.c_char_p, []),
+    "rebvio_hip_default_params": (None, [C.POINTER(Params), C.c_int, C.c_int]),
+    "rebvio_hip_create": (C.c_int, [C.POINTER(Params), C.POINTER(_vp)]),
+    "rebvio_hip_destroy": (None, [_vp]),
+    "rebvio_hip_scale_space": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
+    "rebvio_hip_detect": (C.c_int, [_vp, _fp, C.c_size_t, C.c_uint64, C.POINTER(_vp)]),
+    "rebvio_hip_detect_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(_vp)]),
+    "rebvio_hip_detector_state": (C.c_int, [_vp, _fp, _fp, _ip]),
+    "rebvio_hip_map_size": (C.c_int, [_vp]),
+    "rebvio_hip_map_threshold": (C.c_float, [_vp]),
+    "rebvio_hip_map_ts": (C.c_uint64, [_vp]),
+    "rebvio_hip_map_download": (C.c_int, [_vp, _vp, _ip]),
+    "rebvio_hip_map_upload": (C.c_int, [_vp, _vp, C.c_int]),
+    "rebvio_hip_map_release": (None, [_vp]),
+    "rebvio_hip_build_distance_field": (C.c_int, [_vp, _vp]),
+    "rebvio_hip_distance_field": (C.c_int, [_vp, _ip, _ip]),
+    "rebvio_hip_rotate": (C.c_int, [_vp, _vp, _fp]),
+    "rebvio_hip_quantile": (C.c_int, [_vp, _vp, C.c_float, C.c_int, _fp]),
+    "rebvio_hip_try_vel": (C.c_int, [_vp, _vp, _fp, C.c_float, _fp, _fp]),
+    "rebvio_hip_minimize_vel": (C.c_int, [_vp, _vp, _fp, _fp, _fp, _ip, _fp]),
+    "rebvio_hip_forward_match": (C.c_int, [_vp, _vp, _vp]),
+    "rebvio_hip_ext_rot_vel": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _ip]),
+    "rebvio_hip_directed_match": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, C.c_float, _ip, _ip]),
+    "rebvio_hip_regularize": (C.c_int, [_vp, _vp, _ip]),
+    "rebvio_hip_update_inverse_depth": (C.c_int, [_vp, _fp]),
+    "rebvio_hip_reset_state": (None, [_vp]),
+    "rebvio_hip_track_pair": (C.c_int, [_vp, _vp, _vp, _fp, C.c_float, C.POINTER(PairOut)]),
+    "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
+    "rebvio_hip_flush": (C.c_int, [_vp]),
+    "rebvio_hip_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "rebvio_hip_profile_select": (C.c_int, [_vp, C.c_char_p]),
+    "rebvio_hip_profile_reset": (C.c_int, [_vp]),
+    "rebvio_hip_profile_read": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), _ip, C.c_int]),
+    "rebvio_hip_device_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "rebvio_hip_device_free": (C.c_int, [_vp, _vp]),
+    "rebvio_hip_device_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the backend for gfx950 with hipcc (rebvio_amd/csrc/Makefile)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")] + ([] if verbose else ["-s"]), check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP backend has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HipError(f"rebvio_hip error {rc}: {lib().rebvio_hip_last_error().decode()}")
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return a, a.ctypes.data_as(_fp)
+
+
+def default_params(rows, cols, **over) -> Params:
+    p = Params()
+    lib().rebvio_hip_default_params(C.byref(p), rows, cols)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Map:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def release(self):
+        if self.h:
+            lib().rebvio_hip_map_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def size(self):
+        n = lib().rebvio_hip_map_size(self.h)
+        if n < 0:
+            raise HipError(lib().rebvio_hip_last_error().decode())
+        return n
+
+    @property
+    def threshold(self):
+        return lib().rebvio_hip_map_threshold(self.h)
+
+    def keylines(self) -> np.ndarray:
+        out = np.zeros(self.size(), KEYLINE_DTYPE)
+        _chk(lib().rebvio_hip_map_download(self.h, out.ctypes.data if out.size else None, None))
+        return out
+
+    def mask(self) -> np.ndarray:
+        out = np.empty((self.ctx.rows, self.ctx.cols), np.int32)
+        _chk(lib().rebvio_hip_map_download(self.h, None, out.ctypes.data_as(_ip)))
+        return out
+
+    def upload(self, kl: np.ndarray):
+        kl = np.ascontiguousarray(kl, KEYLINE_DTYPE)
+        _chk(lib().rebvio_hip_map_upload(self.h, kl.ctypes.data if kl.size else None, len(kl)))
+
+
+class Context:
+    def __init__(self, params: Params):
+        self.p = params
+        self.rows, self.cols = params.rows, params.cols
+        h = _vp()
+        _chk(lib().rebvio_hip_create(C.byref(params), C.byref(h)))
+        self.h = h
+        self._dev_bufs = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            for b in self._dev_bufs:
+                lib().rebvio_hip_device_free(self.h, b)
+            self._dev_bufs = []
+            lib().rebvio_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # detection
+    def scale_space(self, img):
+        img, pi = _f(img)
+        outs = [np.empty((self.rows, self.cols), np.float32) for _ in range(4)]
+        _chk(lib().rebvio_hip_scale_space(self.h, pi, *[o.ctypes.data_as(_fp) for o in outs]))
+        return dict(scale0=outs[0], scale1=outs[1], dog=outs[2], mag=outs[3])
+
+    def detect(self, img, ts_us=0) -> Map:
+        img, pi = _f(img)
+        assert img.shape == (self.rows, self.cols)
+        h = _vp()
+        _chk(lib().rebvio_hip_detect(self.h, pi, 0, ts_us, C.byref(h)))
+        return Map(self, h)
+
+    def detect_u8(self, frame_u8, ts_us=0) -> Map:
+        return self.detect(frame_u8.astype(np.float32) * np.float32(3.0), ts_us)
+
+    def upload_frames(self, frames_u8: np.ndarray) -> int:
+        """Stage u8 frames in HBM; returns the device address of frame 0."""
+        frames_u8 = np.ascontiguousarray(frames_u8, np.uint8)
+        d = _vp()
+        _chk(lib().rebvio_hip_device_alloc(self.h, frames_u8.nbytes, C.byref(d)))
+        _chk(lib().rebvio_hip_device_upload(self.h, d, frames_u8.ctypes.data, frames_u8.nbytes))
+        self._dev_bufs.append(d)
+        return d.value
+
+    def detect_u8_device(self, dev_addr: int, ts_us=0) -> Map:
+        h = _vp()
+        _chk(lib().rebvio_hip_detect_u8_device(self.h, _vp(dev_addr), ts_us, C.byref(h)))
+        return Map(self, h)
+
+    def detector_state(self):
+        t, a, n = C.c_float(), C.c_float(), C.c_int()
+        _chk(lib().rebvio_hip_detector_state(self.h, C.byref(t), C.byref(a), C.byref(n)))
+        return t.value, a.value, n.value
+
+    # tracking
+    def build_distance_field(self, m: Map):
+        _chk(lib().rebvio_hip_build_distance_field(self.h, m.h))
+
+    def distance_field(self):
+        ids = np.empty((self.rows, self.cols), np.int32)
+        dist = np.empty((self.rows, self.cols), np.int32)
+        _chk(lib().rebvio_hip_distance_field(self.h, ids.ctypes.data_as(_ip), dist.ctypes.data_as(_ip)))
+        return ids, dist
+
+    def rotate(self, m: Map, R):
+        R, pr = _f(np.asarray(R).reshape(9))
+        _chk(lib().rebvio_hip_rotate(self.h, m.h, pr))
+
+    def quantile(self, m: Map, pct=0.9, bins=100):
+        out = C.c_float()
+        _chk(lib().rebvio_hip_quantile(self.h, m.h, pct, bins, C.byref(out)))
+        return out.value
+
+    def try_vel(self, m: Map, vel, sigma_rho_min, residuals):
+        vel, pv = _f(vel)
+        assert residuals.dtype == np.float32 and residuals.flags.c_contiguous
+        out = np.zeros(10, np.float32)
+        _chk(lib().rebvio_hip_try_vel(self.h, m.h, pv, sigma_rho_min, residuals.ctypes.data_as(_fp), out.ctypes.data_as(_fp)))
+        J = np.array([[out[1], out[4], out[5]], [out[4], out[2], out[6]], [out[5], out[6], out[3]]], np.float32)
+        return float(out[0]), J, out[7:10].copy()
+
+    def minimize_vel(self, m: Map, vel0=(0, 0, 0)):
+        vel = np.array(vel0, np.float32)
+        Rvel = np.zeros(9, np.float32)
+        F, srm, mask = C.c_float(), C.c_float(), C.c_int()
+        _chk(lib().rebvio_hip_minimize_vel(self.h, m.h, vel.ctypes.data_as(_fp), Rvel.ctypes.data_as(_fp), C.byref(F),
+                                           C.byref(mask), C.byref(srm)))
+        return dict(F=F.value, vel=vel, Rvel=Rvel.reshape(3, 3), accept_mask=mask.value, sigma_rho_min=srm.value)
+
+    def forward_match(self, old: Map, new: Map):
+        _chk(lib().rebvio_hip_forward_match(self.h, old.h, new.h))
+
+    def ext_rot_vel(self, vel):
+        vel, pv = _f(vel)
+        Wx = np.zeros(36, np.float32)
+        JtF = np.zeros(6, np.float32)
+        X = np.zeros(6, np.float32)
+        ok = C.c_int()
+        _chk(lib().rebvio_hip_ext_rot_vel(self.h, pv, Wx.ctypes.data_as(_fp), JtF.ctypes.data_as(_fp), X.ctypes.data_as(_fp),
+                                          C.byref(ok)))
+        return dict(ok=ok.value, Wx=Wx.reshape(6, 6), X=X, JtF=JtF)
+
+    def directed_match(self, new: Map, old: Map, vel, Rvel, Rback, max_radius=40.0):
+        vel, pv = _f(vel)
+        Rvel, prv = _f(np.asarray(Rvel).reshape(9))
+        Rback, prb = _f(np.asarray(Rback).reshape(9))
+        n, kf = C.c_int(), C.c_int()
+        _chk(lib().rebvio_hip_directed_match(self.h, new.h, old.h, pv, prv, prb, max_radius, C.byref(n), C.byref(kf)))
+        return n.value, kf.value
+
+    def regularize(self, m: Map):
+        n = C.c_int()
+        _chk(lib().rebvio_hip_regularize(self.h, m.h, C.byref(n)))
+        return n.value
+
+    def update_inverse_depth(self, vel):
+        vel, pv = _f(vel)
+        _chk(lib().rebvio_hip_update_inverse_depth(self.h, pv))
+
+    def reset_state(self):
+        lib().rebvio_hip_reset_state(self.h)
+
+    def track_pair(self, old: Map, new: Map, R_prior=None, frame_dt=0.05) -> PairOut:
+        out = PairOut()
+        pr = None
+        if R_prior is not None:
+            R_prior, pr = _f(np.asarray(R_prior).reshape(9))
+        _chk(lib().rebvio_hip_track_pair(self.h, old.h, new.h, pr, frame_dt, C.byref(out)))
+        return out
+
+    def push_frame_u8_device(self, dev_addr: int, ts_us: int):
+        out = PairOut()
+        n = C.c_int()
+        _chk(lib().rebvio_hip_push_frame_u8_device(self.h, _vp(dev_addr), ts_us, C.byref(out), C.byref(n)))
+        return out, n.value
+
+    def flush(self):
+        _chk(lib().rebvio_hip_flush(self.h))
+
+    # profiling
+    def profile(self, on: bool, only: str | None = None):
+        lib().rebvio_hip_profile_select(self.h, (only or "").encode())
+        lib().rebvio_hip_profile_enable(self.h, 1 if on else 0)
+
+    def profile_reset(self):
+        lib().rebvio_hip_profile_reset(self.h)
+
+    def profile_read(self):
+        cap = 64
+        names = C.create_string_buffer(8192)
+        avg = (C.c_double * cap)()
+        calls = (C.c_int * cap)()
+        k = lib().rebvio_hip_profile_read(self.h, names, 8192, avg, calls, cap)
+        ns = names.value.decode().split("\n")
+        return {ns[i]: (avg[i], calls[i]) for i in range(k)}

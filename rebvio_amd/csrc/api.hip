@@ -1,0 +1,949 @@
+// C-ABI of the gfx950 backend (include/rebvio_hip.h): context / edge-map pool management, stream ordering
+// between the detect stream and the track stream, and the O(1) host glue of one frame pair. All heavy work
+// is in detect.hip / track.hip; nothing here falls back to a CPU implementation of the hot path.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "hostmath.hpp"
+
+using namespace rh;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(const char* what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return -(int)e - 1000;
+}
+int fail_msg(const char* what, int code) {
+  g_err = what;
+  return code;
+}
+#define HIPCHK(expr)                          \
+  do {                                        \
+    hipError_t _e = (expr);                   \
+    if (_e != hipSuccess) return fail(#expr, _e); \
+  } while (0)
+
+// ---- profiler ------------------------------------------------------------------------------------
+struct Profiler {
+  bool on = false;
+  std::string only;
+  struct Sample {
+    int name;
+    hipEvent_t e0, e1;
+  };
+  std::vector<std::string> names;
+  std::vector<Sample> samples;
+  std::vector<hipEvent_t> free_events;
+  int open_name = -1;
+  hipEvent_t open_e0{}, open_e1{};
+  std::map<int, std::pair<double, int>> acc;  // name -> (sum us, calls)
+  size_t cap = 1 << 16;
+  std::mutex mu;
+
+  int name_id(const char* n) {
+    for (size_t i = 0; i < names.size(); ++i)
+      if (names[i] == n) return (int)i;
+    names.emplace_back(n);
+    return (int)names.size() - 1;
+  }
+  hipEvent_t get_event() {
+    if (!free_events.empty()) {
+      hipEvent_t e = free_events.back();
+      free_events.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void drain() {
+    for (auto& s : samples) {
+      float ms = 0.f;
+      if (hipEventSynchronize(s.e1) == hipSuccess && hipEventElapsedTime(&ms, s.e0, s.e1) == hipSuccess) {
+        auto& a = acc[s.name];
+        a.first += (double)ms * 1e3;
+        a.second += 1;
+      }
+      free_events.push_back(s.e0);
+      free_events.push_back(s.e1);
+    }
+    samples.clear();
+  }
+};
+Profiler g_prof;
+}  // namespace
+
+namespace rh {
+void prof_begin(hipStream_t s, const char* name) {
+  if (!g_prof.on) return;
+  std::lock_guard<std::mutex> g(g_prof.mu);
+  g_prof.open_name = -1;
+  if (!g_prof.only.empty() && g_prof.only != name) return;
+  if (g_prof.samples.size() >= g_prof.cap) return;
+  g_prof.open_name = g_prof.name_id(name);
+  g_prof.open_e0 = g_prof.get_event();
+  g_prof.open_e1 = g_prof.get_event();
+  (void)hipEventRecord(g_prof.open_e0, s);
+}
+void prof_end(hipStream_t s) {
+  if (!g_prof.on) return;
+  std::lock_guard<std::mutex> g(g_prof.mu);
+  if (g_prof.open_name < 0) return;
+  (void)hipEventRecord(g_prof.open_e1, s);
+  g_prof.samples.push_back({g_prof.open_name, g_prof.open_e0, g_prof.open_e1});
+  g_prof.open_name = -1;
+}
+}  // namespace rh
+
+// ---- objects ----------------------------------------------------------------------------------------
+struct rebvio_hip_map {
+  rebvio_hip_ctx* ctx = nullptr;
+  MapDev d{};
+  bool in_use = false;
+  uint64_t ts = 0;
+  hipEvent_t ready{};  // detect (+ distance field) finished, recorded on the detect stream
+  hipEvent_t done{};   // last track-stream consumer finished, recorded at release
+  bool has_done = false;
+  bool df_built = false;
+  int n_host = -1;
+  float thr_host = -1.0f;
+};
+
+struct rebvio_hip_ctx {
+  rebvio_hip_params P{};
+  KParams K{};
+  int device = 0;
+  hipStream_t s_det{}, s_trk{}, s_cpy{};
+  ScaleBufs sb{};
+  DetectBufs db{};
+  DetState* det = nullptr;  // [2]
+  uint64_t frame_index = 0;
+  int widths[2][3]{};
+  std::vector<rebvio_hip_map*> pool;
+  float* img_dev = nullptr;
+  uint8_t* img8_dev = nullptr;
+  rebvio_hip_keyline* aos_dev = nullptr;
+  int* scratch_i = nullptr;  // 2 * rows*cols ints (df decode)
+  float* diag0 = nullptr;
+  float* diag1 = nullptr;
+  // tracking
+  LmState* lm = nullptr;    // [16]
+  float* part = nullptr;    // [kMaxLmCalls+1][maxblocks][kPartStride]
+  float* xrv_part = nullptr;
+  int* hist = nullptr;      // [128]
+  float* fscratch = nullptr;
+  int maxblocks = 0;
+  rebvio_hip_map* df_map = nullptr;
+  // pinned host staging
+  LmState* h_lm = nullptr;   // [2]
+  float* h_part = nullptr;
+  float* h_xrv = nullptr;
+  MapState* h_st = nullptr;  // [2]
+  float* h_f = nullptr;
+  // glue state (types/imu.hpp:171-187)
+  float Bg[3]{};
+  hm::M3 W_Bg{}, RGBias{}, RGyro{};
+  // streaming
+  rebvio_hip_map* pend_old = nullptr;
+  rebvio_hip_map* pend_new = nullptr;
+};
+
+namespace {
+
+size_t part_call_stride(const rebvio_hip_ctx* c) { return (size_t)c->maxblocks * kPartStride; }
+
+int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
+  const size_t M = (size_t)c->P.keylines_max, Pn = (size_t)c->P.rows * c->P.cols;
+  MapDev& d = m->d;
+  HIPCHK(hipMalloc(&d.pos, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.pos_img, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.mpos_img, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.grad, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.mgrad, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.gnorm, M * sizeof(float)));
+  HIPCHK(hipMalloc(&d.mgnorm, M * sizeof(float)));
+  HIPCHK(hipMalloc(&d.rs, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.rs_tmp, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.id_prev, M * sizeof(int)));
+  HIPCHK(hipMalloc(&d.id_next, M * sizeof(int)));
+  HIPCHK(hipMalloc(&d.match_id, M * sizeof(int)));
+  HIPCHK(hipMalloc(&d.match_fwd, M * sizeof(int)));
+  HIPCHK(hipMalloc(&d.match_kf, M * sizeof(int)));
+  HIPCHK(hipMalloc(&d.matches, M * sizeof(unsigned)));
+  HIPCHK(hipMalloc(&d.fwd_key, M * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc(&d.residual, M * sizeof(float)));
+  HIPCHK(hipMalloc(&d.mask, Pn * sizeof(int)));
+  HIPCHK(hipMalloc(&d.df, Pn * sizeof(unsigned)));
+  HIPCHK(hipMalloc(&d.st, sizeof(MapState)));
+  HIPCHK(hipMemset(d.st, 0, sizeof(MapState)));
+  HIPCHK(hipMemset(d.mask, 0xFF, Pn * sizeof(int)));
+  HIPCHK(hipMemset(d.df, 0xFF, Pn * sizeof(unsigned)));
+  HIPCHK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
+  return 0;
+}
+
+void free_map(rebvio_hip_map* m) {
+  MapDev& d = m->d;
+  void* ptrs[] = {d.pos, d.pos_img, d.mpos_img, d.grad, d.mgrad, d.gnorm, d.mgnorm, d.rs, d.rs_tmp, d.id_prev, d.id_next,
+                  d.match_id, d.match_fwd, d.match_kf, d.matches, d.fwd_key, d.residual, d.mask, d.df, d.st};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (m->ready) (void)hipEventDestroy(m->ready);
+  if (m->done) (void)hipEventDestroy(m->done);
+  delete m;
+}
+
+rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
+  for (auto* m : c->pool)
+    if (!m->in_use) {
+      m->in_use = true;
+      m->df_built = false;
+      m->n_host = -1;
+      m->thr_host = -1.0f;
+      return m;
+    }
+  return nullptr;
+}
+
+int fetch_map_state(rebvio_hip_map* m, MapState* out, hipStream_t after) {
+  // copy stream: wait for the producer, copy, block the host only on this small transfer
+  rebvio_hip_ctx* c = m->ctx;
+  HIPCHK(hipStreamWaitEvent(c->s_cpy, m->ready, 0));
+  if (after) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e, after));
+    HIPCHK(hipStreamWaitEvent(c->s_cpy, e, 0));
+    (void)hipEventDestroy(e);
+  }
+  HIPCHK(hipMemcpyAsync(c->h_st, m->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_cpy));
+  HIPCHK(hipStreamSynchronize(c->s_cpy));
+  *out = *c->h_st;
+  m->n_host = out->n;
+  m->thr_host = out->threshold;
+  return 0;
+}
+
+int ensure_size(rebvio_hip_map* m) {
+  if (m->n_host >= 0) return 0;
+  MapState st;
+  return fetch_map_state(m, &st, nullptr);
+}
+
+int detect_common(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_map** out) {
+  rebvio_hip_map* m = acquire_map(c);
+  if (!m) return fail_msg("edge-map pool exhausted (release maps or raise map_pool)", -2);
+  if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_det, m->done, 0));
+  m->ts = ts;
+  const DetState* det_in = c->det + (c->frame_index & 1);
+  DetState* det_out = c->det + ((c->frame_index + 1) & 1);
+  ScaleBufs sb = c->sb;
+  sb.scale0 = sb.scale1 = nullptr;
+  launch_scale_space(c->s_det, c->K, img_dev, is_u8, sb, c->widths, c->db.rowcount);
+  launch_keylines(c->s_det, c->K, sb, c->db, m->d, det_in, det_out, c->frame_index);
+  launch_df_build(c->s_det, c->K, m->d, det_in, det_out);
+  m->df_built = true;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(m->ready, c->s_det));
+  c->frame_index++;
+  *out = m;
+  return 0;
+}
+
+void rotate_inputs(const rebvio_hip_ctx* c, const float vel[3], const float Rvel[9], const float Rback[9], float vel_r[3],
+                   float Rvel_r[9]) {
+  // EdgeMap::directedMatch prologue (edge_map.cpp:193-194)
+  (void)c;
+  const hm::M3 Rb = hm::load3(Rback);
+  hm::mulv(Rb, vel, vel_r);
+  hm::store3(hm::mul(hm::mul(Rb, hm::load3(Rvel)), hm::transpose(Rb)), Rvel_r);
+}
+
+void sum_xrv(const float* h_xrv, int nblocks, float Wx[36], float JtF[6], int* nm) {
+  double acc[28];
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  for (int b = 0; b < nblocks; ++b)
+    for (int k = 0; k < 28; ++k) acc[k] += (double)h_xrv[(size_t)b * kXrvStride + k];
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      Wx[i * 6 + j] = (float)acc[k];
+      Wx[j * 6 + i] = (float)acc[k];
+      ++k;
+    }
+  for (int i = 0; i < 6; ++i) JtF[i] = (float)acc[21 + i];
+  if (nm) *nm = (int)std::lround(acc[27]);
+}
+
+void lm_to_out(const LmState& s, float vel[3], float Rvel[9], float* F, int* mask, float* srm) {
+  for (int i = 0; i < 3; ++i) vel[i] = s.vel[i];
+  hm::M3 J;
+  J.a[0][0] = s.JtJ[0]; J.a[1][1] = s.JtJ[1]; J.a[2][2] = s.JtJ[2];
+  J.a[0][1] = J.a[1][0] = s.JtJ[3];
+  J.a[0][2] = J.a[2][0] = s.JtJ[4];
+  J.a[1][2] = J.a[2][1] = s.JtJ[5];
+  hm::store3(hm::invert3(J), Rvel);  // _Rvel = invert(JtJ) (core.cpp:186)
+  if (F) *F = s.F;
+  if (mask) *mask = s.accept_mask;
+  if (srm) *srm = s.sigma_rho_min;
+}
+
+// minimizeVel on the track stream: histogram must already be in c->hist and residuals zeroed.
+void enqueue_lm_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3]) {
+  LmState init;
+  std::memset(&init, 0, sizeof(init));
+  for (int i = 0; i < 3; ++i) init.vel[i] = vel0[i];
+  c->h_lm[1] = init;
+  (void)hipMemcpyAsync(c->lm, &c->h_lm[1], sizeof(LmState), hipMemcpyHostToDevice, c->s_trk);
+  const int calls = (int)c->P.iterations + 1;
+  const size_t cs = part_call_stride(c);
+  for (int i = 0; i < calls; ++i)
+    launch_try_vel(c->s_trk, c->K, om->d, nm->d, 1, i, i == calls - 1, c->lm + i, c->lm + i + 1,
+                   i ? c->part + (size_t)(i - 1) * cs : c->part, c->part + (size_t)i * cs, c->hist, 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rebvio_hip_abi_version(void) { return REBVIO_HIP_ABI_VERSION; }
+const char* rebvio_hip_last_error(void) { return g_err.c_str(); }
+
+void rebvio_hip_default_params(rebvio_hip_params* p, int rows, int cols) {
+  std::memset(p, 0, sizeof(*p));
+  p->rows = rows; p->cols = cols;
+  const float fx = 458.654, fy = 457.296;  // camera.hpp:26-30
+  p->fm = 0.5 * (fx + fy);
+  p->cx = 367.215; p->cy = 248.375;
+  p->keylines_ref = 12000; p->keylines_max = 16000;
+  p->pos_neg_threshold = 0.4; p->dog_threshold = 0.095259868922420; p->threshold = 0.01; p->gain = 5e-7;
+  p->max_threshold = 0.5; p->min_threshold = 0.005;
+  p->search_range = 40.0; p->reweight_distance = 2.0; p->match_treshold = 0.5;
+  p->min_match_threshold = 0; p->iterations = 5; p->global_min_matches_threshold = 500;
+  p->pixel_uncertainty = 1; p->quantile_cutoff = 0.9; p->quantile_num_bins = 100; p->reshape_q_abs = 1e-4;
+  p->pixel_uncertainty_match = 2.0; p->match_threshold_norm = 1.0; p->match_threshold_angle = 45.0;
+  p->regularization_threshold = 0.5;
+  p->gyro_std_dev = 1.6968e-04; p->gyro_bias_std_dev = 1.9393e-05;
+  p->device_id = 0; p->map_pool = 0;
+}
+
+void rebvio_hip_reset_state(rebvio_hip_ctx* c) {
+  c->Bg[0] = c->Bg[1] = c->Bg[2] = 0.f;
+  c->RGBias = hm::identity3();
+  c->RGyro = hm::identity3();
+  c->W_Bg = hm::invert3(hm::diag3(100.0f));  // W_Bg{invert(100.0*RGBias)} (types/imu.hpp:181)
+}
+
+int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
+  *out = nullptr;
+  if (p->rows < 32 || p->cols < 32 || (p->cols % 4) != 0) return fail_msg("rows/cols must be >= 32 and cols % 4 == 0", -3);
+  if (p->cols > 4096) return fail_msg("cols > 4096 unsupported", -3);
+  if (p->quantile_num_bins > 128 || p->quantile_num_bins < 1) return fail_msg("quantile_num_bins must be in 1..128", -3);
+  if ((int)p->iterations + 2 > 15) return fail_msg("iterations too large", -3);
+  const int nr = 2 * (int)p->search_range;
+  if (nr < 2 || (long long)p->keylines_max * nr >= (1ll << kDfSeqBits) || (int)p->search_range > 255)
+    return fail_msg("keylines_max * 2*search_range must stay below 2^23", -3);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail_msg("no HIP device present: the gfx950 backend has no CPU fallback", -4);
+  if (p->device_id < 0 || p->device_id >= ndev) return fail_msg("device_id out of range", -3);
+  HIPCHK(hipSetDevice(p->device_id));
+
+  rebvio_hip_ctx* c = new rebvio_hip_ctx;
+  c->P = *p;
+  c->device = p->device_id;
+  KParams& K = c->K;
+  K.rows = p->rows; K.cols = p->cols; K.fm = p->fm; K.cx = p->cx; K.cy = p->cy;
+  K.kmax = p->keylines_max; K.kref = p->keylines_ref;
+  K.pos_neg_threshold = p->pos_neg_threshold; K.dog_threshold = p->dog_threshold; K.gain = p->gain;
+  K.max_threshold = p->max_threshold; K.min_threshold = p->min_threshold;
+  K.search_range = p->search_range; K.reweight_distance = p->reweight_distance; K.match_treshold = p->match_treshold;
+  K.min_match_threshold = p->min_match_threshold;
+  K.pixel_uncertainty = p->pixel_uncertainty; K.quantile_cutoff = p->quantile_cutoff;
+  K.quantile_num_bins = p->quantile_num_bins; K.reshape_q_abs = p->reshape_q_abs;
+  K.pixel_uncertainty_match = p->pixel_uncertainty_match; K.match_threshold_norm = p->match_threshold_norm;
+  K.cang_min_edge = std::cos(p->match_threshold_angle * M_PI / 180.0);  // edge_map.cpp:104
+  K.regularization_threshold = p->regularization_threshold;
+  K.nseg = div_up(p->cols, 64);
+  K.df_nr = nr;
+
+  // FastGaussian widths (scale_space.cpp:14-41,186)
+  float st0 = 0, st1 = 0;
+  hm::kovesi_widths(3.56359, 3, c->widths[0], &st0);
+  hm::kovesi_widths(st0 * 1.2599, 3, c->widths[1], &st1);
+  for (int f = 0; f < 2; ++f)
+    for (int k = 0; k < 3; ++k)
+      if (c->widths[f][k] < 3 || c->widths[f][k] > 11) {
+        delete c;
+        return fail_msg("unexpected box width", -5);
+      }
+  float recip[128], pinv[75];
+  recip[0] = 0.f;
+  for (int n = 1; n < 128; ++n) recip[n] = (float)(1.0 / (double)(float)n);
+  hm::plane_fit_pinv(pinv);
+  upload_tables(recip, pinv);
+
+  HIPCHK(hipStreamCreateWithFlags(&c->s_det, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->s_cpy, hipStreamNonBlocking));
+  const size_t Pn = (size_t)p->rows * p->cols;
+  for (int f = 0; f < 2; ++f) {
+    HIPCHK(hipMalloc(&c->sb.a[f], Pn * sizeof(float)));
+    HIPCHK(hipMalloc(&c->sb.b[f], Pn * sizeof(float)));
+  }
+  HIPCHK(hipMalloc(&c->sb.dog, Pn * sizeof(float)));
+  HIPCHK(hipMalloc(&c->sb.mag, Pn * sizeof(float)));
+  HIPCHK(hipMalloc(&c->db.stash, Pn * sizeof(float4)));
+  HIPCHK(hipMalloc(&c->db.bits, (size_t)p->rows * K.nseg * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc(&c->db.rowcount, (size_t)p->rows * sizeof(int)));
+  HIPCHK(hipMemset(c->db.rowcount, 0, (size_t)p->rows * sizeof(int)));
+  HIPCHK(hipMalloc(&c->det, 3 * sizeof(DetState)));  // [0],[1]: ping-pong servo state, [2]: scratch sink
+  DetState d0[2];
+  for (int i = 0; i < 2; ++i) {
+    d0[i].threshold = p->threshold;       // config_->threshold
+    d0[i].count = 0;                      // keylines_count_(0) (edge_detector.cpp:18)
+    d0[i].auto_threshold = p->threshold;  // auto_threshold_(config_->threshold) (edge_detector.cpp:20)
+    d0[i].pad = 0;
+  }
+  HIPCHK(hipMemcpy(c->det, d0, sizeof(d0), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&c->img_dev, Pn * sizeof(float)));
+  HIPCHK(hipMalloc(&c->img8_dev, Pn));
+  HIPCHK(hipMalloc(&c->aos_dev, (size_t)p->keylines_max * sizeof(rebvio_hip_keyline)));
+  HIPCHK(hipMalloc(&c->scratch_i, 2 * Pn * sizeof(int)));
+
+  c->maxblocks = div_up(p->keylines_max, 256);
+  HIPCHK(hipMalloc(&c->lm, 16 * sizeof(LmState)));
+  HIPCHK(hipMemset(c->lm, 0, 16 * sizeof(LmState)));
+  HIPCHK(hipMalloc(&c->part, (size_t)(kMaxLmCalls + 1) * part_call_stride(c) * sizeof(float)));
+  HIPCHK(hipMemset(c->part, 0, (size_t)(kMaxLmCalls + 1) * part_call_stride(c) * sizeof(float)));
+  HIPCHK(hipMalloc(&c->xrv_part, (size_t)c->maxblocks * kXrvStride * sizeof(float)));
+  HIPCHK(hipMalloc(&c->hist, 128 * sizeof(int)));
+  HIPCHK(hipMalloc(&c->fscratch, 64 * sizeof(float)));
+  HIPCHK(hipHostMalloc(&c->h_lm, 2 * sizeof(LmState), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&c->h_part, part_call_stride(c) * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&c->h_xrv, (size_t)c->maxblocks * kXrvStride * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&c->h_st, 2 * sizeof(MapState), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&c->h_f, 64 * sizeof(float), hipHostMallocDefault));
+
+  int pool = p->map_pool > 0 ? p->map_pool : 4;
+  if (pool < 3) pool = 3;
+  for (int i = 0; i < pool; ++i) {
+    rebvio_hip_map* m = new rebvio_hip_map;
+    m->ctx = c;
+    c->pool.push_back(m);
+    int rc = alloc_map(c, m);
+    if (rc) return rc;
+  }
+  rebvio_hip_reset_state(c);
+  HIPCHK(hipDeviceSynchronize());
+  *out = c;
+  return 0;
+}
+
+void rebvio_hip_destroy(rebvio_hip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  {
+    std::lock_guard<std::mutex> g(g_prof.mu);
+    g_prof.drain();
+  }
+  for (auto* m : c->pool) free_map(m);
+  void* dptr[] = {c->sb.a[0], c->sb.a[1], c->sb.b[0], c->sb.b[1], c->sb.dog, c->sb.mag, c->db.stash, c->db.bits,
+                  c->db.rowcount, c->det, c->img_dev, c->img8_dev, c->aos_dev, c->scratch_i, c->diag0, c->diag1, c->lm,
+                  c->part, c->xrv_part, c->hist, c->fscratch};
+  for (void* p : dptr)
+    if (p) (void)hipFree(p);
+  void* hptr[] = {c->h_lm, c->h_part, c->h_xrv, c->h_st, c->h_f};
+  for (void* p : hptr)
+    if (p) (void)hipHostFree(p);
+  (void)hipStreamDestroy(c->s_det);
+  (void)hipStreamDestroy(c->s_trk);
+  (void)hipStreamDestroy(c->s_cpy);
+  delete c;
+}
+
+int rebvio_hip_scale_space(rebvio_hip_ctx* c, const float* img, float* scale0, float* scale1, float* dog, float* mag) {
+  HIPCHK(hipSetDevice(c->device));
+  const size_t nb = (size_t)c->P.rows * c->P.cols * sizeof(float);
+  if (!c->diag0) {
+    HIPCHK(hipMalloc(&c->diag0, nb));
+    HIPCHK(hipMalloc(&c->diag1, nb));
+  }
+  HIPCHK(hipMemcpyAsync(c->img_dev, img, nb, hipMemcpyHostToDevice, c->s_det));
+  ScaleBufs sb = c->sb;
+  sb.scale0 = c->diag0;
+  sb.scale1 = c->diag1;
+  launch_scale_space(c->s_det, c->K, c->img_dev, 0, sb, c->widths, c->db.rowcount);
+  HIPCHK(hipGetLastError());
+  if (scale0) HIPCHK(hipMemcpyAsync(scale0, c->diag0, nb, hipMemcpyDeviceToHost, c->s_det));
+  if (scale1) HIPCHK(hipMemcpyAsync(scale1, c->diag1, nb, hipMemcpyDeviceToHost, c->s_det));
+  if (dog) HIPCHK(hipMemcpyAsync(dog, c->sb.dog, nb, hipMemcpyDeviceToHost, c->s_det));
+  if (mag) HIPCHK(hipMemcpyAsync(mag, c->sb.mag, nb, hipMemcpyDeviceToHost, c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_det));
+  return 0;
+}
+
+int rebvio_hip_detect(rebvio_hip_ctx* c, const float* img, size_t pitch_bytes, uint64_t ts_us, rebvio_hip_map** out) {
+  HIPCHK(hipSetDevice(c->device));
+  const size_t rowb = (size_t)c->P.cols * sizeof(float);
+  if (pitch_bytes == 0) pitch_bytes = rowb;
+  HIPCHK(hipMemcpy2DAsync(c->img_dev, rowb, img, pitch_bytes, rowb, c->P.rows, hipMemcpyHostToDevice, c->s_det));
+  return detect_common(c, c->img_dev, 0, ts_us, out);
+}
+
+int rebvio_hip_detect_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_map** out) {
+  HIPCHK(hipSetDevice(c->device));
+  return detect_common(c, frame_dev, 1, ts_us, out);
+}
+
+int rebvio_hip_detector_state(rebvio_hip_ctx* c, float* threshold, float* auto_threshold, int* count) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->s_det));
+  DetState d;
+  HIPCHK(hipMemcpy(&d, c->det + (c->frame_index & 1), sizeof(d), hipMemcpyDeviceToHost));
+  if (threshold) *threshold = d.threshold;
+  if (auto_threshold) *auto_threshold = d.auto_threshold;
+  if (count) *count = d.count;
+  return 0;
+}
+
+int rebvio_hip_map_size(rebvio_hip_map* m) {
+  if (ensure_size(m)) return -1;
+  return m->n_host;
+}
+float rebvio_hip_map_threshold(rebvio_hip_map* m) {
+  if (ensure_size(m)) return std::numeric_limits<float>::quiet_NaN();
+  return m->thr_host;
+}
+uint64_t rebvio_hip_map_ts(rebvio_hip_map* m) { return m->ts; }
+
+int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int* mask) {
+  rebvio_hip_ctx* c = m->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  int rc = ensure_size(m);
+  if (rc) return rc;
+  // mirror reflects everything enqueued so far on both streams
+  HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  if (keylines && m->n_host > 0) {
+    launch_map_pack(c->s_cpy, c->K, m->d, c->aos_dev);
+    HIPCHK(hipMemcpyAsync(keylines, c->aos_dev, (size_t)m->n_host * sizeof(rebvio_hip_keyline), hipMemcpyDeviceToHost, c->s_cpy));
+  }
+  if (mask)
+    HIPCHK(hipMemcpyAsync(mask, m->d.mask, (size_t)c->P.rows * c->P.cols * sizeof(int), hipMemcpyDeviceToHost, c->s_cpy));
+  HIPCHK(hipStreamSynchronize(c->s_cpy));
+  return 0;
+}
+
+int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines, int n) {
+  rebvio_hip_ctx* c = m->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  int rc = ensure_size(m);
+  if (rc) return rc;
+  if (n != m->n_host) return fail_msg("map_upload: count differs from map size", -6);
+  HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(c->aos_dev, keylines, (size_t)n * sizeof(rebvio_hip_keyline), hipMemcpyHostToDevice, c->s_cpy));
+    launch_map_unpack(c->s_cpy, c->K, m->d, c->aos_dev, n);
+  }
+  HIPCHK(hipStreamSynchronize(c->s_cpy));
+  m->df_built = false;
+  return 0;
+}
+
+void rebvio_hip_map_release(rebvio_hip_map* m) {
+  if (!m || !m->in_use) return;
+  rebvio_hip_ctx* c = m->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipEventRecord(m->done, c->s_trk);
+  m->has_done = true;
+  if (c->df_map == m) c->df_map = nullptr;
+  m->in_use = false;
+}
+
+int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  if (!m->df_built) {
+    HIPCHK(hipMemsetAsync(m->d.df, 0xFF, (size_t)c->P.rows * c->P.cols * sizeof(unsigned), c->s_trk));
+    const DetState* dprev = c->det + (c->frame_index & 1);
+    launch_df_build(c->s_trk, c->K, m->d, dprev, c->det + 2);
+    HIPCHK(hipGetLastError());
+    m->df_built = true;
+  }
+  c->df_map = m;
+  return 0;
+}
+
+int rebvio_hip_distance_field(rebvio_hip_ctx* c, int* id_out, int* dist_out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->df_map) return fail_msg("no distance field built", -7);
+  const size_t Pn = (size_t)c->P.rows * c->P.cols;
+  launch_df_decode(c->s_trk, c->K, c->df_map->d, c->scratch_i, c->scratch_i + Pn);
+  HIPCHK(hipGetLastError());
+  if (id_out) HIPCHK(hipMemcpyAsync(id_out, c->scratch_i, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
+  if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, c->scratch_i + Pn, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  return 0;
+}
+
+int rebvio_hip_rotate(rebvio_hip_ctx* c, rebvio_hip_map* m, const float R[9]) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  launch_rotate(c->s_trk, c->K, m->d, R, nullptr, 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int rebvio_hip_quantile(rebvio_hip_ctx* c, rebvio_hip_map* m, float percentile, int num_bins, float* out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (num_bins < 1 || num_bins > 128) return fail_msg("num_bins must be in 1..128", -3);
+  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  launch_quantile(c->s_trk, c->K, m->d, c->hist, percentile, num_bins, c->fscratch);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_f, c->fscratch, sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  *out = c->h_f[0];
+  return 0;
+}
+
+int rebvio_hip_try_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, const float vel[3], float sigma_rho_min, float* residuals,
+                       float out10[10]) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->df_map) return fail_msg("try_vel needs a distance field", -7);
+  int rc = ensure_size(m);
+  if (rc) return rc;
+  const int n = m->n_host;
+  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  if (n > 0) HIPCHK(hipMemcpyAsync(m->d.residual, residuals, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->s_trk));
+  LmState st;
+  std::memset(&st, 0, sizeof(st));
+  for (int i = 0; i < 3; ++i) st.Vnew[i] = st.vel[i] = vel[i];
+  st.sigma_rho_min = sigma_rho_min;
+  c->h_lm[1] = st;
+  HIPCHK(hipMemcpyAsync(c->lm, &c->h_lm[1], sizeof(LmState), hipMemcpyHostToDevice, c->s_trk));
+  launch_try_vel(c->s_trk, c->K, m->d, c->df_map->d, 0, 0, 0, c->lm, c->lm + 1, c->part, c->part, c->hist, 0);
+  HIPCHK(hipGetLastError());
+  const int nb = std::max(1, div_up(n, 256));
+  HIPCHK(hipMemcpyAsync(c->h_part, c->part, (size_t)nb * kPartStride * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
+  if (n > 0) HIPCHK(hipMemcpyAsync(residuals, m->d.residual, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  for (int k = 0; k < 10; ++k) {
+    float acc = 0.f;  // same fixed order as the device-side reducer
+    for (int b = 0; b < div_up(n, 256); ++b) acc += c->h_part[(size_t)b * kPartStride + k];
+    out10[k] = acc;
+  }
+  // resolve cross-workgroup carry markers (a later device call would do this in its prologue)
+  float carry = 0.f;
+  for (int b = 0; b < div_up(n, 256); ++b) {
+    const int lo = b * 256, hi = std::min(n, lo + 256);
+    for (int i = lo; i < hi; ++i)
+      if (residuals[i] == kResidualCarry) residuals[i] = std::fabs(carry);
+    if (c->h_part[(size_t)b * kPartStride + 10] != 0.f) carry = c->h_part[(size_t)b * kPartStride + 11];
+  }
+  return 0;
+}
+
+int rebvio_hip_minimize_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, float vel[3], float Rvel[9], float* F, int* accept_mask,
+                            float* sigma_rho_min) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->df_map) return fail_msg("minimize_vel needs a distance field", -7);
+  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(hipMemsetAsync(m->d.residual, 0, (size_t)c->P.keylines_max * sizeof(float), c->s_trk));
+  HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));
+  // histogram of sigma_rho for estimateQuantile (core.cpp:153)
+  launch_quantile(c->s_trk, c->K, m->d, c->hist, c->P.quantile_cutoff, c->P.quantile_num_bins, c->fscratch);
+  enqueue_lm_chain(c, m, c->df_map, vel);
+  const int calls = (int)c->P.iterations + 1;
+  launch_lm_final(c->s_trk, m->d, calls, c->lm + calls, c->lm + calls + 1,
+                  c->part + (size_t)(calls - 1) * part_call_stride(c));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&c->h_lm[0], c->lm + calls + 1, sizeof(LmState), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  lm_to_out(c->h_lm[0], vel, Rvel, F, accept_mask, sigma_rho_min);
+  return 0;
+}
+
+int rebvio_hip_forward_match(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamWaitEvent(c->s_trk, om->ready, 0));
+  HIPCHK(hipStreamWaitEvent(c->s_trk, nm->ready, 0));
+  launch_forward_keys(c->s_trk, c->K, om->d, nm->d);
+  const float v0[3] = {0, 0, 0};
+  launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 0, 0, c->lm, c->lm, c->part, c->xrv_part, v0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int rebvio_hip_ext_rot_vel(rebvio_hip_ctx* c, const float vel[3], float Wx[36], float JtF[6], float X[6], int* ok) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->df_map) return fail_msg("ext_rot_vel needs a distance field", -7);
+  rebvio_hip_map* nm = c->df_map;
+  int rc = ensure_size(nm);
+  if (rc) return rc;
+  launch_ext_rot_vel(c->s_trk, c->K, nm->d, nm->d, 0, 0, 0, c->lm, c->lm, c->part, c->xrv_part, vel);
+  HIPCHK(hipGetLastError());
+  const int nb = std::max(1, div_up(nm->n_host, 256));
+  HIPCHK(hipMemcpyAsync(c->h_xrv, c->xrv_part, (size_t)nb * kXrvStride * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  float jtf[6];
+  sum_xrv(c->h_xrv, div_up(nm->n_host, 256), Wx, jtf, nullptr);
+  if (JtF) std::memcpy(JtF, jtf, sizeof(jtf));
+  hm::sym6_pinv_solve(Wx, jtf, X);
+  int good = 1;
+  for (int i = 0; i < 6; ++i)
+    if (std::isnan(X[i])) good = 0;
+  if (ok) *ok = good;
+  return 0;
+}
+
+int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_map* om, const float vel[3],
+                              const float Rvel[9], const float Rback[9], float max_radius, int* matches, int* kf_matches) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamWaitEvent(c->s_trk, om->ready, 0));
+  HIPCHK(hipStreamWaitEvent(c->s_trk, nm->ready, 0));
+  float vel_r[3], Rvel_r[9];
+  rotate_inputs(c, vel, Rvel, Rback, vel_r, Rvel_r);
+  HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 3 * sizeof(int), c->s_trk));
+  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius);
+  HIPCHK(hipGetLastError());
+  MapState st;
+  int rc = fetch_map_state(nm, &st, c->s_trk);
+  if (rc) return rc;
+  if (matches) *matches = st.dm_matches;
+  if (kf_matches) *kf_matches = st.dm_kf;
+  return 0;
+}
+
+int rebvio_hip_regularize(rebvio_hip_ctx* c, rebvio_hip_map* m, int* count) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(hipMemsetAsync(&m->d.st->reg_count, 0, sizeof(int), c->s_trk));
+  launch_regularize(c->s_trk, c->K, m->d, 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(m->d.rs, m->d.rs_tmp, (size_t)c->P.keylines_max * sizeof(float2), hipMemcpyDeviceToDevice, c->s_trk));
+  MapState st;
+  int rc = fetch_map_state(m, &st, c->s_trk);
+  if (rc) return rc;
+  if (count) *count = st.reg_count;
+  return 0;
+}
+
+int rebvio_hip_update_inverse_depth(rebvio_hip_ctx* c, const float vel[3]) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->df_map) return fail_msg("update_inverse_depth needs a distance field", -7);
+  launch_depth_ekf(c->s_trk, c->K, c->df_map->d, vel, 0, 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float* R_prior, float frame_dt,
+                          rebvio_hip_pair_out* out) {
+  HIPCHK(hipSetDevice(c->device));
+  std::memset(out, 0, sizeof(*out));
+  hipStream_t s = c->s_trk;
+  HIPCHK(hipStreamWaitEvent(s, om->ready, 0));
+  HIPCHK(hipStreamWaitEvent(s, nm->ready, 0));
+  int rc = rebvio_hip_build_distance_field(c, nm);  // rebvio.cpp:142 (no-op when detect already built it)
+  if (rc) return rc;
+
+  // R = imu.R(); R.T() = SO3(Bg) * R.T()  (rebvio.cpp:163-164)
+  hm::M3 R = R_prior ? hm::load3(R_prior) : hm::identity3();
+  R = hm::transpose(hm::mul(hm::so3_exp(c->Bg), hm::transpose(R)));
+  float RT[9];
+  hm::store3(hm::transpose(R), RT);
+
+  HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), s));
+  launch_rotate(s, c->K, om->d, RT, c->hist, 0);  // rebvio.cpp:165 (+ histogram for estimateQuantile)
+  const float v0[3] = {0, 0, 0};                  // imu_state_.Vg = Zeros (rebvio.cpp:167)
+  enqueue_lm_chain(c, om, nm, v0);                // minimizeVel (rebvio.cpp:169)
+  const int calls = (int)c->P.iterations + 1;
+  // forwardMatch + extRotVel (rebvio.cpp:172-177), LM's last accept/reject in the prologue
+  launch_ext_rot_vel(s, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
+                     c->part + (size_t)(calls - 1) * part_call_stride(c), c->xrv_part, v0);
+  HIPCHK(hipGetLastError());
+  const int nbmax = c->maxblocks;
+  HIPCHK(hipMemcpyAsync(&c->h_lm[0], c->lm + calls + 1, sizeof(LmState), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(c->h_xrv, c->xrv_part, (size_t)nbmax * kXrvStride * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&c->h_st[1], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+
+  nm->n_host = c->h_st[1].n;
+  nm->thr_host = c->h_st[1].threshold;
+  float Vg[3], P_Vg[9];
+  lm_to_out(c->h_lm[0], Vg, P_Vg, &out->F, &out->lm_accept_mask, &out->sigma_rho_min);
+  float Xv[6], W_Xv[36], JtF6[6];
+  sum_xrv(c->h_xrv, div_up(nm->n_host, 256), W_Xv, JtF6, nullptr);
+  hm::sym6_pinv_solve(W_Xv, JtF6, Xv);
+  out->ext_ok = 1;
+  for (int i = 0; i < 6; ++i)
+    if (std::isnan(Xv[i])) out->ext_ok = 0;
+
+  float Xgv[6], W_Xgv[36];
+  std::memcpy(Xgv, Xv, sizeof(Xv));
+  std::memcpy(W_Xgv, W_Xv, sizeof(W_Xv));
+  // rebvio.cpp:186-191
+  const float s_b = c->P.gyro_bias_std_dev * c->P.gyro_bias_std_dev * frame_dt * frame_dt;
+  const float s_g = c->P.gyro_std_dev * c->P.gyro_std_dev * frame_dt * frame_dt;
+  c->RGBias = hm::diag3(s_b);
+  c->RGyro = hm::diag3(s_g);
+  float dg[3];
+  hm::gyro_bias_correction(Xgv, W_Xgv, c->W_Bg, c->RGyro, c->RGBias, dg);
+  for (int i = 0; i < 3; ++i) c->Bg[i] += dg[i];
+  const float dVgv[3] = {Xgv[0], Xgv[1], Xgv[2]};
+  const float dWgv[3] = {Xgv[3], Xgv[4], Xgv[5]};
+  // rebvio.cpp:195-203
+  const hm::M3 R0 = hm::so3_exp(dWgv);
+  R = hm::transpose(hm::mul(R0, hm::transpose(R)));
+  float V[3];
+  hm::mulv(R0, Vg, V);
+  for (int i = 0; i < 3; ++i) V[i] += dVgv[i];
+  float R_Xgv[36];
+  hm::cholesky6_inverse(W_Xgv, R_Xgv);
+  float P_V[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) P_V[i * 3 + j] = R_Xgv[i * 6 + j];
+  float Rgva[9], R0a[9];
+  hm::store3(R, Rgva);  // rebvio.cpp:228
+  hm::store3(R0, R0a);
+
+  for (int i = 0; i < 3; ++i) { out->Vg[i] = Vg[i]; out->V[i] = V[i]; }
+  std::memcpy(out->P_Vg, P_Vg, sizeof(P_Vg));
+  std::memcpy(out->Xv, Xv, sizeof(Xv));
+  std::memcpy(out->W_Xv, W_Xv, sizeof(W_Xv));
+  std::memcpy(out->Xgv, Xgv, sizeof(Xgv));
+  std::memcpy(out->R, Rgva, sizeof(Rgva));
+  std::memcpy(out->P_V, P_V, sizeof(P_V));
+
+  launch_rotate(s, c->K, om->d, R0a, nullptr, 0);  // rebvio.cpp:232
+  if (std::isnan(V[0]) || std::isnan(V[1]) || std::isnan(V[2])) {  // rebvio.cpp:236
+    out->status = 1;
+    return 0;
+  }
+  float vel_r[3], Rvel_r[9];
+  rotate_inputs(c, V, P_V, Rgva, vel_r, Rvel_r);
+  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, Rgva, c->P.search_range);  // rebvio.cpp:245
+  const int gate = (int)c->P.global_min_matches_threshold;
+  launch_regularize(s, c->K, nm->d, gate > 0 ? gate : 0);  // rebvio.cpp:256 (skipped on device when klm < gate)
+  launch_depth_ekf(s, c->K, nm->d, V, 1, gate > 0 ? gate : 0);  // rebvio.cpp:259
+  HIPCHK(hipGetLastError());
+  if (gate <= 0) {
+    // no gate: regularize always ran; depth filter consumed rs_tmp
+  }
+  HIPCHK(hipMemcpyAsync(&c->h_st[1], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  out->klm_num = c->h_st[1].dm_matches;
+  out->kf_matches = c->h_st[1].dm_kf;
+  out->reg_num = c->h_st[1].reg_count;
+  if ((unsigned)out->klm_num < c->P.global_min_matches_threshold) out->status = 2;  // rebvio.cpp:247-252
+  return 0;
+}
+
+int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
+                                    int* keylines) {
+  rebvio_hip_map* m = nullptr;
+  int rc = rebvio_hip_detect_u8_device(c, frame_dev, ts_us, &m);  // asynchronous on the detect stream
+  if (rc) return rc;
+  if (out) {
+    std::memset(out, 0, sizeof(*out));
+    out->status = -1;
+  }
+  if (keylines) *keylines = -1;
+  if (c->pend_old && c->pend_new) {
+    rebvio_hip_pair_out tmp;
+    const float dt = (float)((double)(float)(c->pend_new->ts - c->pend_old->ts) / 1000000.0);  // rebvio.cpp:183
+    rc = rebvio_hip_track_pair(c, c->pend_old, c->pend_new, nullptr, dt, out ? out : &tmp);
+    if (rc) return rc;
+    if (keylines) *keylines = c->pend_new->n_host;
+    rebvio_hip_map_release(c->pend_old);
+  }
+  c->pend_old = c->pend_new;
+  c->pend_new = m;
+  return 0;
+}
+
+int rebvio_hip_flush(rebvio_hip_ctx* c) {
+  HIPCHK(hipSetDevice(c->device));
+  if (c->pend_old) rebvio_hip_map_release(c->pend_old);
+  if (c->pend_new) rebvio_hip_map_release(c->pend_new);
+  c->pend_old = c->pend_new = nullptr;
+  HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  return 0;
+}
+
+int rebvio_hip_profile_enable(rebvio_hip_ctx* c, int on) {
+  (void)c;
+  std::lock_guard<std::mutex> g(g_prof.mu);
+  g_prof.on = on != 0;
+  return 0;
+}
+
+int rebvio_hip_profile_select(rebvio_hip_ctx* c, const char* only_kernel) {
+  (void)c;
+  std::lock_guard<std::mutex> g(g_prof.mu);
+  g_prof.only = only_kernel ? only_kernel : "";
+  return 0;
+}
+
+int rebvio_hip_profile_reset(rebvio_hip_ctx* c) {
+  (void)c;
+  std::lock_guard<std::mutex> g(g_prof.mu);
+  g_prof.drain();
+  g_prof.acc.clear();
+  return 0;
+}
+
+int rebvio_hip_profile_read(rebvio_hip_ctx* c, char* names, size_t names_cap, double* avg_us, int* calls, int cap) {
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> g(g_prof.mu);
+  g_prof.drain();
+  std::string all;
+  int k = 0;
+  for (auto& kv : g_prof.acc) {
+    if (k >= cap) break;
+    const std::string& nm = g_prof.names[kv.first];
+    if (all.size() + nm.size() + 2 > names_cap) break;
+    all += nm;
+    all += '\n';
+    avg_us[k] = kv.second.second ? kv.second.first / kv.second.second : 0.0;
+    calls[k] = kv.second.second;
+    ++k;
+  }
+  if (names_cap) {
+    std::strncpy(names, all.c_str(), names_cap - 1);
+    names[names_cap - 1] = 0;
+  }
+  return k;
+}
+
+int rebvio_hip_device_alloc(rebvio_hip_ctx* c, size_t bytes, void** out) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(out, bytes));
+  return 0;
+}
+int rebvio_hip_device_free(rebvio_hip_ctx* c, void* p) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipFree(p));
+  return 0;
+}
+int rebvio_hip_device_upload(rebvio_hip_ctx* c, void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // extern "C"

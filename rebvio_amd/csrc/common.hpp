@@ -1,0 +1,167 @@
+// Internal structures shared by the HIP kernels and the C-ABI host code (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rebvio_hip.h"
+
+namespace rh {
+
+constexpr int kWave = 64;           // CDNA wavefront
+constexpr int kBlock = 256;         // 4 waves
+constexpr int kNumBins = 100;       // EdgeDetectorConfig::num_bins (edge_detector.hpp:29)
+constexpr int kMaxImageValue = 765; // edge_detector.cpp:21
+constexpr unsigned kDfEmpty = 0xFFFFFFFFu;
+constexpr int kDfSeqBits = 23;
+constexpr unsigned kDfSeqMask = (1u << kDfSeqBits) - 1u;
+constexpr int kPartStride = 16;     // floats per block record of k_try_vel
+constexpr int kXrvStride = 32;      // floats per block record of k_ext_rot_vel
+constexpr int kMaxLmCalls = 8;
+constexpr float kResidualCarry = -1.0f;  // marker: "|fi| carried in from an earlier block" (see try_vel)
+
+// Device-resident per-map scalars.
+struct MapState {
+  int n;               // keylines kept (min(total, keylines_max))
+  int total;           // candidates found before truncation
+  unsigned gmin_bits;  // min / max gradient_norm as IEEE bits (values are >= 0)
+  unsigned gmax_bits;
+  float threshold;     // EdgeMap::threshold_ (edge_map.hpp:132)
+  int dm_matches;      // directedMatch counters
+  int dm_kf;
+  int reg_count;
+  int pad[8];
+};
+
+// EdgeDetector servo state (edge_detector.hpp:84-91), ping-ponged between frames.
+struct DetState {
+  float threshold;       // config_->threshold
+  int count;             // keylines_count_ of the previous detect
+  float auto_threshold;  // auto_threshold_
+  int pad;
+};
+
+// SoA view of one edge map in HBM (capacity keylines_max). float2 pairs keep gathers at 8 bytes.
+struct MapDev {
+  float2* pos;       // KeyLine::pos
+  float2* pos_img;   // KeyLine::pos_img
+  float2* mpos_img;  // KeyLine::match_pos_img
+  float2* grad;      // KeyLine::gradient
+  float2* mgrad;     // KeyLine::match_gradient
+  float* gnorm;      // KeyLine::gradient_norm
+  float* mgnorm;     // KeyLine::match_gradient_norm
+  float2* rs;        // (rho, sigma_rho)
+  float2* rs_tmp;    // regularize1Iter staging
+  int* id_prev;
+  int* id_next;
+  int* match_id;
+  int* match_fwd;    // match_id_forward
+  int* match_kf;     // match_id_keyframe
+  unsigned* matches;
+  unsigned long long* fwd_key;  // forwardMatch winner key per keyline of this (new) map
+  float* residual;              // minimizeVel's residuals[] for this (old) map
+  int* mask;                    // dense image index -> keyline index
+  unsigned* df;                 // distance field keys built from this map
+  MapState* st;
+};
+
+struct KParams {
+  int rows, cols;
+  float fm, cx, cy;
+  int kmax, kref;
+  float pos_neg_threshold, dog_threshold, gain, max_threshold, min_threshold;
+  float search_range, reweight_distance, match_treshold;
+  unsigned min_match_threshold;
+  float pixel_uncertainty, quantile_cutoff;
+  int quantile_num_bins;
+  float reshape_q_abs;
+  float pixel_uncertainty_match, match_threshold_norm, cang_min_edge, regularization_threshold;
+  int nseg;  // ceil(cols / 64)
+  int df_nr; // 2 * search_range
+};
+
+// Levenberg-Marquardt state of minimizeVel kept on the device (core.cpp:150-189).
+struct LmState {
+  float vel[3];
+  float F;
+  float JtJ[6];  // (0,0) (1,1) (2,2) (0,1) (0,2) (1,2)
+  float JtF[3];
+  float u, v;
+  float Vnew[3];
+  float h[3];
+  float sigma_rho_min;
+  int accept_mask;
+  int pad[4];
+};
+
+// x86 cvttss2si / cvttsd2si semantics (NaN / out of range -> INT_MIN), see oracle header.
+__host__ __device__ inline int cvtt_f32(float v) {
+  if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (int)0x80000000;
+  return (int)v;
+}
+__host__ __device__ inline int cvtt_f64(double v) {
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+  return (int)v;
+}
+
+// ---- launchers (defined in detect.hip / track.hip) ------------------------------------------------
+struct ScaleBufs {
+  float* a[2];  // per filter: scan buffer A
+  float* b[2];  // per filter: scan buffer B
+  float* dog;
+  float* mag;
+  float* scale0;  // optional diagnostics (may be null)
+  float* scale1;
+};
+
+struct DetectBufs {
+  float4* stash;              // per pixel plane-fit result of candidates
+  unsigned long long* bits;   // [rows][nseg] candidate ballots
+  int* rowcount;              // [rows]
+};
+
+void upload_tables(const float* recip128, const float* pinv75);
+
+void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
+                        const int widths[2][3], int* rowcount_to_zero);
+void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
+                     const DetState* det_in, DetState* det_out, uint64_t frame_index);
+void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, DetState* det_cur);
+void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out);
+
+void launch_rotate(hipStream_t s, const KParams& p, const MapDev& m, const float R[9], int* hist_or_null,
+                   int zero_dm_counters);
+void launch_quantile(hipStream_t s, const KParams& p, const MapDev& m, int* hist, float pct, int bins, float* out_dev);
+void launch_try_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int mode_lm, int call,
+                    int last, LmState* st_in, LmState* st_out, const float* part_prev, float* part_out, const int* hist,
+                    int frame_count);
+void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
+                        int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
+                        float* xrv_part, const float* vel_manual);
+void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm);
+void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
+void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
+                           const float Rvel[9], const float Rback[9], float max_radius);
+void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate);
+void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp,
+                      int min_matches_gate);
+void launch_map_pack(hipStream_t s, const KParams& p, const MapDev& m, rebvio_hip_keyline* aos_dev);
+void launch_map_unpack(hipStream_t s, const KParams& p, const MapDev& m, const rebvio_hip_keyline* aos_dev, int n);
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Optional per-kernel timing with HIP events recorded on the launching stream (api.hip).
+void prof_begin(hipStream_t s, const char* name);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s;
+  ProfScope(hipStream_t s_, const char* name) : s(s_) { prof_begin(s, name); }
+  ~ProfScope() { prof_end(s); }
+};
+#define RH_LAUNCH(kernel, grid, block, shm, stream, ...)                 \
+  do {                                                                   \
+    ::rh::ProfScope _ps(stream, #kernel);                                \
+    hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);   \
+  } while (0)
+
+}  // namespace rh

@@ -1,0 +1,528 @@
+// Edge detection on gfx950: integral-image box filters (bit-exact evaluation order of the reference),
+// DoG + squared gradient, keyline extraction with ordered (raster-rank) compaction, edge chaining,
+// auto-threshold statistics and the integer distance field.
+//
+// Reference semantics (baumlin/rebvio): scale_space.cpp:48-128,203-233; edge_detector.cpp:30-186;
+// core.hpp:37-71. All kernels are compiled with -ffp-contract=off: every +,-,* is a separately
+// rounded fp32 operation exactly as in the CPU path, divisions and sqrt are IEEE correctly rounded.
+//
+// Bound: HBM/L2 bandwidth for the per-pixel sweeps; the two scan kernels are additionally bound by
+// their sequential fp32 add chains (cols resp. rows dependent adds) which bit-exactness requires.
+#include "common.hpp"
+
+namespace rh {
+
+__constant__ float c_recip[128];  // c_recip[n] = float(1.0 / double(n))  (scale_space.cpp:166-170)
+__constant__ float c_pinv[75];    // Pinv = invert(Phi^T Phi) Phi^T, 3 x 25 (edge_detector.cpp:55-68)
+
+void upload_tables(const float* recip128, const float* pinv75) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_recip), recip128, sizeof(float) * 128);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pinv), pinv75, sizeof(float) * 75);
+}
+
+// FastGaussian::average (scale_space.cpp:69-128): the nine border/interior cases with their distinct
+// operand orders. II is the integral image, d the box width.
+__device__ __forceinline__ float box_avg(const float* __restrict__ II, int r, int c, int d, int R, int C) {
+  const int d2 = d >> 1;
+  const bool top = r < d2 + 1, bot = r >= R - d2;
+  const bool left = c < d2 + 1, right = c >= C - d2;
+  const int r1 = (bot && !top) ? R - 1 : r + d2;
+  const int c1 = (right && !left) ? C - 1 : c + d2;
+  const int ny = top ? r + d2 + 1 : (bot ? R - r + d2 : d);
+  const int nx = left ? c + d2 + 1 : (right ? C - c + d2 : d);
+  const float div = c_recip[nx * ny];
+  const float A = II[(size_t)r1 * C + c1];
+  float acc;
+  if (top) {
+    acc = left ? A : A - II[(size_t)r1 * C + (c - d2 - 1)];
+  } else {
+    const int r2 = r - d2 - 1;
+    const float Cc = II[(size_t)r2 * C + c1];
+    if (left) {
+      acc = A - Cc;
+    } else {
+      const int c2 = c - d2 - 1;
+      const float B = II[(size_t)r1 * C + c2];
+      const float D = II[(size_t)r2 * C + c2];
+      acc = bot ? (((A - Cc) - B) + D) : (((A - B) - Cc) + D);
+    }
+  }
+  return acc * div;
+}
+
+// ---- row prefix (scale_space.cpp:50-57) ---------------------------------------------------------------
+// One workgroup stages a strip of kStrip rows in LDS with coalesced 16-byte accesses (for passes 2 and 3
+// the box average of the previous integral image is evaluated on the fly), then one lane per row walks
+// its row left to right: a sequential fp32 chain, which is what keeps the result bit-identical to the
+// CPU. LDS row pitch = cols + pad with (pitch/4) odd: the 16 row-lanes' ds_read/write_b128 hit 16
+// distinct 4-bank groups.
+constexpr int kStrip = 16;
+
+template <int MODE>  // 0: u8 image * 3.0f, 1: fp32 image, 2: box average (width d) of an integral image
+__global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, const void* __restrict__ src1,
+                                                 float* __restrict__ dst0, float* __restrict__ dst1, int R, int C, int d0,
+                                                 int d1, int ldw) {
+  extern __shared__ float4 smem4[];
+  float* tile = reinterpret_cast<float*>(smem4);
+  const int f = blockIdx.y;
+  const void* __restrict__ src = f ? src1 : src0;
+  float* __restrict__ dst = f ? dst1 : dst0;
+  const int d = f ? d1 : d0;
+  const int r0 = blockIdx.x * kStrip;
+  const int nrows = min(kStrip, R - r0);
+  const int C4 = C >> 2;
+  const int total = nrows * C4;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int lr = i / C4, c4 = i - lr * C4;
+    const int r = r0 + lr, c = c4 * 4;
+    float4 v;
+    if (MODE == 0) {
+      const uchar4 u = reinterpret_cast<const uchar4*>(src)[(size_t)r * C4 + c4];
+      v = make_float4((float)u.x * 3.0f, (float)u.y * 3.0f, (float)u.z * 3.0f, (float)u.w * 3.0f);
+    } else if (MODE == 1) {
+      v = reinterpret_cast<const float4*>(src)[(size_t)r * C4 + c4];
+    } else {
+      const float* II = reinterpret_cast<const float*>(src);
+      v.x = box_avg(II, r, c, d, R, C);
+      v.y = box_avg(II, r, c + 1, d, R, C);
+      v.z = box_avg(II, r, c + 2, d, R, C);
+      v.w = box_avg(II, r, c + 3, d, R, C);
+    }
+    *reinterpret_cast<float4*>(&tile[lr * ldw + c]) = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nrows) {
+    float* rowp = tile + threadIdx.x * ldw;
+    float4 v = *reinterpret_cast<float4*>(rowp);
+    v.y = v.x + v.y;
+    v.z = v.y + v.z;
+    v.w = v.z + v.w;
+    *reinterpret_cast<float4*>(rowp) = v;
+    float s = v.w;
+#pragma unroll 4
+    for (int c = 4; c < C; c += 4) {
+      float4 w = *reinterpret_cast<float4*>(rowp + c);
+      w.x = s + w.x;
+      w.y = w.x + w.y;
+      w.z = w.y + w.z;
+      w.w = w.z + w.w;
+      s = w.w;
+      *reinterpret_cast<float4*>(rowp + c) = w;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int lr = i / C4, c4 = i - lr * C4;
+    reinterpret_cast<float4*>(dst)[(size_t)(r0 + lr) * C4 + c4] = *reinterpret_cast<float4*>(&tile[lr * ldw + c4 * 4]);
+  }
+}
+
+// ---- column accumulation (scale_space.cpp:59-65): one lane per column, coalesced rows, sequential chain
+__global__ __launch_bounds__(64) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C) {
+  float* __restrict__ buf = blockIdx.y ? buf1 : buf0;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float* p = buf + c;
+  float s = p[0];
+  int r = 1;
+  constexpr int U = 16;
+  for (; r + U <= R; r += U) {
+    float v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = p[(size_t)(r + k) * C];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      s = v[k] + s;
+      p[(size_t)(r + k) * C] = s;
+    }
+  }
+  for (; r < R; ++r) {
+    s = p[(size_t)r * C] + s;
+    p[(size_t)r * C] = s;
+  }
+}
+
+// ---- last box pass of both filters fused with DoG and squared gradient (scale_space.cpp:210-233) ------
+__global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, const float* __restrict__ II1, int d0,
+                                                 int d1, float* __restrict__ dog, float* __restrict__ mag,
+                                                 float* __restrict__ scale0, float* __restrict__ scale1, int R, int C,
+                                                 int* __restrict__ rowcount) {
+  __shared__ float s0[6][66];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int i = tid; i < 6 * 66; i += 256) {
+    const int lr = i / 66, lc = i - lr * 66;
+    const int r = r0 + lr - 1, c = c0 + lc - 1;
+    s0[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? box_avg(II0, r, c, d0, R, C) : 0.0f;
+  }
+  __syncthreads();
+  const int r = r0 + threadIdx.y, c = c0 + threadIdx.x;
+  if (r >= R || c >= C) return;
+  if (c == 0) rowcount[r] = 0;  // reset for the candidate kernel of this frame
+  const float v0 = s0[threadIdx.y + 1][threadIdx.x + 1];
+  const float v1 = box_avg(II1, r, c, d1, R, C);
+  const size_t i = (size_t)r * C + c;
+  dog[i] = v1 - v0;
+  float m = 0.0f;
+  if (r >= 1 && r < R - 1 && c >= 1 && c < C - 1) {
+    const float dx = s0[threadIdx.y + 1][threadIdx.x + 2] - s0[threadIdx.y + 1][threadIdx.x];
+    const float dy = s0[threadIdx.y + 2][threadIdx.x + 1] - s0[threadIdx.y][threadIdx.x + 1];
+    m = dx * dx + dy * dy;
+  }
+  mag[i] = m;
+  if (scale0) scale0[i] = v0;
+  if (scale1) scale1[i] = v1;
+}
+
+// Threshold servo of EdgeDetector::detect (edge_detector.cpp:33-36), evaluated identically by every thread.
+__device__ __forceinline__ float servo_threshold(const KParams& p, const DetState& d) {
+  float t = d.threshold;
+  if (p.gain > 0) {
+    t -= p.gain * float(p.kref - d.count);
+    t = (t > p.max_threshold) ? p.max_threshold : ((t < p.min_threshold) ? p.min_threshold : t);
+  }
+  return t;
+}
+
+// ---- candidate test + plane fit (edge_detector.cpp:73-107) ---------------------------------------------
+// Tile = 4 rows x 64 columns; each wavefront is one 64-pixel row segment, so a __ballot is exactly the
+// raster-ordered candidate set of that segment.
+__global__ __launch_bounds__(256) void k_keyline_flag(const float* __restrict__ dog, const float* __restrict__ mag,
+                                                      KParams p, const DetState* __restrict__ det_in,
+                                                      float4* __restrict__ stash, unsigned long long* __restrict__ bits,
+                                                      int* __restrict__ rowcount) {
+  __shared__ float sd[8][68];
+  const int R = p.rows, C = p.cols;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int i = tid; i < 8 * 68; i += 256) {
+    const int lr = i / 68, lc = i - lr * 68;
+    const int r = r0 + lr - 2, c = c0 + lc - 2;
+    sd[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? dog[(size_t)r * C + c] : 0.0f;
+  }
+  __syncthreads();
+  const float thr = servo_threshold(p, *det_in);
+  const float pn_threshold = float((2.0 * 2 + 1.0) * (2.0 * 2 + 1.0)) * p.pos_neg_threshold;
+  const float gradient_threshold_squared = (thr * kMaxImageValue * p.dog_threshold) * (thr * kMaxImageValue * p.dog_threshold);
+  const float mag_threshold = (thr * kMaxImageValue) * (thr * kMaxImageValue);
+
+  const int r = r0 + threadIdx.y, c = c0 + threadIdx.x;
+  bool cand = false;
+  float4 fit = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r >= 2 && r < R - 2 && c >= 2 && c < C - 2) {
+    const float mg = mag[(size_t)r * C + c];
+    if (!(mg < mag_threshold)) {
+      int pn = 0;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 25; ++k) {
+        const float y = sd[threadIdx.y + k / 5][threadIdx.x + k % 5];
+        pn = (y > 0.0f) ? pn + 1 : pn - 1;
+        t0 += c_pinv[k] * y;
+        t1 += c_pinv[25 + k] * y;
+        t2 += c_pinv[50 + k] * y;
+      }
+      if (!(fabsf((float)pn) > pn_threshold)) {
+        const float g2 = t0 * t0 + t1 * t1;
+        const float tmp = t2 / g2;
+        const float xs = -t0 * tmp;
+        const float ys = -t1 * tmp;
+        if (!(fabsf(xs) > 0.5f || fabsf(ys) > 0.5f)) {
+          if (!(g2 < gradient_threshold_squared)) {
+            cand = true;
+            fit = make_float4(t0, t1, xs, ys);
+          }
+        }
+      }
+    }
+  }
+  const unsigned long long b = __ballot(cand);
+  if (r < R && c < C && cand) stash[(size_t)r * C + c] = fit;
+  if (threadIdx.x == 0 && r < R) {
+    bits[(size_t)r * p.nseg + blockIdx.x] = b;
+    const int n = __popcll(b);
+    if (n) atomicAdd(&rowcount[r], n);
+  }
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- ordered emission (edge_detector.cpp:109-119) -------------------------------------------------------
+// rank = (#candidates in earlier rows) + (#candidates in earlier segments of this row) + (#lower lanes):
+// the raster rank of the reference's sequential loop, with truncation at keylines_max. Also rewrites the
+// whole dense mask and clears this map's distance-field cells.
+__global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const float4* __restrict__ stash,
+                                                      const unsigned long long* __restrict__ bits,
+                                                      const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
+                                                      DetState* __restrict__ det_out) {
+  const int R = p.rows, C = p.cols;
+  const int r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x;
+  if (r >= R) return;  // whole wave
+  int part = 0;
+  for (int i = lane; i < r; i += 64) part += rowcount[i];
+  if (lane < (int)blockIdx.x) part += __popcll(bits[(size_t)r * p.nseg + lane]);
+  const int offset = wave_sum(part);
+  if (r == 0 && blockIdx.x == 0) {  // one wave publishes the frame's scalars
+    int tp = 0;
+    for (int i = lane; i < R; i += 64) tp += rowcount[i];
+    const int total = wave_sum(tp);
+    if (lane == 0) {
+      const int n = min(total, p.kmax);
+      m.st->n = n;
+      m.st->total = total;
+      m.st->gmin_bits = 0x7F800000u;
+      m.st->gmax_bits = 0u;
+      m.st->dm_matches = 0;
+      m.st->dm_kf = 0;
+      m.st->reg_count = 0;
+      det_out->threshold = servo_threshold(p, *det_in);
+      det_out->count = n;
+      det_out->auto_threshold = det_in->auto_threshold;
+    }
+  }
+  if (c >= C) return;
+  const unsigned long long b = bits[(size_t)r * p.nseg + blockIdx.x];
+  const bool cand = (b >> lane) & 1ull;
+  const int rank = offset + __popcll(b & ((1ull << lane) - 1ull));
+  const size_t pix = (size_t)r * C + c;
+  int mk = -1;
+  if (cand && rank < p.kmax) {
+    mk = rank;
+    const float4 fit = stash[pix];
+    const float px = float(c) + fit.z, py = float(r) + fit.w;
+    m.pos[rank] = make_float2(px, py);
+    const float2 pi = make_float2(px - p.cx, py - p.cy);
+    m.pos_img[rank] = pi;
+    m.mpos_img[rank] = pi;
+    m.grad[rank] = make_float2(fit.x, fit.y);
+    m.mgrad[rank] = make_float2(0.f, 0.f);
+    m.gnorm[rank] = sqrtf(fit.x * fit.x + fit.y * fit.y);
+    m.mgnorm[rank] = 0.f;
+    m.rs[rank] = make_float2(1.0f, 20.0f);
+    m.id_prev[rank] = -1;
+    m.id_next[rank] = -1;
+    m.match_id[rank] = -1;
+    m.match_fwd[rank] = -1;
+    m.match_kf[rank] = -1;
+    m.matches[rank] = 0u;
+    m.fwd_key[rank] = 0ull;
+    m.residual[rank] = 0.f;
+  }
+  m.mask[pix] = mk;
+  m.df[pix] = kDfEmpty;
+}
+
+// ---- joinEdges (edge_detector.cpp:125-165) + min/max of gradient_norm for tuneThreshold (:168-174) -----
+__global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m) {
+  const int n = m.st->n;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int C = p.cols;
+  unsigned gb = 0x7F800000u, gB = 0u;
+  if (idx < n) {
+    const float2 pos = m.pos[idx];
+    const float2 g = m.grad[idx];
+    const int x = cvtt_f64((double)pos.x + 0.5);
+    const int y = cvtt_f64((double)pos.y + 0.5);
+    const float tx = -g.y, ty = g.x;
+    int dx1, dy2;  // probes: (y, x+dx1), (y+dy2, x), (y+dy2, x+dx1)
+    if (ty > 0.0f) {
+      dy2 = 1;
+      dx1 = (tx > 0.0f) ? 1 : -1;
+    } else {
+      dy2 = -1;
+      dx1 = (tx < 0.0f) ? -1 : 1;
+    }
+    int nxt = -1;
+    if (x >= 1 && x < C - 1 && y >= 1 && y < p.rows - 1) {  // always true for detected keylines
+      nxt = m.mask[(size_t)y * C + x + dx1];
+      if (nxt < 0) nxt = m.mask[(size_t)(y + dy2) * C + x];
+      if (nxt < 0) nxt = m.mask[(size_t)(y + dy2) * C + x + dx1];
+    }
+    if (nxt >= 0) {
+      atomicMax(&m.id_prev[nxt], idx);  // sequential last-writer-wins == largest index
+      m.id_next[idx] = nxt;
+    }
+    gb = gB = __float_as_uint(m.gnorm[idx]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    gb = min(gb, (unsigned)__shfl_xor((int)gb, o));
+    gB = max(gB, (unsigned)__shfl_xor((int)gB, o));
+  }
+  if ((threadIdx.x & 63) == 0 && gB != 0u) {
+    atomicMin(&m.st->gmin_bits, gb);
+    atomicMax(&m.st->gmax_bits, gB);
+  }
+}
+
+// tuneThreshold (edge_detector.cpp:167-186). With size() <= keylines_max the cumulative loop can never
+// reach keylines_max (bin 0 always holds the maximum), so it always ends at i = num_bins and the result
+// depends on min/max only; the histogram itself is dead code there.
+__device__ __forceinline__ float auto_threshold_from(const MapState& st, float previous) {
+  if (st.n <= 0) return previous;
+  const float max_dog = __uint_as_float(st.gmax_bits);
+  const float min_dog = __uint_as_float(st.gmin_bits);
+  return max_dog - float(kNumBins * (max_dog - min_dog)) / float(kNumBins);
+}
+
+// ---- DistanceField::build (core.hpp:37-59) ---------------------------------------------------------------
+// One thread per (keyline, r). Sequential semantics "smallest |r| wins, ties -> last (idx, r) visited" become
+// an order-independent atomicMin on key = |r| << 23 | (2^23-1 - (idx*nr + r+range)).
+__global__ __launch_bounds__(256) void k_df_build(KParams p, MapDev m, const DetState* __restrict__ det_prev,
+                                                  DetState* __restrict__ det_cur) {
+  const int n = m.st->n;
+  const float thr = auto_threshold_from(*m.st, det_prev->auto_threshold);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    m.st->threshold = thr;
+    det_cur->auto_threshold = thr;
+  }
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int nr = p.df_nr;
+  const int idx = gid / nr;
+  if (idx >= n) return;
+  const int ri = gid - idx * nr;
+  const int r = ri - (nr >> 1);
+  const float gn = m.gnorm[idx];
+  if (thr > 0.0f && gn < thr) return;
+  const float2 g = m.grad[idx];
+  const float2 pos = m.pos[idx];
+  const float fr = (g.y / gn) * float(r) + pos.y;
+  const float fc = (g.x / gn) * float(r) + pos.x;
+  const int row = cvtt_f32(roundf(fr));
+  const int col = cvtt_f32(roundf(fc));
+  if ((unsigned)row >= (unsigned)p.rows || (unsigned)col >= (unsigned)p.cols) return;
+  const unsigned seq = (unsigned)(idx * nr + ri);
+  const unsigned key = ((unsigned)abs(r) << kDfSeqBits) | (kDfSeqMask - seq);
+  atomicMin(&m.df[(size_t)row * p.cols + col], key);
+}
+
+__global__ __launch_bounds__(256) void k_df_decode(KParams p, MapDev m, int* __restrict__ id_out, int* __restrict__ dist_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.rows * p.cols) return;
+  const unsigned key = m.df[i];
+  int id = -1, dist = 0x7FFFFFFF;
+  if (key != kDfEmpty) {
+    id = (int)((kDfSeqMask - (key & kDfSeqMask)) / (unsigned)p.df_nr);
+    dist = (int)(key >> kDfSeqBits);
+  }
+  if (id_out) id_out[i] = id;
+  if (dist_out) dist_out[i] = dist;
+}
+
+// ---- AoS <-> SoA for the lazy host mirror of EdgeMap::keylines() (edge_map.hpp:50) ------------------------
+__global__ __launch_bounds__(256) void k_map_pack(MapDev m, rebvio_hip_keyline* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= m.st->n) return;
+  rebvio_hip_keyline k;
+  const float2 a = m.pos[idx], b = m.pos_img[idx], c = m.mpos_img[idx], g = m.grad[idx], mg = m.mgrad[idx], rs = m.rs[idx];
+  k.pos[0] = a.x; k.pos[1] = a.y;
+  k.pos_img[0] = b.x; k.pos_img[1] = b.y;
+  k.match_pos_img[0] = c.x; k.match_pos_img[1] = c.y;
+  k.gradient[0] = g.x; k.gradient[1] = g.y;
+  k.match_gradient[0] = mg.x; k.match_gradient[1] = mg.y;
+  k.gradient_norm = m.gnorm[idx];
+  k.match_gradient_norm = m.mgnorm[idx];
+  k.rho = rs.x; k.sigma_rho = rs.y;
+  k.id = -1;
+  k.id_prev = m.id_prev[idx];
+  k.id_next = m.id_next[idx];
+  k.match_id = m.match_id[idx];
+  k.match_id_forward = m.match_fwd[idx];
+  k.match_id_keyframe = m.match_kf[idx];
+  k.matches = m.matches[idx];
+  out[idx] = k;
+}
+
+__global__ __launch_bounds__(256) void k_map_unpack(MapDev m, const rebvio_hip_keyline* __restrict__ in, int n) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const rebvio_hip_keyline k = in[idx];
+  m.pos[idx] = make_float2(k.pos[0], k.pos[1]);
+  m.pos_img[idx] = make_float2(k.pos_img[0], k.pos_img[1]);
+  m.mpos_img[idx] = make_float2(k.match_pos_img[0], k.match_pos_img[1]);
+  m.grad[idx] = make_float2(k.gradient[0], k.gradient[1]);
+  m.mgrad[idx] = make_float2(k.match_gradient[0], k.match_gradient[1]);
+  m.gnorm[idx] = k.gradient_norm;
+  m.mgnorm[idx] = k.match_gradient_norm;
+  m.rs[idx] = make_float2(k.rho, k.sigma_rho);
+  m.id_prev[idx] = k.id_prev;
+  m.id_next[idx] = k.id_next;
+  m.match_id[idx] = k.match_id;
+  m.match_fwd[idx] = k.match_id_forward;
+  m.match_kf[idx] = k.match_id_keyframe;
+  m.matches[idx] = k.matches;
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------
+static int lds_pitch(int cols) {
+  int pad = 4;
+  if (((cols + pad) / 4) % 2 == 0) pad = 8;
+  return cols + pad;
+}
+
+void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
+                        const int widths[2][3], int* rowcount_to_zero) {
+  const int R = p.rows, C = p.cols;
+  const int ldw = lds_pitch(C);
+  const size_t shm = (size_t)kStrip * ldw * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const dim3 g1(div_up(R, kStrip), 1), g2(div_up(R, kStrip), 2);
+  const dim3 c1(div_up(C, 64), 1), c2(div_up(C, 64), 2);
+  // pass 1: both filters share the integral image of the input (scale_space.cpp:175)
+  if (img_is_u8)
+    RH_LAUNCH(k_rowscan<0>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
+  else
+    RH_LAUNCH(k_rowscan<1>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
+  RH_LAUNCH(k_colscan, c1, dim3(64), 0, s, sb.a[0], sb.a[0], R, C);
+  // pass 2: average(width[0]) fused into the row scan, per filter
+  RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.a[0], (const void*)sb.a[0], sb.b[0], sb.b[1], R,
+                     C, widths[0][0], widths[1][0], ldw);
+  RH_LAUNCH(k_colscan, c2, dim3(64), 0, s, sb.b[0], sb.b[1], R, C);
+  // pass 3: filter f averages its own integral image
+  RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R,
+                     C, widths[0][1], widths[1][1], ldw);
+  RH_LAUNCH(k_colscan, c2, dim3(64), 0, s, sb.a[0], sb.a[1], R, C);
+  const dim3 gt(div_up(C, 64), div_up(R, 4));
+  RH_LAUNCH(k_dog_mag, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2],
+                     widths[1][2], sb.dog, sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
+}
+
+void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
+                     const DetState* det_in, DetState* det_out, uint64_t) {
+  const dim3 gt(div_up(p.cols, 64), div_up(p.rows, 4));
+  RH_LAUNCH(k_keyline_flag, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in,
+                     db.stash, db.bits, db.rowcount);
+  RH_LAUNCH(k_keyline_emit, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash,
+                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out);
+  RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m);
+}
+
+void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, DetState* det_cur) {
+  const long long threads = (long long)p.kmax * p.df_nr;
+  RH_LAUNCH(k_df_build, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, m, det_prev, det_cur);
+}
+
+void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out) {
+  RH_LAUNCH(k_df_decode, dim3(div_up(p.rows * p.cols, 256)), dim3(256), 0, s, p, m, id_out, dist_out);
+}
+
+void launch_map_pack(hipStream_t s, const KParams& p, const MapDev& m, rebvio_hip_keyline* aos_dev) {
+  RH_LAUNCH(k_map_pack, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, m, aos_dev);
+}
+
+void launch_map_unpack(hipStream_t s, const KParams& p, const MapDev& m, const rebvio_hip_keyline* aos_dev, int n) {
+  RH_LAUNCH(k_map_unpack, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, m, aos_dev, n);
+}
+
+}  // namespace rh

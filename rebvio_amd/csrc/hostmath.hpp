@@ -1,0 +1,322 @@
+// Host-side O(1) math of the frame-pair glue (3x3 / 6x6): stays on the CPU exactly like the reference keeps
+// it in TooN on the tracking thread (rebvio.cpp:163-233, core.cpp:244-248,264-284). fp32 with TooN's evaluation
+// order (dot products accumulate from 0 in index order); TooN itself is an absent submodule, so its published
+// algorithms are restated: determinant by pivoted elimination, LDL^T Cholesky inverse, Rodrigues SO3::exp.
+// SVD<6>::backsub (LAPACK gesvd underneath) is replaced by a cyclic-Jacobi eigen solve with TooN's 1e9
+// condition cut.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rh {
+namespace hm {
+
+struct M3 {
+  float a[3][3];
+};
+
+inline M3 identity3() {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = (i == j) ? 1.0f : 0.0f;
+  return r;
+}
+inline M3 load3(const float* p) {
+  M3 r;
+  std::memcpy(r.a, p, sizeof(r.a));
+  return r;
+}
+inline void store3(const M3& m, float* p) { std::memcpy(p, m.a, sizeof(m.a)); }
+inline M3 transpose(const M3& m) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = m.a[j][i];
+  return r;
+}
+inline M3 mul(const M3& x, const M3& y) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float s = 0;
+      for (int k = 0; k < 3; ++k) s += x.a[i][k] * y.a[k][j];
+      r.a[i][j] = s;
+    }
+  return r;
+}
+inline void mulv(const M3& m, const float v[3], float out[3]) {
+  float t[3];
+  for (int i = 0; i < 3; ++i) {
+    float s = 0;
+    for (int k = 0; k < 3; ++k) s += m.a[i][k] * v[k];
+    t[i] = s;
+  }
+  out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+}
+inline M3 add(const M3& x, const M3& y) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = x.a[i][j] + y.a[i][j];
+  return r;
+}
+inline M3 sub(const M3& x, const M3& y) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = x.a[i][j] - y.a[i][j];
+  return r;
+}
+inline M3 diag3(float v) {
+  M3 r = identity3();
+  for (int i = 0; i < 3; ++i) r.a[i][i] = v;
+  return r;
+}
+
+inline float det3(const M3& m) {
+  float A[3][3];
+  std::memcpy(A, m.a, sizeof(A));
+  float det = 1;
+  for (int i = 0; i < 3; ++i) {
+    int arg = i;
+    float mx = std::fabs(A[i][i]);
+    for (int ii = i + 1; ii < 3; ++ii)
+      if (std::fabs(A[ii][i]) > mx) {
+        mx = std::fabs(A[ii][i]);
+        arg = ii;
+      }
+    const float pivot = A[arg][i];
+    if (arg != i) {
+      det *= -1;
+      for (int ii = i; ii < 3; ++ii) std::swap(A[i][ii], A[arg][ii]);
+    }
+    det *= A[i][i];
+    if (det == 0) return 0;
+    for (int u = i + 1; u < 3; ++u) {
+      const float factor = A[u][i] / pivot;
+      for (int uu = i; uu < 3; ++uu) A[u][uu] = A[u][uu] - factor * A[i][uu];
+    }
+  }
+  return det;
+}
+
+// types::invert (types/definitions.hpp:40-53)
+inline M3 invert3(const M3& in) {
+  const float(*m)[3] = in.a;
+  M3 o;
+  o.a[0][0] = m[1][1] * m[2][2] - m[1][2] * m[2][1];
+  o.a[0][1] = m[0][2] * m[2][1] - m[0][1] * m[2][2];
+  o.a[0][2] = m[0][1] * m[1][2] - m[0][2] * m[1][1];
+  o.a[1][0] = m[1][2] * m[2][0] - m[1][0] * m[2][2];
+  o.a[1][1] = m[0][0] * m[2][2] - m[0][2] * m[2][0];
+  o.a[1][2] = m[0][2] * m[1][0] - m[0][0] * m[1][2];
+  o.a[2][0] = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+  o.a[2][1] = m[0][1] * m[2][0] - m[0][0] * m[2][1];
+  o.a[2][2] = m[0][0] * m[1][1] - m[0][1] * m[1][0];
+  const float d = det3(in);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o.a[i][j] = o.a[i][j] / d;
+  return o;
+}
+
+// TooN SO3<float>::exp
+inline M3 so3_exp(const float w[3]) {
+  const float one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+  float tsq = 0;
+  for (int i = 0; i < 3; ++i) tsq += w[i] * w[i];
+  float A, B;
+  if (tsq < 1e-8) {
+    A = 1.0 - one_6th * tsq;
+    B = 0.5;
+  } else if (tsq < 1e-6) {
+    B = 0.5 - 0.25 * one_6th * tsq;
+    A = 1.0 - tsq * one_6th * (1.0 - one_20th * tsq);
+  } else {
+    const float th = std::sqrt(tsq), inv = 1.0 / th;
+    A = std::sin(th) * inv;
+    B = (1 - std::cos(th)) * (inv * inv);
+  }
+  M3 R;
+  const float wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+  R.a[0][0] = 1.0 - B * (wy2 + wz2);
+  R.a[1][1] = 1.0 - B * (wx2 + wz2);
+  R.a[2][2] = 1.0 - B * (wx2 + wy2);
+  float a = A * w[2], b = B * (w[0] * w[1]);
+  R.a[0][1] = b - a; R.a[1][0] = b + a;
+  a = A * w[1]; b = B * (w[0] * w[2]);
+  R.a[0][2] = b + a; R.a[2][0] = b - a;
+  a = A * w[0]; b = B * (w[1] * w[2]);
+  R.a[1][2] = b - a; R.a[2][1] = b + a;
+  return R;
+}
+
+// TooN Cholesky<6,float>::get_inverse (LDL^T)
+inline void cholesky6_inverse(const float* A, float* inv) {
+  constexpr int N = 6;
+  float L[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) L[i][j] = A[i * N + j];
+  for (int col = 0; col < N; ++col) {
+    float inv_diag = 1;
+    for (int row = col; row < N; ++row) {
+      float val = L[row][col];
+      for (int c2 = 0; c2 < col; ++c2) val -= L[c2][col] * L[row][c2];
+      if (row == col) {
+        L[row][col] = val;
+        if (val == 0) break;
+        inv_diag = 1 / val;
+      } else {
+        L[col][row] = val;
+        L[row][col] = val * inv_diag;
+      }
+    }
+  }
+  for (int c = 0; c < N; ++c) {
+    float y[N], res[N];
+    for (int i = 0; i < N; ++i) {
+      float val = (i == c) ? 1.0f : 0.0f;
+      for (int j = 0; j < i; ++j) val -= L[i][j] * y[j];
+      y[i] = val;
+    }
+    for (int i = 0; i < N; ++i) y[i] /= L[i][i];
+    for (int i = N - 1; i >= 0; --i) {
+      float val = y[i];
+      for (int j = i + 1; j < N; ++j) val -= L[j][i] * res[j];
+      res[i] = val;
+    }
+    for (int i = 0; i < N; ++i) inv[i * N + c] = res[i];
+  }
+}
+
+// x = pinv(A) b for symmetric 6x6 A (stands in for SVD<6,6,float>(A).backsub(b), core.cpp:247-248)
+inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
+  constexpr int N = 6;
+  double A[N][N], V[N][N];
+  bool bad = false;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      if (std::isnan(A_[i * N + j])) bad = true;
+      A[i][j] = 0.5 * ((double)A_[i * N + j] + (double)A_[j * N + i]);
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 60 && !bad; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = ((theta >= 0) ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < N; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = cs * akp - sn * akq;
+          A[k][q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = cs * apk - sn * aqk;
+          A[q][k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = cs * vkp - sn * vkq;
+          V[k][q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  double dmax = 0, x[N] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(A[i][i]));
+  for (int k = 0; k < N && !bad; ++k) {
+    const double lam = A[k][k];
+    if (!(std::fabs(lam) * 1e9 > dmax)) continue;
+    double proj = 0;
+    for (int i = 0; i < N; ++i) proj += V[i][k] * (double)b_[i];
+    proj /= lam;
+    for (int i = 0; i < N; ++i) x[i] += V[i][k] * proj;
+  }
+  for (int i = 0; i < N; ++i) x_[i] = bad ? std::numeric_limits<float>::quiet_NaN() : (float)x[i];
+}
+
+// Core::gyroBiasCorrection (core.cpp:264-284); dgbias is zero on entry, as in the reference.
+inline void gyro_bias_correction(float X[6], float Wx[36], M3& Wb, const M3& Rg, const M3& Rb, float dgbias_out[3]) {
+  float dgbias[3] = {0, 0, 0};
+  const M3 Wg = invert3(Rg);
+  Wb = invert3(add(invert3(Wb), Rb));
+  float Wxb[36];
+  std::memcpy(Wxb, Wx, sizeof(Wxb));
+  const M3 iWgWb = invert3(add(Wg, Wb));
+  const M3 upd = mul(Wg, sub(identity3(), mul(iWgWb, Wg)));
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Wxb[(3 + i) * 6 + 3 + j] += upd.a[i][j];
+  float X1[6];
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+    for (int k = 0; k < 6; ++k) s += Wx[i * 6 + k] * X[k];
+    X1[i] = s;
+  }
+  {
+    float t[3];
+    mulv(mul(mul(Wg, iWgWb), Wb), dgbias, t);
+    for (int i = 0; i < 3; ++i) X1[3 + i] += t[i];
+  }
+  float inv[36];
+  cholesky6_inverse(Wxb, inv);
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+    for (int k = 0; k < 6; ++k) s += inv[i * 6 + k] * X1[k];
+    X[i] = s;
+  }
+  {
+    float a[3], b[3], sum[3];
+    const float xw[3] = {X[3], X[4], X[5]};
+    mulv(Wg, xw, a);
+    mulv(Wb, dgbias, b);
+    for (int i = 0; i < 3; ++i) sum[i] = a[i] + b[i];
+    mulv(iWgWb, sum, dgbias);
+  }
+  Wb = add(Wg, Wb);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Wx[(3 + i) * 6 + 3 + j] += Wg.a[i][j];
+  for (int i = 0; i < 3; ++i) dgbias_out[i] = dgbias[i];
+}
+
+// Kovesi box widths of FastGaussian::FastGaussian (scale_space.cpp:19-35)
+inline void kovesi_widths(float sigma, int n, int* widths, float* sigma_true) {
+  const float w_ideal = std::sqrt(12.0 * sigma * sigma / float(n + 1));
+  int w_l = int(w_ideal);
+  if (int(w_l / 2) * 2 == w_l) --w_l;
+  const int m = std::round((3 * n + 4 * n * w_l + n * w_l * w_l - 12 * sigma * sigma) / (4 + 4 * w_l));
+  int i = 0;
+  for (; i < m; i++) widths[i] = w_l;
+  for (; i < n; i++) widths[i] = w_l + 2;
+  *sigma_true = std::sqrt((m * w_l * w_l + (n - m) * (w_l + 2.0) * (w_l + 2.0) - n) / 12.0);
+}
+
+// Pinv = invert(Phi^T Phi) Phi^T for the 5x5 plane fit (edge_detector.cpp:55-68)
+inline void plane_fit_pinv(float out[75]) {
+  float Phi[25][3];
+  for (int row = -2, k = 0; row <= 2; ++row)
+    for (int col = -2; col <= 2; ++col, ++k) {
+      Phi[k][0] = col; Phi[k][1] = row; Phi[k][2] = 1;
+    }
+  M3 PtP;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float s = 0;
+      for (int k = 0; k < 25; ++k) s += Phi[k][i] * Phi[k][j];
+      PtP.a[i][j] = s;
+    }
+  const M3 inv = invert3(PtP);
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 25; ++k) {
+      float s = 0;
+      for (int j = 0; j < 3; ++j) s += inv.a[i][j] * Phi[k][j];
+      out[i * 25 + k] = s;
+    }
+}
+
+}  // namespace hm
+}  // namespace rh

@@ -1,0 +1,830 @@
+// Edge tracking on gfx950: one thread per keyline, wavefront (64-lane) butterfly reductions, fixed-order
+// block/grid reductions (deterministic), order-independent restatements of the reference's sequential
+// "last writer wins" rules.
+//
+// Reference semantics (baumlin/rebvio): edge_map.cpp:39-259; core.cpp:39-261,417-456. Compiled with
+// -ffp-contract=off; float/double promotion follows the reference expression by expression (see the
+// oracle's header for the rules).
+//
+// Bound: HBM/L2 gather bandwidth (keyline SoA streams + distance-field / mask / matched-keyline gathers);
+// no dense contraction exists on this path (largest product is 6x6), so MFMA does not apply.
+#include "common.hpp"
+
+namespace rh {
+
+constexpr float kRhoMax = 20.0f;   // types/keyline.hpp:17
+constexpr float kRhoMin = 1e-3f;   // types/keyline.hpp:18
+constexpr float kRhoInit = 1.0f;   // types/keyline.hpp:19
+
+struct Mat3 {
+  float a[9];
+};
+struct Vec3 {
+  float a[3];
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Order-preserving float -> uint map (for atomicMax on rho).
+__device__ __forceinline__ unsigned order_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// ---- EdgeMap::rotateKeylines (edge_map.cpp:58-71) [+ estimateQuantile histogram, :39-46] -------------------
+// makeVector(float, float, 1.0) mixes float and double arguments: TooN's double overload is selected, so the
+// matrix-vector product is accumulated in double and rounded to float once per component.
+__global__ __launch_bounds__(256) void k_rotate(KParams p, MapDev m, Mat3 R, int* __restrict__ hist, int hist_bins,
+                                                int zero_dm) {
+  __shared__ int sh[128];
+  const int n = m.st->n;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (hist) {
+    if (threadIdx.x < 128) sh[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  if (zero_dm && blockIdx.x == 0 && threadIdx.x == 0) {
+    m.st->dm_matches = 0;
+    m.st->dm_kf = 0;
+    m.st->reg_count = 0;
+  }
+  if (idx < n) {
+    float2 pi = m.pos_img[idx];
+    float2 rs = m.rs[idx];
+    const float2 g = m.grad[idx];
+    const double v0 = (double)(pi.x / p.fm), v1 = (double)(pi.y / p.fm);
+    float q[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double s = 0.0;
+      s += (double)R.a[i * 3 + 0] * v0;
+      s += (double)R.a[i * 3 + 1] * v1;
+      s += (double)R.a[i * 3 + 2] * 1.0;
+      q[i] = (float)s;
+    }
+    if (fabsf(q[2]) > 0.0f) {
+      pi.x = q[0] / q[2] * p.fm;
+      pi.y = q[1] / q[2] * p.fm;
+      rs.x /= q[2];
+      rs.y /= q[2];
+      m.pos_img[idx] = pi;
+      m.rs[idx] = rs;
+    }
+    float gq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double s = 0.0;
+      s += (double)R.a[i * 3 + 0] * (double)g.x;
+      s += (double)R.a[i * 3 + 1] * (double)g.y;
+      s += (double)R.a[i * 3 + 2] * 0.0;
+      gq[i] = (float)s;
+    }
+    m.grad[idx] = make_float2(gq[0], gq[1]);
+    if (hist) {
+      m.residual[idx] = 0.f;  // minimizeVel starts from residuals[] = {0} (core.cpp:158)
+      int i = cvtt_f32(hist_bins * (rs.y - kRhoMin) / (kRhoMax - kRhoMin));
+      i = (i > hist_bins - 1) ? (hist_bins - 1) : i;
+      i = (i < 0) ? 0 : i;
+      atomicAdd(&sh[i], 1);
+    }
+  }
+  if (hist) {
+    __syncthreads();
+    if ((int)threadIdx.x < hist_bins && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+  }
+}
+
+// Histogram only (stand-alone EdgeMap::estimateQuantile).
+__global__ __launch_bounds__(256) void k_sigma_hist(MapDev m, int* __restrict__ hist, int hist_bins) {
+  __shared__ int sh[128];
+  const int n = m.st->n;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < 128) sh[threadIdx.x] = 0;
+  __syncthreads();
+  if (idx < n) {
+    int i = cvtt_f32(hist_bins * (m.rs[idx].y - kRhoMin) / (kRhoMax - kRhoMin));
+    i = (i > hist_bins - 1) ? (hist_bins - 1) : i;
+    i = (i < 0) ? 0 : i;
+    atomicAdd(&sh[i], 1);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < hist_bins && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+// Tail of estimateQuantile (edge_map.cpp:47-55): first bin whose running count (checked before adding the
+// bin) exceeds percentile * size.
+__device__ __forceinline__ float quantile_from_hist(const int* __restrict__ hist, int bins, float pct, int n) {
+  float sigma_rho = 1e3f;
+  int a = 0;
+  for (int i = 0; i < bins; ++i) {
+    if ((float)a > pct * (float)n) {
+      sigma_rho = float(i) * (kRhoMax - kRhoMin) / float(bins) + kRhoMin;
+      break;
+    }
+    a += hist[i];
+  }
+  return sigma_rho;
+}
+
+__global__ void k_quantile(MapDev m, const int* __restrict__ hist, int bins, float pct, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = quantile_from_hist(hist, bins, pct, m.st->n);
+}
+
+// ---- 3x3 helpers with the reference's operation order -------------------------------------------------------
+// TooN::determinant for N = 3: Gaussian elimination with partial pivoting.
+__device__ float det3_elim(const float* A_) {
+  float A[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) A[i][j] = A_[i * 3 + j];
+  float det = 1;
+  for (int i = 0; i < 3; ++i) {
+    int argmax = i;
+    float mx = fabsf(A[i][i]);
+    for (int ii = i + 1; ii < 3; ++ii)
+      if (fabsf(A[ii][i]) > mx) {
+        mx = fabsf(A[ii][i]);
+        argmax = ii;
+      }
+    const float pivot = A[argmax][i];
+    if (argmax != i) {
+      det *= -1;
+      for (int ii = i; ii < 3; ++ii) {
+        const float t = A[i][ii];
+        A[i][ii] = A[argmax][ii];
+        A[argmax][ii] = t;
+      }
+    }
+    det *= A[i][i];
+    if (det == 0) return 0;
+    for (int u = i + 1; u < 3; ++u) {
+      const float factor = A[u][i] / pivot;
+      for (int uu = i; uu < 3; ++uu) A[u][uu] = A[u][uu] - factor * A[i][uu];
+    }
+  }
+  return det;
+}
+
+// types::invert (types/definitions.hpp:40-53)
+__device__ void invert3(const float* m, float* o) {
+  o[0] = m[4] * m[8] - m[5] * m[7];
+  o[1] = m[2] * m[7] - m[1] * m[8];
+  o[2] = m[1] * m[5] - m[2] * m[4];
+  o[3] = m[5] * m[6] - m[3] * m[8];
+  o[4] = m[0] * m[8] - m[2] * m[6];
+  o[5] = m[2] * m[3] - m[0] * m[5];
+  o[6] = m[3] * m[7] - m[4] * m[6];
+  o[7] = m[1] * m[6] - m[0] * m[7];
+  o[8] = m[0] * m[4] - m[1] * m[3];
+  const float d = det3_elim(m);
+  for (int i = 0; i < 9; ++i) o[i] = o[i] / d;
+}
+
+__device__ __forceinline__ void sym6_to_9(const float* J, float* M) {
+  M[0] = J[0]; M[1] = J[3]; M[2] = J[4];
+  M[3] = J[3]; M[4] = J[1]; M[5] = J[5];
+  M[6] = J[4]; M[7] = J[5]; M[8] = J[2];
+}
+
+// One Levenberg-Marquardt bookkeeping step of Core::minimizeVel (core.cpp:161-185), run redundantly and
+// identically by thread 0 of every workgroup; `red` = fixed-order sum of the previous call's block records.
+// call: index of the tryVel evaluation about to run (0..iterations); final: no further evaluation follows.
+__device__ void lm_step(LmState& s, const float* red, int call, bool final_only) {
+  if (call == 1) {
+    s.F = red[0];
+    for (int i = 0; i < 6; ++i) s.JtJ[i] = red[1 + i];
+    for (int i = 0; i < 3; ++i) s.JtF[i] = red[7 + i];
+    s.v = 2.0f;
+    const float tau = 1e-3f;
+    float mx = s.JtJ[0];
+    for (int i = 1; i < 6; ++i)
+      if (s.JtJ[i] > mx) mx = s.JtJ[i];
+    s.u = tau * mx;
+    s.accept_mask = 0;
+  } else if (call >= 2) {
+    const float Fnew = red[0];
+    double den = 0.0;
+    for (int i = 0; i < 3; ++i) den += (0.5 * (double)s.h[i]) * (double)(s.u * s.h[i] - s.JtF[i]);
+    const float gain = (float)((double)(s.F - Fnew) / den);
+    if (gain > 0.0f) {
+      s.F = Fnew;
+      for (int i = 0; i < 3; ++i) s.vel[i] = s.Vnew[i];
+      for (int i = 0; i < 6; ++i) s.JtJ[i] = red[1 + i];
+      for (int i = 0; i < 3; ++i) s.JtF[i] = red[7 + i];
+      const double g = (double)gain;
+      const double c = 1.0 - ((2.0 * g - 1.0) * (2.0 * g - 1.0) * (2.0 * g - 1.0));
+      s.u = (float)((double)s.u * (0.33 > c ? 0.33 : c));
+      s.v = 2.0f;
+      s.accept_mask |= 1 << (call - 2);
+    } else {
+      s.u *= s.v;
+      s.v = (float)((double)s.v * 2.0);
+    }
+  }
+  if (call >= 1 && !final_only) {
+    float M[9], inv[9];
+    sym6_to_9(s.JtJ, M);
+    M[0] = M[0] + 1.0f * s.u;
+    M[4] = M[4] + 1.0f * s.u;
+    M[8] = M[8] + 1.0f * s.u;
+    M[1] = M[1] + 0.0f * s.u; M[2] = M[2] + 0.0f * s.u; M[3] = M[3] + 0.0f * s.u;
+    M[5] = M[5] + 0.0f * s.u; M[6] = M[6] + 0.0f * s.u; M[7] = M[7] + 0.0f * s.u;
+    invert3(M, inv);
+    const float neg[3] = {-s.JtF[0], -s.JtF[1], -s.JtF[2]};
+    for (int i = 0; i < 3; ++i) {
+      float acc = 0;
+      for (int k = 0; k < 3; ++k) acc += inv[i * 3 + k] * neg[k];
+      s.h[i] = acc;
+    }
+    for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i] + s.h[i];
+  }
+}
+
+// Shared prologue: fixed-order reduction of the previous tryVel call's block records + carry-in of the
+// "last written fi" (oracle header, H3) for this workgroup.
+__device__ void reduce_prev_records(const float* __restrict__ part_prev, int nblocks, float* red /*shared[16]*/,
+                                    float* carry_in /*shared*/) {
+  if (threadIdx.x < 10) {
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += part_prev[b * kPartStride + threadIdx.x];
+    red[threadIdx.x] = acc;
+  } else if (threadIdx.x == 10) {
+    float cv = 0.f;
+    for (int b = (int)blockIdx.x - 1; b >= 0; --b)
+      if (part_prev[b * kPartStride + 10] != 0.f) {
+        cv = part_prev[b * kPartStride + 11];
+        break;
+      }
+    *carry_in = fabsf(cv);
+  }
+}
+
+// ---- Core::tryVel + calculatefJ + testfk (core.cpp:39-148) ---------------------------------------------------
+// mode_lm = 0: evaluate at st_in->Vnew with st_in->sigma_rho_min (stand-alone tryVel).
+// mode_lm = 1: call `call` of minimizeVel; prologue derives the LM state from the previous call's records.
+// last: the evaluation whose side effects persist (core.cpp:166-185 never re-evaluates an accepted point):
+//       matched keylines publish forwardMatch keys (edge_map.cpp:78-96) so that no extra pass is needed.
+__global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm, int mode_lm, int call, int last,
+                                                 const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
+                                                 const float* __restrict__ part_prev, float* __restrict__ part_out,
+                                                 const int* __restrict__ hist, unsigned frame_count) {
+  __shared__ LmState s;
+  __shared__ float red[16];
+  __shared__ float carry_in;
+  __shared__ float wsum[4][10];
+  __shared__ float wlast[4];
+  __shared__ int whas[4];
+
+  const int n = om.st->n;
+  const int nblocks = (n + 255) / 256;
+  if (threadIdx.x == 0) carry_in = 0.f;
+  if (mode_lm && call >= 1) reduce_prev_records(part_prev, nblocks, red, &carry_in);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = *st_in;
+    if (mode_lm) {
+      if (call == 0) {
+        s.sigma_rho_min = quantile_from_hist(hist, p.quantile_num_bins, p.quantile_cutoff, n);
+        for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
+      } else {
+        lm_step(s, red, call, false);
+      }
+    }
+    if (blockIdx.x == 0) *st_out = s;
+  }
+  __syncthreads();
+  if ((int)blockIdx.x >= nblocks && blockIdx.x != 0) return;
+
+  const float vx = s.Vnew[0], vy = s.Vnew[1], vz = s.Vnew[2];
+  const float srm = s.sigma_rho_min;
+  const float cin = carry_in;
+  const unsigned min_matches = min(p.min_match_threshold, frame_count);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+  float f = 0.f, jx = 0.f, jy = 0.f, jz = 0.f, fi = 0.f;
+  bool contrib = false, matched = false, need_carry = false;
+  if (idx < n) {
+    int mfwd = -1;
+    const float gn = om.gnorm[idx];
+    const float thr = om.st->threshold;
+    const float2 rs = om.rs[idx];
+    const bool skip = (thr > 0.0f && gn < thr) || (rs.y > srm) || (om.matches[idx] < min_matches);
+    if (!skip) {
+      float res = om.residual[idx];
+      if (res == kResidualCarry) res = cin;
+      float res_out = res;
+      float weight = 1.0f;
+      if (res > p.reweight_distance) weight = p.reweight_distance / res;
+      const float z_p = (float)(1.0 / (double)rs.x + (double)vz);
+      const float2 pi = om.pos_img[idx];
+      bool penalty1 = false;
+      float rho_p = 0.f, p_x = 0.f, p_y = 0.f, p_xc = 0.f, p_yc = 0.f;
+      int x = 0, y = 0;
+      if (z_p <= 0.0f) {
+        penalty1 = true;
+      } else {
+        rho_p = (float)(1.0 / (double)z_p);
+        p_x = rho_p * (vx * p.fm - vz * pi.x) + pi.x;
+        p_y = rho_p * (vy * p.fm - vz * pi.y) + pi.y;
+        p_xc = p_x + p.cx;
+        p_yc = p_y + p.cy;
+        x = cvtt_f64((double)p_xc + 0.5);
+        y = cvtt_f64((double)p_yc + 0.5);
+        if (x < 1 || y < 1 || (unsigned)x >= (unsigned)p.cols - 1u || (unsigned)y >= (unsigned)p.rows - 1u) penalty1 = true;
+      }
+      contrib = true;
+      if (penalty1) {
+        f = (float)(((1.0 / (double)rs.y) * (double)p.search_range) * (double)weight);
+      } else {
+        float df_dx = 0.f, df_dy = 0.f;
+        const unsigned key = nm.df[(size_t)y * p.cols + x];
+        if (key != kDfEmpty) {
+          const int id = (int)((kDfSeqMask - (key & kDfSeqMask)) / (unsigned)p.df_nr);
+          const float2 g2 = om.grad[idx];
+          const float2 g1 = nm.grad[id];
+          const float norm_squared = gn * gn;
+          const float dot_product = g1.x * g2.x + g1.y * g2.y;
+          if (!(fabsf(dot_product - norm_squared) > p.match_treshold * norm_squared)) {
+            const float2 pn = nm.pos[id];
+            const float gnn = nm.gnorm[id];
+            const float dx = p_xc - pn.x;
+            const float dy = p_yc - pn.y;
+            const float gnx = g1.x / gnn;
+            const float gny = g1.y / gnn;
+            fi = (dx * gnx + dy * gny);
+            df_dx = gnx / rs.y;
+            df_dy = gny / rs.y;
+            mfwd = id;
+            f = fi / rs.y;
+            matched = true;
+          }
+        }
+        if (!matched) {
+          f = p.search_range / rs.y;
+          need_carry = true;
+        }
+        f *= weight;
+        jx = rho_p * p.fm * df_dx * weight;
+        jy = rho_p * p.fm * df_dy * weight;
+        jz = -rho_p * (p_x * df_dx + p_y * df_dy) * weight;
+        if (matched) res_out = fabsf(fi);
+      }
+      if (!need_carry) om.residual[idx] = res_out;
+      if (matched && last) {
+        const unsigned long long key = ((unsigned long long)order_key(rs.x) << 32) | (unsigned)idx;
+        atomicMax(&nm.fwd_key[mfwd], key);
+      }
+    }
+    om.match_fwd[idx] = mfwd;
+  }
+
+  // carry-forward of the last written fi (index order) for calculatefJ's early-return paths
+  const unsigned long long mm = __ballot(matched);
+  const unsigned long long below = mm & ((1ull << lane) - 1ull);
+  const int src = below ? (63 - __clzll((long long)below)) : 0;
+  const float fi_prev = __shfl(fi, src);
+  const int wl = mm ? (63 - __clzll((long long)mm)) : 0;
+  const float fi_wlast = __shfl(fi, wl);
+  if (lane == 0) {
+    whas[wid] = mm ? 1 : 0;
+    wlast[wid] = fi_wlast;
+  }
+
+  const float sc = contrib ? f * f : 0.f;
+  float v[10] = {sc, jx * jx, jy * jy, jz * jz, jx * jy, jx * jz, jy * jz, jx * f, jy * f, jz * f};
+#pragma unroll
+  for (int k = 0; k < 10; ++k) v[k] = wave_sum_f(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) wsum[wid][k] = v[k];
+  }
+  __syncthreads();
+  if (need_carry) {
+    float r;
+    if (below) {
+      r = fabsf(fi_prev);
+    } else {
+      r = kResidualCarry;
+      for (int w = wid - 1; w >= 0; --w)
+        if (whas[w]) {
+          r = fabsf(wlast[w]);
+          break;
+        }
+    }
+    om.residual[idx] = r;
+  }
+  if (threadIdx.x < 10) {
+    float acc = 0.f;
+    for (int w = 0; w < 4; ++w) acc += wsum[w][threadIdx.x];
+    part_out[blockIdx.x * kPartStride + threadIdx.x] = acc;
+  } else if (threadIdx.x == 10) {
+    float hv = 0.f, lv = 0.f;
+    for (int w = 3; w >= 0; --w)
+      if (whas[w]) {
+        hv = 1.f;
+        lv = wlast[w];
+        break;
+      }
+    part_out[blockIdx.x * kPartStride + 10] = hv;
+    part_out[blockIdx.x * kPartStride + 11] = lv;
+  }
+}
+
+// Final accept/reject of minimizeVel for the stand-alone entry (the fused path does this in k_ext_rot_vel).
+__global__ __launch_bounds__(64) void k_lm_final(MapDev om, int calls, const LmState* __restrict__ st_in,
+                                                 LmState* __restrict__ st_out, const float* __restrict__ part_prev) {
+  __shared__ float red[16];
+  __shared__ float carry_in;
+  reduce_prev_records(part_prev, (om.st->n + 255) / 256, red, &carry_in);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    LmState s = *st_in;
+    lm_step(s, red, calls, true);
+    *st_out = s;
+  }
+}
+
+// Stand-alone forwardMatch keys from match_id_forward (for the stepwise API; the fused path publishes the
+// keys from the last tryVel evaluation).
+__global__ __launch_bounds__(256) void k_forward_keys(MapDev om, MapDev nm) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= om.st->n) return;
+  const int j = om.match_fwd[idx];
+  if (j < 0) return;
+  const unsigned long long key = ((unsigned long long)order_key(om.rs[idx].x) << 32) | (unsigned)idx;
+  atomicMax(&nm.fwd_key[j], key);
+}
+
+// ---- EdgeMap::forwardMatch gather (edge_map.cpp:78-96) + Core::extRotVel sums (core.cpp:198-245) -------------
+// Sequential rule "overwrite unless the target already holds a larger rho" == the writer with the largest
+// rho wins, ties -> largest index: exactly the atomicMax key. One thread per keyline of the NEW map.
+// Per-thread outer product of the 6-vector row (Phi is never materialised): 21 + 6 sums + match count.
+__global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDev nm, int do_forward, int do_lm_final,
+                                                     int calls, const LmState* __restrict__ st_in,
+                                                     LmState* __restrict__ st_out, const float* __restrict__ part_prev,
+                                                     float* __restrict__ xrv_part, Vec3 vel_manual) {
+  __shared__ LmState s;
+  __shared__ float red[16];
+  __shared__ float carry_in;
+  __shared__ float wsum[4][28];
+  const int n = nm.st->n;
+  if (do_lm_final) {
+    const int nb_old = (om.st->n + 255) / 256;
+    reduce_prev_records(part_prev, nb_old, red, &carry_in);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s = *st_in;
+      lm_step(s, red, calls, true);
+      if (blockIdx.x == 0) *st_out = s;
+    }
+    __syncthreads();
+  }
+  const float vx = do_lm_final ? s.vel[0] : vel_manual.a[0];
+  const float vy = do_lm_final ? s.vel[1] : vel_manual.a[1];
+  const float vz = do_lm_final ? s.vel[2] : vel_manual.a[2];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+  float row[6] = {0, 0, 0, 0, 0, 0};
+  float Y = 0.f;
+  int cnt = 0;
+  if (idx < n) {
+    int mid = nm.match_id[idx];
+    float2 rs = nm.rs[idx];
+    float2 mpi = nm.mpos_img[idx];
+    if (do_forward) {
+      const unsigned long long key = nm.fwd_key[idx];
+      if (key != 0ull) {
+        const int o = (int)(unsigned)(key & 0xFFFFFFFFull);
+        rs = om.rs[o];
+        mpi = om.pos_img[o];
+        mid = o;
+        nm.rs[idx] = rs;
+        nm.matches[idx] = om.matches[o] + 1u;
+        nm.match_id[idx] = o;
+        nm.mpos_img[idx] = mpi;
+        nm.mgrad[idx] = om.grad[o];
+        nm.mgnorm[idx] = om.gnorm[o];
+        nm.match_kf[idx] = om.match_kf[o];
+      }
+    }
+    if (mid >= 0) {
+      const float2 g = nm.grad[idx];
+      const float gn = nm.gnorm[idx];
+      const float2 q = nm.pos_img[idx];
+      const float u_x = g.x / gn;
+      const float u_y = g.y / gn;
+      const float rho_t = (float)(1.0 / (1.0 / (double)rs.x + (double)vz));
+      const float qt_x = mpi.x + rho_t * (vx * p.fm - vz * mpi.x);
+      const float qt_y = mpi.y + rho_t * (vy * p.fm - vz * mpi.y);
+      const float q_x = q.x, q_y = q.y;
+      row[0] = u_x * rho_t * p.fm;
+      row[1] = u_y * rho_t * p.fm;
+      row[2] = u_x * (-rho_t * q_x) + u_y * (-rho_t * q_y);
+      row[3] = -u_x * q_x * q_y / p.fm - u_y * (p.fm + q_y * q_y / p.fm);
+      row[4] = u_y * q_x * q_y / p.fm + u_x * (p.fm + q_x * q_x / p.fm);
+      row[5] = -u_x * q_y + u_y * q_x;
+      Y = u_x * (q_x - qt_x) + u_y * (q_y - qt_y);
+      const float dqvel = u_x * (vx * p.fm - vz * mpi.x) + u_y * (vy * p.fm - vz * mpi.y);
+      const float s_y = sqrtf(rs.y * rs.y * dqvel * dqvel + p.pixel_uncertainty * p.pixel_uncertainty);
+      float weight = 1.0f;
+      if (fabsf(Y) > p.reweight_distance) weight = fabsf(Y) / p.reweight_distance;
+      const float dv = s_y * weight;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) row[i] /= dv;
+      Y /= dv;
+      cnt = 1;
+    }
+  }
+  float v[28];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) v[k++] = row[i] * row[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[21 + i] = row[i] * Y;
+    v[27] = (float)cnt;
+  }
+#pragma unroll
+  for (int k = 0; k < 28; ++k) v[k] = wave_sum_f(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    float acc = 0.f;
+    for (int w = 0; w < 4; ++w) acc += wsum[w][threadIdx.x];
+    xrv_part[blockIdx.x * kXrvStride + threadIdx.x] = acc;
+  }
+}
+
+// ---- EdgeMap::directedMatch / searchMatch (edge_map.cpp:101-218) ----------------------------------------------
+// One thread per keyline of the NEW map; probes the OLD map's dense mask along the epipolar line, first hit in
+// the reference's alternating order wins. vel / Rvel are already rotated by Rback on the host (:193-194).
+__global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel, Mat3 Rvel, Mat3 Rback,
+                                                        float max_radius) {
+  const int n = nm.st->n;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  int found = -1;
+  int kf = 0;
+  if (idx < n) {
+    const float2 pi = nm.pos_img[idx];
+    const float2 rsq = nm.rs[idx];
+    const float2 gq = nm.grad[idx];
+    const float gnq = nm.gnorm[idx];
+    float p_m3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float s = 0.f;
+      s += Rback.a[i * 3 + 0] * pi.x;
+      s += Rback.a[i * 3 + 1] * pi.y;
+      s += Rback.a[i * 3 + 2] * p.fm;
+      p_m3[i] = s;
+    }
+    const float pmx = p_m3[0] * p.fm / p_m3[2];
+    const float pmy = p_m3[1] * p.fm / p_m3[2];
+    const float k_rho = rsq.x * p.fm / p_m3[2];
+    const float pi0x = pmx + p.cx;
+    const float pi0y = pmy + p.cy;
+    float t_x = -(vel.a[0] * p.fm - vel.a[2] * pmx);
+    float t_y = -(vel.a[1] * p.fm - vel.a[2] * pmy);
+    float norm_t = sqrtf(t_x * t_x + t_y * t_y);
+    const float DrDv[3] = {p.fm, p.fm, -(pmx + pmy)};
+    float rowv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float s = 0.f;
+      s += DrDv[0] * Rvel.a[0 * 3 + j];
+      s += DrDv[1] * Rvel.a[1 * 3 + j];
+      s += DrDv[2] * Rvel.a[2 * 3 + j];
+      rowv[j] = s;
+    }
+    float sigma2_t = 0.f;
+    sigma2_t += rowv[0] * DrDv[0];
+    sigma2_t += rowv[1] * DrDv[1];
+    sigma2_t += rowv[2] * DrDv[2];
+
+    float dq_min = 0.f, dq_max = 0.f, dq_rho = 0.f;
+    int t_steps = 0;
+    if ((double)norm_t > 1e-6) {
+      t_x /= norm_t;
+      t_y /= norm_t;
+      dq_rho = norm_t * k_rho;
+      dq_min = fmaxf(0.0f, norm_t * (k_rho - rsq.y)) - p.pixel_uncertainty_match;
+      dq_max = fminf(max_radius, norm_t * (k_rho + rsq.y)) + p.pixel_uncertainty_match;
+      if (dq_rho > dq_max) {
+        dq_rho = (float)(0.5 * (double)(dq_max + dq_min));
+        t_steps = cvtt_f64((double)dq_rho + 0.5);
+      } else {
+        t_steps = cvtt_f32(fmaxf(dq_max - dq_rho, dq_rho - dq_min));
+      }
+    } else {
+      t_x = gq.x;
+      t_y = gq.y;
+      norm_t = gnq;
+      t_x /= norm_t;
+      t_y /= norm_t;
+      norm_t = 1.0f;
+      dq_min = -max_radius - p.pixel_uncertainty_match;
+      dq_max = max_radius + p.pixel_uncertainty_match;
+      dq_rho = 0.0f;
+      t_steps = cvtt_f32(dq_max);
+    }
+    // std::max / std::min on NaN operands keep the first argument when the comparison is false; fmaxf/fminf
+    // return the non-NaN one. The operands here are finite whenever rho/sigma are, which the depth filter
+    // guarantees (core.cpp:451-455).
+    float tn = dq_rho;
+    float tp = dq_rho + 1.0f;
+    for (int t_i = 0; t_i < t_steps && found < 0; ++t_i, tp += 1.0f, tn -= 1.0f) {
+      for (int i_idx = 0; i_idx < 2; ++i_idx) {
+        float t;
+        if (i_idx) {
+          t = tp;
+          if (t > dq_max) continue;
+        } else {
+          t = tn;
+          if (t < dq_min) continue;
+        }
+        const int row = cvtt_f32(roundf(t_y * t + pi0y));
+        const int col = cvtt_f32(roundf(t_x * t + pi0x));
+        if ((unsigned)row >= (unsigned)p.rows || (unsigned)col >= (unsigned)p.cols) continue;
+        const int cand = om.mask[(size_t)row * p.cols + col];
+        if (cand < 0) continue;
+        const float2 g = om.grad[cand];
+        const float gnc = om.gnorm[cand];
+        const float cang = (g.x * gq.x + g.y * gq.y) / (gnc * gnq);
+        if (cang < p.cang_min_edge || fabs((double)(gnc / gnq) - 1.0) > (double)p.match_threshold_norm) continue;
+        const float2 rsc = om.rs[cand];
+        const float v_rho_dr = (p.pixel_uncertainty_match * p.pixel_uncertainty_match + rsc.y * rsc.y * norm_t * norm_t +
+                                sigma2_t * rsc.x * rsc.x);
+        if ((t - norm_t * rsc.x) * (t - norm_t * rsc.x) > v_rho_dr) continue;
+        found = cand;
+        break;
+      }
+    }
+    if (found >= 0) {
+      nm.rs[idx] = om.rs[found];
+      nm.match_id[idx] = found;
+      nm.matches[idx] = om.matches[found] + 1u;
+      nm.mpos_img[idx] = om.pos_img[found];
+      nm.mgrad[idx] = om.grad[found];
+      nm.mgnorm[idx] = om.gnorm[found];
+      const int k = om.match_kf[found];
+      nm.match_kf[idx] = k;
+      kf = (k >= 0) ? 1 : 0;
+    }
+  }
+  const int c1 = wave_sum_i(found >= 0 ? 1 : 0);
+  const int c2 = wave_sum_i(kf);
+  if ((threadIdx.x & 63) == 0) {
+    if (c1) atomicAdd(&nm.st->dm_matches, c1);
+    if (c2) atomicAdd(&nm.st->dm_kf, c2);
+  }
+}
+
+// ---- EdgeMap::regularize1Iter (edge_map.cpp:220-259): Jacobi step, results staged in rs_tmp ----------------------
+__global__ __launch_bounds__(256) void k_regularize(KParams p, MapDev m, int gate_min_matches) {
+  const int n = m.st->n;
+  if (gate_min_matches > 0 && m.st->dm_matches < gate_min_matches) return;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  int set = 0;
+  if (idx < n) {
+    const float2 rs = m.rs[idx];
+    float2 out = rs;
+    const int in = m.id_next[idx], ip = m.id_prev[idx];
+    if (in >= 0 && ip >= 0) {
+      const float2 rn = m.rs[in], rp = m.rs[ip];
+      if (!((rn.x - rp.x) * (rn.x - rp.x) > (rn.y * rn.y + rp.y * rp.y))) {
+        const float2 gn = m.grad[in], gp = m.grad[ip];
+        float alpha = (gn.x * gp.x + gn.y * gp.y) / (m.gnorm[in] * m.gnorm[ip]);
+        if (!(alpha < p.regularization_threshold)) {
+          alpha = (float)((double)(alpha - p.regularization_threshold) / (1.0 - (double)p.regularization_threshold));
+          alpha = (float)((double)alpha / ((double)(fabsf(rn.x - rp.x) / (rn.y + rp.y)) + 1.0));
+          const float wr = (float)(1.0 / (double)(rs.y * rs.y));
+          const float wrn = alpha / (rn.y * rn.y);
+          const float wrp = alpha / (rp.y * rp.y);
+          out.x = (rs.x * wr + rn.x * wrn + rp.x * wrp) / (wr + wrn + wrp);
+          out.y = (rs.y * wr + rn.y * wrn + rp.y * wrp) / (wr + wrn + wrp);
+          set = 1;
+        }
+      }
+    }
+    m.rs_tmp[idx] = out;
+  }
+  const int c = wave_sum_i(set);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&m.st->reg_count, c);
+}
+
+// ---- Core::updateInverseDepth[ARLU] (core.cpp:417-456): scalar EKF per matched keyline ----------------------------
+__global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel, int use_tmp, int gate_min_matches) {
+  const int n = m.st->n;
+  if (gate_min_matches > 0 && m.st->dm_matches < gate_min_matches) return;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  float2 rs = use_tmp ? m.rs_tmp[idx] : m.rs[idx];
+  if (m.match_id[idx] >= 0) {
+    const float2 q = m.pos_img[idx];
+    const float2 q0 = m.mpos_img[idx];
+    const float2 mg = m.mgrad[idx];
+    const float mgn = m.mgnorm[idx];
+    const float vx = vel.a[0], vy = vel.a[1], vz = vel.a[2];
+    float v_rho = rs.y * rs.y;
+    const float ux = mg.x / mgn;
+    const float uy = mg.y / mgn;
+    const float Y = ux * (q.x - q0.x) + uy * (q.y - q0.y);
+    const float H = ux * (vx * p.fm - vz * q0.x) + uy * (vy * p.fm - vz * q0.y);
+    const float rho_p = (float)(1.0 / (1.0 / (double)rs.x + (double)vz));
+    float F = (float)(1.0 / (1.0 + (double)(rs.x * vz)));
+    F *= F;
+    const float p_p = F * v_rho * F + p.reshape_q_abs * p.reshape_q_abs;
+    const float e = Y - H * rho_p;
+    const float S = H * p_p * H + p.pixel_uncertainty * p.pixel_uncertainty;
+    const float K = (float)((double)(p_p * H) * (1.0 / (double)S));
+    float rho = rho_p + K * e;
+    v_rho = (float)((1.0 - (double)(K * H)) * (double)p_p);
+    float sig = sqrtf(v_rho);
+    if (rho < kRhoMin) {
+      sig += kRhoMin - rho;
+      rho = kRhoMin;
+    } else if (rho > kRhoMax) {
+      rho = kRhoMax;
+    } else if (isnan(rho) || isnan(sig) || isinf(rho) || isinf(sig)) {
+      rho = kRhoInit;
+      sig = kRhoMax;
+    }
+    rs = make_float2(rho, sig);
+  }
+  m.rs[idx] = rs;
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+static Mat3 mat3(const float* r) {
+  Mat3 m;
+  for (int i = 0; i < 9; ++i) m.a[i] = r[i];
+  return m;
+}
+static Vec3 vec3(const float* r) {
+  Vec3 v;
+  for (int i = 0; i < 3; ++i) v.a[i] = r ? r[i] : 0.f;
+  return v;
+}
+
+void launch_rotate(hipStream_t s, const KParams& p, const MapDev& m, const float R[9], int* hist, int zero_dm) {
+  RH_LAUNCH(k_rotate, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, mat3(R), hist, p.quantile_num_bins, zero_dm);
+}
+
+void launch_quantile(hipStream_t s, const KParams& p, const MapDev& m, int* hist, float pct, int bins, float* out_dev) {
+  (void)hipMemsetAsync(hist, 0, sizeof(int) * 128, s);
+  RH_LAUNCH(k_sigma_hist, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, m, hist, bins);
+  RH_LAUNCH(k_quantile, dim3(1), dim3(64), 0, s, m, (const int*)hist, bins, pct, out_dev);
+}
+
+void launch_try_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int mode_lm, int call,
+                    int last, LmState* st_in, LmState* st_out, const float* part_prev, float* part_out, const int* hist,
+                    int frame_count) {
+  RH_LAUNCH(k_try_vel, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, oldm, newm, mode_lm, call, last,
+                     (const LmState*)st_in, st_out, part_prev, part_out, hist, (unsigned)frame_count);
+}
+
+void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev) {
+  RH_LAUNCH(k_lm_final, dim3(1), dim3(64), 0, s, oldm, calls, (const LmState*)st_in, st_out, part_prev);
+}
+
+void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm) {
+  RH_LAUNCH(k_forward_keys, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, oldm, newm);
+}
+
+void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
+                        int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
+                        float* xrv_part, const float* vel_manual) {
+  RH_LAUNCH(k_ext_rot_vel, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, oldm, newm, do_forward, do_lm_final,
+                     calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual));
+}
+
+void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
+                           const float Rvel[9], const float Rback[9], float max_radius) {
+  RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
+                     mat3(Rback), max_radius);
+}
+
+void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate) {
+  RH_LAUNCH(k_regularize, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, gate);
+}
+
+void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp, int gate) {
+  RH_LAUNCH(k_depth_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(vel), use_tmp, gate);
+}
+
+}  // namespace rh

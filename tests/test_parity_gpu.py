@@ -1,0 +1,342 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Bars:
+  * bit-exact: scale space (DoG, squared gradient), keyline set + order + every keyline field, dense mask,
+    edge chaining ids, auto threshold, distance-field ids/distances, rotateKeylines, estimateQuantile,
+    match_id_forward / residuals of tryVel, forwardMatch, directedMatch, regularize1Iter, depth EKF
+    (all per-keyline fp32 arithmetic is evaluated in the reference's order, fp contraction off);
+  * tolerance (stated at each assert): the fp32 sums over ~15k keylines (tryVel: score/JtJ/JtF, extRotVel:
+    JtJ/JtF) — the oracle adds sequentially in index order, the GPU uses a fixed butterfly/tree order.
+"""
+import numpy as np
+import pytest
+
+from conftest import params_for
+
+pytestmark = pytest.mark.gpu
+
+REL_SUM = 2e-4   # relative tolerance of a 15k-term fp32 sum, sequential vs tree order
+KW_C2 = dict(keylines_ref=15000, keylines_max=16000)
+
+
+@pytest.fixture(scope="module")
+def B():
+    import torch  # noqa: F401  (the bench process has torch's HIP runtime loaded first; do the same here)
+    from rebvio_amd import backend
+    backend.lib()
+    return backend
+
+
+def _bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.dtype.kind == "f":
+        return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    return np.array_equal(a, b)
+
+
+def assert_keylines_equal(ko, kg, fields=None, what=""):
+    assert len(ko) == len(kg), f"{what}: size {len(ko)} vs {len(kg)}"
+    for f in (fields or ko.dtype.names):
+        if not _bits_equal(ko[f], kg[f]):
+            bad = np.nonzero((ko[f] != kg[f]).reshape(len(ko), -1).any(1))[0]
+            raise AssertionError(f"{what}: field {f} differs at {len(bad)} keylines, first {bad[:5]}: "
+                                 f"{ko[f][bad[:3]]} vs {kg[f][bad[:3]]}")
+
+
+class Pair:
+    """Oracle and GPU contexts driven over the same frames; keeps the last two maps of each."""
+
+    def __init__(self, O, B, frames, cam, **kw):
+        self.O, self.B = O, B
+        self.frames, self.cam = frames, cam
+        self.orc = O.Oracle(params_for(O, cam, **kw))
+        self.ctx = B.Context(params_for(B, cam, **kw))
+        self.om = []
+        self.gm = []
+
+    def detect(self, i):
+        om = self.orc.detect_u8(self.frames[i], i * 50000)
+        gm = self.ctx.detect_u8(self.frames[i], i * 50000)
+        self.om.append(om)
+        self.gm.append(gm)
+        if len(self.om) > 2:
+            self.om.pop(0)
+            self.gm.pop(0).release()
+        return om, gm
+
+    def sync_gpu_from_oracle(self):
+        for om, gm in zip(self.om, self.gm):
+            gm.upload(om.keylines())
+
+
+def warm(O, B, frames, cam, n_pairs, **kw):
+    """Run n_pairs oracle tracking steps so that depths/matches are realistic; the GPU only detects."""
+    P = Pair(O, B, frames, cam, **kw)
+    P.detect(0)
+    for i in range(1, n_pairs + 1):
+        P.detect(i)
+        P.orc.track_pair(P.om[0], P.om[1])
+    P.detect(n_pairs + 1)  # pair under test: om[0] (tracked once as "new"), om[1] fresh
+    P.sync_gpu_from_oracle()
+    return P
+
+
+# --------------------------------------------------------------------------------------------------------
+def test_scale_space_bit_exact(orc_mod, B, c2_stream):
+    frames, cam = c2_stream
+    orc = orc_mod.Oracle(params_for(orc_mod, cam))
+    ctx = B.Context(params_for(B, cam))
+    for i in (0, 3):
+        img = frames[i].astype(np.float32) * np.float32(3.0)
+        so, sg = orc.scale_space(img), ctx.scale_space(img)
+        for k in ("scale0", "scale1", "dog", "mag"):
+            assert _bits_equal(so[k], sg[k]), f"{k} differs in {(so[k] != sg[k]).sum()} pixels"
+
+
+@pytest.mark.parametrize("shape", [(64, 48), (100, 36), (752, 480)])
+def test_scale_space_ragged_sizes(orc_mod, B, shape):
+    """Widths that are not multiples of the 64-lane tiles / 16-row strips, and EuRoC's 752x480."""
+    w, h = shape
+    rng = np.random.default_rng(w * 1000 + h)
+    img = (rng.integers(0, 256, (h, w)).astype(np.float32)) * np.float32(3.0)
+    pO = orc_mod.default_params(h, w)
+    pB = B.default_params(h, w)
+    so, sg = orc_mod.Oracle(pO).scale_space(img), B.Context(pB).scale_space(img)
+    for k in ("scale0", "scale1", "dog", "mag"):
+        assert _bits_equal(so[k], sg[k]), k
+
+
+def test_detect_sequence_bit_exact(orc_mod, B, c2_stream):
+    """Keyline index set, order, every field, masks, servo and auto thresholds over consecutive frames
+    (includes truncation at keylines_max in the first frames)."""
+    frames, cam = c2_stream
+    P = Pair(orc_mod, B, frames, cam, **KW_C2)
+    for i in range(len(frames)):
+        om, gm = P.detect(i)
+        assert om.size() == gm.size()
+        assert_keylines_equal(om.keylines(), gm.keylines(), what=f"frame {i}")
+        assert np.array_equal(om.mask(cam.height, cam.width), gm.mask())
+        thr, auto, cnt = P.ctx.detector_state()
+        assert np.float32(thr) == np.float32(P.orc.threshold)
+        assert np.float32(auto) == np.float32(P.orc.auto_threshold)
+        assert cnt == om.size()
+        assert np.float32(gm.threshold) == np.float32(om.threshold)
+
+
+def test_detect_constant_and_empty(orc_mod, B):
+    """A constant image has no keylines: empty map, threshold carried over."""
+    w, h = 128, 96
+    img = np.full((h, w), 300.0, np.float32)
+    orc = orc_mod.Oracle(orc_mod.default_params(h, w))
+    ctx = B.Context(B.default_params(h, w))
+    om, gm = orc.detect(img), ctx.detect(img)
+    assert om.size() == 0 and gm.size() == 0
+    assert (gm.mask() == -1).all()
+    assert np.float32(gm.threshold) == np.float32(om.threshold)
+
+
+def test_detect_small_keylines_max(orc_mod, B, small_stream):
+    """Early truncation: only the first keylines_max raster-ordered candidates survive, mask cleared after."""
+    frames, cam = small_stream
+    kw = dict(keylines_ref=150, keylines_max=200)
+    orc = orc_mod.Oracle(params_for(orc_mod, cam, **kw))
+    ctx = B.Context(params_for(B, cam, **kw))
+    om, gm = orc.detect_u8(frames[0]), ctx.detect_u8(frames[0])
+    assert om.size() == 200 == gm.size()
+    assert_keylines_equal(om.keylines(), gm.keylines())
+    assert np.array_equal(om.mask(cam.height, cam.width), gm.mask())
+
+
+def test_distance_field_exact(orc_mod, B, c2_stream):
+    frames, cam = c2_stream
+    P = Pair(orc_mod, B, frames, cam, **KW_C2)
+    for i in range(3):
+        om, gm = P.detect(i)
+    P.orc.build_distance_field(om)
+    P.ctx.build_distance_field(gm)
+    ido, dso = P.orc.distance_field()
+    idg, dsg = P.ctx.distance_field()
+    assert np.array_equal(ido, idg)
+    sel = ido >= 0
+    assert np.array_equal(dso[sel], dsg[sel])
+    assert sel.sum() > 100000
+
+
+def test_rotate_and_quantile_bit_exact(orc_mod, B, c2_stream):
+    frames, cam = c2_stream
+    P = warm(orc_mod, B, frames, cam, 2, **KW_C2)
+    a = 0.004
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    R = (R @ np.array([[1, 0, 0], [0, np.cos(0.002), -np.sin(0.002)], [0, np.sin(0.002), np.cos(0.002)]], np.float32)).astype(np.float32)
+    om, gm = P.om[0], P.gm[0]
+    P.orc.rotate(om, R)
+    P.ctx.rotate(gm, R)
+    assert_keylines_equal(om.keylines(), gm.keylines(), what="rotate")
+    for pct, bins in ((0.9, 100), (0.5, 37), (0.99, 128)):
+        assert np.float32(P.orc.quantile(om, pct, bins)) == np.float32(P.ctx.quantile(gm, pct, bins))
+
+
+def _sums_close(a, b, scale=None, rel=REL_SUM):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    s = scale if scale is not None else max(np.abs(a).max(), 1e-30)
+    assert np.abs(a - b).max() <= rel * s, f"max diff {np.abs(a - b).max()} vs scale {s}"
+
+
+def test_try_vel_parity(orc_mod, B, c2_stream):
+    """tryVel: match_id_forward and residuals exact (incl. the carry-forward rule), sums within REL_SUM."""
+    frames, cam = c2_stream
+    P = warm(orc_mod, B, frames, cam, 3, **KW_C2)
+    om_old, om_new = P.om
+    gm_old, gm_new = P.gm
+    P.orc.build_distance_field(om_new)
+    P.ctx.build_distance_field(gm_new)
+    n = om_old.size()
+    srm = P.orc.quantile(om_old)
+    res_o = np.zeros(n, np.float32)
+    res_g = np.zeros(n, np.float32)
+    nmatched = []
+    for vel in ([0, 0, 0], [-0.011, -0.005, -0.003], [0.02, 0.01, -0.9]):
+        so, Jo, Fo = P.orc.try_vel(om_old, vel, srm, res_o)
+        sg, Jg, Fg = P.ctx.try_vel(gm_old, vel, srm, res_g)
+        ko, kg = om_old.keylines(), gm_old.keylines()
+        assert np.array_equal(ko["match_id_forward"], kg["match_id_forward"])
+        assert _bits_equal(res_o, res_g), f"residuals differ at {(res_o != res_g).sum()}"
+        assert abs(so - sg) <= REL_SUM * abs(so)
+        # off-diagonal / signed sums cancel: scale by the diagonal magnitude
+        _sums_close(Jo, Jg, scale=np.abs(np.diag(Jo)).max())
+        _sums_close(Fo, Fg, scale=np.sqrt(so * np.abs(np.diag(Jo)).max()))
+        nmatched.append(int((ko["match_id_forward"] >= 0).sum()))
+    assert nmatched[0] > 1000 and nmatched[1] > 1000  # the third velocity sends most keylines out of view
+
+
+def test_minimize_vel_parity(orc_mod, B, c2_stream):
+    frames, cam = c2_stream
+    P = warm(orc_mod, B, frames, cam, 3, **KW_C2)
+    om_old, om_new = P.om
+    gm_old, gm_new = P.gm
+    P.orc.build_distance_field(om_new)
+    P.ctx.build_distance_field(gm_new)
+    ro = P.orc.minimize_vel(om_old)
+    rg = P.ctx.minimize_vel(gm_old)
+    assert np.float32(ro["sigma_rho_min"]) == np.float32(rg["sigma_rho_min"])
+    assert ro["accept_mask"] == rg["accept_mask"]
+    # single LM run on identical inputs: fp32 sum order is the only difference
+    assert np.abs(ro["vel"] - rg["vel"]).max() <= 1e-6 + 1e-3 * np.abs(ro["vel"]).max()
+    assert abs(ro["F"] - rg["F"]) <= 1e-3 * abs(ro["F"])
+    assert np.abs(ro["Rvel"] - rg["Rvel"]).max() <= 2e-3 * np.abs(ro["Rvel"]).max()
+    ko, kg = om_old.keylines(), gm_old.keylines()
+    same = (ko["match_id_forward"] == kg["match_id_forward"]).mean()
+    assert same >= 0.999, same
+
+
+def test_forward_match_and_ext_rot_vel(orc_mod, B, c2_stream):
+    frames, cam = c2_stream
+    P = warm(orc_mod, B, frames, cam, 3, **KW_C2)
+    om_old, om_new = P.om
+    gm_old, gm_new = P.gm
+    P.orc.build_distance_field(om_new)
+    P.ctx.build_distance_field(gm_new)
+    ro = P.orc.minimize_vel(om_old)
+    # make the GPU old map carry the oracle's match_id_forward, then compare forwardMatch exactly
+    gm_old.upload(om_old.keylines())
+    P.orc.forward_match(om_old, om_new)
+    P.ctx.forward_match(gm_old, gm_new)
+    assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="forwardMatch")
+    assert (om_new.keylines()["match_id"] >= 0).sum() > 1000
+    eo = P.orc.ext_rot_vel(ro["vel"])
+    eg = P.ctx.ext_rot_vel(ro["vel"])
+    d = np.sqrt(np.abs(np.diag(eo["Wx"])))
+    _sums_close(eo["Wx"] / np.outer(d, d), eg["Wx"] / np.outer(d, d), scale=1.0)
+    _sums_close(eo["JtF"] / d, eg["JtF"] / d, scale=np.abs(eo["JtF"] / d).max() + 1.0)
+    assert eo["ok"] == eg["ok"] == 1
+    # solution of a 6x6 system with condition ~1e4: looser
+    assert np.abs(eo["X"] - eg["X"]).max() <= 5e-3 * np.abs(eo["X"]).max() + 1e-6
+
+
+def test_directed_match_regularize_ekf_bit_exact(orc_mod, B, c2_stream):
+    frames, cam = c2_stream
+    P = warm(orc_mod, B, frames, cam, 3, **KW_C2)
+    om_old, om_new = P.om
+    gm_old, gm_new = P.gm
+    P.orc.build_distance_field(om_new)
+    P.ctx.build_distance_field(gm_new)
+    ro = P.orc.minimize_vel(om_old)
+    P.orc.forward_match(om_old, om_new)
+    gm_old.upload(om_old.keylines())
+    gm_new.upload(om_new.keylines())
+    V = ro["vel"]
+    Rvel = ro["Rvel"]
+    a = 0.0007
+    Rb = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    no, kfo = P.orc.directed_match(om_new, om_old, V, Rvel, Rb)
+    ng, kfg = P.ctx.directed_match(gm_new, gm_old, V, Rvel, Rb)
+    assert (no, kfo) == (ng, kfg)
+    assert no > 5000
+    assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="directedMatch")
+    ro_n, rg_n = P.orc.regularize(om_new), P.ctx.regularize(gm_new)
+    assert ro_n == rg_n and ro_n > 1000
+    assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="regularize")
+    P.orc.update_inverse_depth(V)
+    P.ctx.update_inverse_depth(V)
+    assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="depth EKF")
+
+
+def test_directed_match_degenerate_velocity(orc_mod, B, small_stream):
+    """|t| <= 1e-6 branch of searchMatch: search along the keyline's own gradient."""
+    frames, cam = small_stream
+    P = warm(orc_mod, B, frames, cam, 2)
+    om_old, om_new = P.om
+    gm_old, gm_new = P.gm
+    V = np.zeros(3, np.float32)
+    I = np.eye(3, dtype=np.float32)
+    no, kfo = P.orc.directed_match(om_new, om_old, V, I * 1e-6, I)
+    ng, kfg = P.ctx.directed_match(gm_new, gm_old, V, I * 1e-6, I)
+    assert (no, kfo) == (ng, kfg) and no > 50
+    assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="directedMatch degenerate")
+
+
+def test_track_pair_sequence(orc_mod, B, c2_stream):
+    """End-to-end frame pairs with state carried on each side independently (no re-sync):
+    per-pair tolerances of SURVEY.md H4, and agreement of the integer outputs."""
+    frames, cam = c2_stream
+    P = Pair(orc_mod, B, frames, cam, **KW_C2)
+    P.detect(0)
+    for i in range(1, len(frames)):
+        om, gm = P.detect(i)
+        po = P.orc.track_pair(P.om[0], P.om[1])
+        pg = P.ctx.track_pair(P.gm[0], P.gm[1])
+        assert po.status == pg.status == 0
+        assert po.lm_accept_mask == pg.lm_accept_mask
+        vo, vg = np.array(po.Vg), np.array(pg.Vg)
+        assert np.abs(vo - vg).max() <= 1e-6 + 5e-2 * np.abs(vo).max(), (i, vo, vg)
+        assert abs(po.klm_num - pg.klm_num) <= 0.01 * po.klm_num
+        ko, kg = om.keylines(), gm.keylines()
+        assert (ko["match_id"] == kg["match_id"]).mean() >= 0.97
+        both = (ko["match_id"] == kg["match_id"]) & (ko["match_id"] >= 0)
+        rel = np.abs(ko["rho"][both] - kg["rho"][both]) / np.abs(ko["rho"][both])
+        assert np.median(rel) < 1e-3
+
+
+def test_full_size_properties(B):
+    """1280x960 (~60k keylines): properties that need no oracle pass over the image at this size are cheap
+    to state - here the oracle still finishes in well under a second per frame, so compare directly, plus
+    raster-order / mask consistency invariants."""
+    from oracle import oracle_py as O
+    from rebvio_amd import synth
+    frames, cam = synth.render_stream(1280, 960, 2, density=1.0)
+    kw = dict(keylines_ref=60000, keylines_max=64000)
+    orc = O.Oracle(params_for(O, cam, **kw))
+    ctx = B.Context(params_for(B, cam, **kw))
+    for i in range(2):
+        om, gm = orc.detect_u8(frames[i]), ctx.detect_u8(frames[i])
+        kg = gm.keylines()
+        assert_keylines_equal(om.keylines(), kg, what=f"C3 frame {i}")
+        mask = gm.mask()
+        ys, xs = np.nonzero(mask >= 0)
+        assert len(ys) == len(kg)
+        assert np.array_equal(mask[ys, xs], np.arange(len(kg)))  # raster rank == keyline index
+        px = np.floor(kg["pos"] + 0.5)
+        assert (np.abs(kg["pos"][:, 0] - xs) <= 0.5).all() and (np.abs(kg["pos"][:, 1] - ys) <= 0.5).all()
+        assert px.shape[0] == len(kg)
