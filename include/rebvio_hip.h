@@ -172,7 +172,7 @@ int rebvio_hip_flush(rebvio_hip_ctx* ctx);
 
 /* Per-kernel device timing of the last N launches of each kernel, measured with HIP events on the
  * stream the kernel runs on. names: '\n'-separated. Used by bench.py's roofline leg. */
-int rebvio_hip_profile_enable(rebvio_hip_ctx* ctx, int on);
+int rebvio_hip_profile_enable(rebvio_hip_ctx* ctx, int on); /* 0 off, 1 every launch, N>1 every N-th launch */
 int rebvio_hip_profile_select(rebvio_hip_ctx* ctx, const char* only_kernel); /* NULL/"" = every kernel */
 int rebvio_hip_profile_reset(rebvio_hip_ctx* ctx);
 int rebvio_hip_profile_read(rebvio_hip_ctx* ctx, char* names, size_t names_cap, double* avg_us, int* calls, int cap);

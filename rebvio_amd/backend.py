@@ -322,9 +322,9 @@ class Context:
         _chk(lib().rebvio_hip_flush(self.h))
 
     # profiling
-    def profile(self, on: bool, only: str | None = None):
+    def profile(self, on: bool, only: str | None = None, stride: int = 1):
         lib().rebvio_hip_profile_select(self.h, (only or "").encode())
-        lib().rebvio_hip_profile_enable(self.h, 1 if on else 0)
+        lib().rebvio_hip_profile_enable(self.h, (max(1, stride) if on else 0))
 
     def profile_reset(self):
         lib().rebvio_hip_profile_reset(self.h)

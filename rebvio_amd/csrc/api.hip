@@ -36,6 +36,8 @@ int fail_msg(const char* what, int code) {
 struct Profiler {
   bool on = false;
   std::string only;
+  int stride = 1;        // record every stride-th launch of a kernel (keeps the timed region cheap)
+  std::map<std::string, unsigned> seen;
   struct Sample {
     int name;
     hipEvent_t e0, e1;
@@ -88,6 +90,7 @@ void prof_begin(hipStream_t s, const char* name) {
   std::lock_guard<std::mutex> g(g_prof.mu);
   g_prof.open_name = -1;
   if (!g_prof.only.empty() && g_prof.only != name) return;
+  if (g_prof.stride > 1 && (g_prof.seen[name]++ % (unsigned)g_prof.stride) != 0) return;
   if (g_prof.samples.size() >= g_prof.cap) return;
   g_prof.open_name = g_prof.name_id(name);
   g_prof.open_e0 = g_prof.get_event();
@@ -110,7 +113,8 @@ struct rebvio_hip_map {
   MapDev d{};
   bool in_use = false;
   uint64_t ts = 0;
-  hipEvent_t ready{};  // detect (+ distance field) finished, recorded on the detect stream
+  hipEvent_t detected{};  // keylines + mask + chaining finished (detect stream)
+  hipEvent_t ready{};     // ... and distance field built (distance-field stream)
   hipEvent_t done{};   // last track-stream consumer finished, recorded at release
   bool has_done = false;
   bool df_built = false;
@@ -122,11 +126,12 @@ struct rebvio_hip_ctx {
   rebvio_hip_params P{};
   KParams K{};
   int device = 0;
-  hipStream_t s_det{}, s_trk{}, s_cpy{};
+  hipStream_t s_det{}, s_df{}, s_trk{}, s_cpy{};
   ScaleBufs sb{};
   DetectBufs db{};
-  DetState* det = nullptr;  // [2]
+  DetState* det = nullptr;  // [kDetRing] servo-state ring + [kDetRing]: scratch sink
   uint64_t frame_index = 0;
+  rebvio_hip_map* last_detected = nullptr;
   int widths[2][3]{};
   std::vector<rebvio_hip_map*> pool;
   float* img_dev = nullptr;
@@ -140,6 +145,8 @@ struct rebvio_hip_ctx {
   float* part = nullptr;    // [kMaxLmCalls+1][maxblocks][kPartStride]
   float* xrv_part = nullptr;
   int* hist = nullptr;      // [128]
+  int* dm_work = nullptr;   // [keylines_max] directedMatch long-search queue
+  int* dm_work_n = nullptr; // its length (zero between pairs)
   float* fscratch = nullptr;
   int maxblocks = 0;
   rebvio_hip_map* df_map = nullptr;
@@ -152,9 +159,26 @@ struct rebvio_hip_ctx {
   // glue state (types/imu.hpp:171-187)
   float Bg[3]{};
   hm::M3 W_Bg{}, RGBias{}, RGyro{};
-  // streaming
-  rebvio_hip_map* pend_old = nullptr;
-  rebvio_hip_map* pend_new = nullptr;
+  LmState* lm_zero = nullptr;  // constant start state of minimizeVel (Vg = 0, rebvio.cpp:167)
+  // streaming pipeline (rebvio_hip_push_frame_u8_device)
+  static constexpr int kSlots = 4;
+  PairSlot* slot[kSlots]{};    // pinned, written by k_ext_rot_vel
+  hipEvent_t slot_ev[kSlots]{};
+  struct PendingPair {
+    rebvio_hip_map* om = nullptr;
+    rebvio_hip_map* nm = nullptr;
+    int slot = -1;
+    bool a_enqueued = false;
+    hm::M3 R;          // prior rotation used for the first rotate
+    float frame_dt = 0.f;
+    rebvio_hip_pair_out out{};
+    bool b_enqueued = false;
+  };
+  std::vector<rebvio_hip_map*> frames;  // detected maps not yet consumed as "old"
+  PendingPair cur{};                    // pair whose A-chain is in flight
+  PendingPair prev{};                   // pair whose B-chain is in flight (counters arrive with cur's slot)
+  bool has_cur = false, has_prev = false;
+  uint64_t pair_seq = 0;
 };
 
 namespace {
@@ -162,7 +186,8 @@ namespace {
 size_t part_call_stride(const rebvio_hip_ctx* c) { return (size_t)c->maxblocks * kPartStride; }
 
 int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
-  const size_t M = (size_t)c->P.keylines_max, Pn = (size_t)c->P.rows * c->P.cols;
+  // keyline arrays are padded to the launch grid (multiple of 256) so kernels may load before checking n
+  const size_t M = (size_t)div_up(c->P.keylines_max, 256) * 256, Pn = (size_t)c->P.rows * c->P.cols;
   MapDev& d = m->d;
   HIPCHK(hipMalloc(&d.pos, M * sizeof(float2)));
   HIPCHK(hipMalloc(&d.pos_img, M * sizeof(float2)));
@@ -188,6 +213,7 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipMemset(d.mask, 0xFF, Pn * sizeof(int)));
   HIPCHK(hipMemset(d.df, 0xFF, Pn * sizeof(unsigned)));
   HIPCHK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&m->detected, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
   return 0;
 }
@@ -199,6 +225,7 @@ void free_map(rebvio_hip_map* m) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (m->ready) (void)hipEventDestroy(m->ready);
+  if (m->detected) (void)hipEventDestroy(m->detected);
   if (m->done) (void)hipEventDestroy(m->done);
   delete m;
 }
@@ -245,17 +272,22 @@ int detect_common(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts
   if (!m) return fail_msg("edge-map pool exhausted (release maps or raise map_pool)", -2);
   if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_det, m->done, 0));
   m->ts = ts;
-  const DetState* det_in = c->det + (c->frame_index & 1);
-  DetState* det_out = c->det + ((c->frame_index + 1) & 1);
+  const DetState* det_in = c->det + (c->frame_index % kDetRing);
+  DetState* det_out = c->det + ((c->frame_index + 1) % kDetRing);
   ScaleBufs sb = c->sb;
   sb.scale0 = sb.scale1 = nullptr;
   launch_scale_space(c->s_det, c->K, img_dev, is_u8, sb, c->widths, c->db.rowcount);
-  launch_keylines(c->s_det, c->K, sb, c->db, m->d, det_in, det_out, c->frame_index);
-  launch_df_build(c->s_det, c->K, m->d, det_in, det_out);
+  launch_keylines(c->s_det, c->K, sb, c->db, m->d, det_in, det_out, c->last_detected ? c->last_detected->d.st : nullptr);
+  HIPCHK(hipGetLastError());
+  // distance field of this map on its own stream: overlaps the next frame's scan kernels
+  HIPCHK(hipEventRecord(m->detected, c->s_det));
+  HIPCHK(hipStreamWaitEvent(c->s_df, m->detected, 0));
+  launch_df_build(c->s_df, c->K, m->d, det_out);
   m->df_built = true;
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(m->ready, c->s_det));
+  HIPCHK(hipEventRecord(m->ready, c->s_df));
   c->frame_index++;
+  c->last_detected = m;
   *out = m;
   return 0;
 }
@@ -300,15 +332,19 @@ void lm_to_out(const LmState& s, float vel[3], float Rvel[9], float* F, int* mas
 
 // minimizeVel on the track stream: histogram must already be in c->hist and residuals zeroed.
 void enqueue_lm_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3]) {
-  LmState init;
-  std::memset(&init, 0, sizeof(init));
-  for (int i = 0; i < 3; ++i) init.vel[i] = vel0[i];
-  c->h_lm[1] = init;
-  (void)hipMemcpyAsync(c->lm, &c->h_lm[1], sizeof(LmState), hipMemcpyHostToDevice, c->s_trk);
+  LmState* first = c->lm_zero;
+  if (vel0[0] != 0.f || vel0[1] != 0.f || vel0[2] != 0.f) {
+    LmState init;
+    std::memset(&init, 0, sizeof(init));
+    for (int i = 0; i < 3; ++i) init.vel[i] = vel0[i];
+    c->h_lm[1] = init;
+    (void)hipMemcpyAsync(c->lm, &c->h_lm[1], sizeof(LmState), hipMemcpyHostToDevice, c->s_trk);
+    first = c->lm;
+  }
   const int calls = (int)c->P.iterations + 1;
   const size_t cs = part_call_stride(c);
   for (int i = 0; i < calls; ++i)
-    launch_try_vel(c->s_trk, c->K, om->d, nm->d, 1, i, i == calls - 1, c->lm + i, c->lm + i + 1,
+    launch_try_vel(c->s_trk, c->K, om->d, nm->d, 1, i, i == calls - 1, i ? c->lm + i : first, c->lm + i + 1,
                    i ? c->part + (size_t)(i - 1) * cs : c->part, c->part + (size_t)i * cs, c->hist, 0);
 }
 
@@ -348,6 +384,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   *out = nullptr;
   if (p->rows < 32 || p->cols < 32 || (p->cols % 4) != 0) return fail_msg("rows/cols must be >= 32 and cols % 4 == 0", -3);
   if (p->cols > 4096) return fail_msg("cols > 4096 unsupported", -3);
+  if ((size_t)(p->rows + 12) * 16 * sizeof(float) > 160 * 1024 || (size_t)(p->cols + 8) * 4 * sizeof(float) > 160 * 1024)
+    return fail_msg("image too large for the LDS-staged scan strips (rows <= 2548)", -3);
   if (p->quantile_num_bins > 128 || p->quantile_num_bins < 1) return fail_msg("quantile_num_bins must be in 1..128", -3);
   if ((int)p->iterations + 2 > 15) return fail_msg("iterations too large", -3);
   const int nr = 2 * (int)p->search_range;
@@ -395,6 +433,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
 
   HIPCHK(hipStreamCreateWithFlags(&c->s_det, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->s_df, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->s_cpy, hipStreamNonBlocking));
   const size_t Pn = (size_t)p->rows * p->cols;
   for (int f = 0; f < 2; ++f) {
@@ -407,9 +446,9 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->db.bits, (size_t)p->rows * K.nseg * sizeof(unsigned long long)));
   HIPCHK(hipMalloc(&c->db.rowcount, (size_t)p->rows * sizeof(int)));
   HIPCHK(hipMemset(c->db.rowcount, 0, (size_t)p->rows * sizeof(int)));
-  HIPCHK(hipMalloc(&c->det, 3 * sizeof(DetState)));  // [0],[1]: ping-pong servo state, [2]: scratch sink
-  DetState d0[2];
-  for (int i = 0; i < 2; ++i) {
+  HIPCHK(hipMalloc(&c->det, (kDetRing + 1) * sizeof(DetState)));
+  DetState d0[kDetRing + 1];
+  for (int i = 0; i < kDetRing + 1; ++i) {
     d0[i].threshold = p->threshold;       // config_->threshold
     d0[i].count = 0;                      // keylines_count_(0) (edge_detector.cpp:18)
     d0[i].auto_threshold = p->threshold;  // auto_threshold_(config_->threshold) (edge_detector.cpp:20)
@@ -428,6 +467,18 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMemset(c->part, 0, (size_t)(kMaxLmCalls + 1) * part_call_stride(c) * sizeof(float)));
   HIPCHK(hipMalloc(&c->xrv_part, (size_t)c->maxblocks * kXrvStride * sizeof(float)));
   HIPCHK(hipMalloc(&c->hist, 128 * sizeof(int)));
+  HIPCHK(hipMemset(c->hist, 0, 128 * sizeof(int)));
+  HIPCHK(hipMalloc(&c->dm_work, (size_t)div_up(p->keylines_max, 256) * 256 * sizeof(int)));
+  HIPCHK(hipMalloc(&c->dm_work_n, sizeof(int)));
+  HIPCHK(hipMemset(c->dm_work_n, 0, sizeof(int)));
+  HIPCHK(hipMalloc(&c->lm_zero, sizeof(LmState)));
+  HIPCHK(hipMemset(c->lm_zero, 0, sizeof(LmState)));
+  for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
+    const size_t sz = sizeof(PairSlot) + (size_t)c->maxblocks * kXrvStride * sizeof(float);
+    HIPCHK(hipHostMalloc(&c->slot[i], sz, hipHostMallocDefault));
+    std::memset(c->slot[i], 0, sz);
+    HIPCHK(hipEventCreateWithFlags(&c->slot_ev[i], hipEventDisableTiming));
+  }
   HIPCHK(hipMalloc(&c->fscratch, 64 * sizeof(float)));
   HIPCHK(hipHostMalloc(&c->h_lm, 2 * sizeof(LmState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_part, part_call_stride(c) * sizeof(float), hipHostMallocDefault));
@@ -435,8 +486,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipHostMalloc(&c->h_st, 2 * sizeof(MapState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_f, 64 * sizeof(float), hipHostMallocDefault));
 
-  int pool = p->map_pool > 0 ? p->map_pool : 4;
-  if (pool < 3) pool = 3;
+  int pool = p->map_pool > 0 ? p->map_pool : 6;
+  if (pool < 4) pool = 4;
   for (int i = 0; i < pool; ++i) {
     rebvio_hip_map* m = new rebvio_hip_map;
     m->ctx = c;
@@ -469,6 +520,14 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
     if (p) (void)hipHostFree(p);
   (void)hipStreamDestroy(c->s_det);
   (void)hipStreamDestroy(c->s_trk);
+  (void)hipStreamDestroy(c->s_df);
+  for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
+    if (c->slot[i]) (void)hipHostFree(c->slot[i]);
+    if (c->slot_ev[i]) (void)hipEventDestroy(c->slot_ev[i]);
+  }
+  if (c->lm_zero) (void)hipFree(c->lm_zero);
+  if (c->dm_work) (void)hipFree(c->dm_work);
+  if (c->dm_work_n) (void)hipFree(c->dm_work_n);
   (void)hipStreamDestroy(c->s_cpy);
   delete c;
 }
@@ -511,9 +570,20 @@ int rebvio_hip_detector_state(rebvio_hip_ctx* c, float* threshold, float* auto_t
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->s_det));
   DetState d;
-  HIPCHK(hipMemcpy(&d, c->det + (c->frame_index & 1), sizeof(d), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&d, c->det + (c->frame_index % kDetRing), sizeof(d), hipMemcpyDeviceToHost));
+  float at = d.auto_threshold;
+  if (c->last_detected) {  // tuneThreshold of the last frame (edge_detector.cpp:184), same fp32 formula as the kernels
+    MapState st;
+    HIPCHK(hipMemcpy(&st, c->last_detected->d.st, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.n > 0) {
+      float mx, mn;
+      std::memcpy(&mx, &st.gmax_bits, 4);
+      std::memcpy(&mn, &st.gmin_bits, 4);
+      at = mx - float(kNumBins * (mx - mn)) / float(kNumBins);
+    }
+  }
   if (threshold) *threshold = d.threshold;
-  if (auto_threshold) *auto_threshold = d.auto_threshold;
+  if (auto_threshold) *auto_threshold = at;
   if (count) *count = d.count;
   return 0;
 }
@@ -533,8 +603,9 @@ int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int
   HIPCHK(hipSetDevice(c->device));
   int rc = ensure_size(m);
   if (rc) return rc;
-  // mirror reflects everything enqueued so far on both streams
+  // mirror reflects everything enqueued so far on every stream
   HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_trk));
   if (keylines && m->n_host > 0) {
     launch_map_pack(c->s_cpy, c->K, m->d, c->aos_dev);
@@ -552,6 +623,7 @@ int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines,
   int rc = ensure_size(m);
   if (rc) return rc;
   if (n != m->n_host) return fail_msg("map_upload: count differs from map size", -6);
+  HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_trk));
   if (n > 0) {
@@ -570,7 +642,7 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
   (void)hipEventRecord(m->done, c->s_trk);
   m->has_done = true;
   if (c->df_map == m) c->df_map = nullptr;
-  m->in_use = false;
+  m->in_use = false;  // (c->last_detected may keep pointing at it: only its MapState is read, stream-ordered)
 }
 
 int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
@@ -578,8 +650,7 @@ int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
   if (!m->df_built) {
     HIPCHK(hipMemsetAsync(m->d.df, 0xFF, (size_t)c->P.rows * c->P.cols * sizeof(unsigned), c->s_trk));
-    const DetState* dprev = c->det + (c->frame_index & 1);
-    launch_df_build(c->s_trk, c->K, m->d, dprev, c->det + 2);
+    launch_df_build(c->s_trk, c->K, m->d, c->det + (c->frame_index % kDetRing));
     HIPCHK(hipGetLastError());
     m->df_built = true;
   }
@@ -614,6 +685,7 @@ int rebvio_hip_quantile(rebvio_hip_ctx* c, rebvio_hip_map* m, float percentile, 
   launch_quantile(c->s_trk, c->K, m->d, c->hist, percentile, num_bins, c->fscratch);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_f, c->fscratch, sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));  // invariant: the histogram is zero between uses
   HIPCHK(hipStreamSynchronize(c->s_trk));
   *out = c->h_f[0];
   return 0;
@@ -671,6 +743,7 @@ int rebvio_hip_minimize_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, float vel[3], 
                   c->part + (size_t)(calls - 1) * part_call_stride(c));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(&c->h_lm[0], c->lm + calls + 1, sizeof(LmState), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));  // invariant: the histogram is zero between uses
   HIPCHK(hipStreamSynchronize(c->s_trk));
   lm_to_out(c->h_lm[0], vel, Rvel, F, accept_mask, sigma_rho_min);
   return 0;
@@ -682,7 +755,7 @@ int rebvio_hip_forward_match(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_m
   HIPCHK(hipStreamWaitEvent(c->s_trk, nm->ready, 0));
   launch_forward_keys(c->s_trk, c->K, om->d, nm->d);
   const float v0[3] = {0, 0, 0};
-  launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 0, 0, c->lm, c->lm, c->part, c->xrv_part, v0);
+  launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 0, 0, c->lm, c->lm, c->part, c->xrv_part, v0, nullptr, nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -693,7 +766,7 @@ int rebvio_hip_ext_rot_vel(rebvio_hip_ctx* c, const float vel[3], float Wx[36], 
   rebvio_hip_map* nm = c->df_map;
   int rc = ensure_size(nm);
   if (rc) return rc;
-  launch_ext_rot_vel(c->s_trk, c->K, nm->d, nm->d, 0, 0, 0, c->lm, c->lm, c->part, c->xrv_part, vel);
+  launch_ext_rot_vel(c->s_trk, c->K, nm->d, nm->d, 0, 0, 0, c->lm, c->lm, c->part, c->xrv_part, vel, nullptr, nullptr);
   HIPCHK(hipGetLastError());
   const int nb = std::max(1, div_up(nm->n_host, 256));
   HIPCHK(hipMemcpyAsync(c->h_xrv, c->xrv_part, (size_t)nb * kXrvStride * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
@@ -717,7 +790,8 @@ int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, vel, Rvel, Rback, vel_r, Rvel_r);
   HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 3 * sizeof(int), c->s_trk));
-  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius);
+  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, c->dm_work, c->dm_work_n);
+  HIPCHK(hipMemsetAsync(c->dm_work_n, 0, sizeof(int), c->s_trk));
   HIPCHK(hipGetLastError());
   MapState st;
   int rc = fetch_map_state(nm, &st, c->s_trk);
@@ -731,7 +805,7 @@ int rebvio_hip_regularize(rebvio_hip_ctx* c, rebvio_hip_map* m, int* count) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
   HIPCHK(hipMemsetAsync(&m->d.st->reg_count, 0, sizeof(int), c->s_trk));
-  launch_regularize(c->s_trk, c->K, m->d, 0);
+  launch_regularize(c->s_trk, c->K, m->d, 0, nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(m->d.rs, m->d.rs_tmp, (size_t)c->P.keylines_max * sizeof(float2), hipMemcpyDeviceToDevice, c->s_trk));
   MapState st;
@@ -749,48 +823,24 @@ int rebvio_hip_update_inverse_depth(rebvio_hip_ctx* c, const float vel[3]) {
   return 0;
 }
 
-int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float* R_prior, float frame_dt,
-                          rebvio_hip_pair_out* out) {
-  HIPCHK(hipSetDevice(c->device));
-  std::memset(out, 0, sizeof(*out));
-  hipStream_t s = c->s_trk;
-  HIPCHK(hipStreamWaitEvent(s, om->ready, 0));
-  HIPCHK(hipStreamWaitEvent(s, nm->ready, 0));
-  int rc = rebvio_hip_build_distance_field(c, nm);  // rebvio.cpp:142 (no-op when detect already built it)
-  if (rc) return rc;
-
-  // R = imu.R(); R.T() = SO3(Bg) * R.T()  (rebvio.cpp:163-164)
-  hm::M3 R = R_prior ? hm::load3(R_prior) : hm::identity3();
-  R = hm::transpose(hm::mul(hm::so3_exp(c->Bg), hm::transpose(R)));
-  float RT[9];
-  hm::store3(hm::transpose(R), RT);
-
-  HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), s));
-  launch_rotate(s, c->K, om->d, RT, c->hist, 0);  // rebvio.cpp:165 (+ histogram for estimateQuantile)
-  const float v0[3] = {0, 0, 0};                  // imu_state_.Vg = Zeros (rebvio.cpp:167)
-  enqueue_lm_chain(c, om, nm, v0);                // minimizeVel (rebvio.cpp:169)
-  const int calls = (int)c->P.iterations + 1;
-  // forwardMatch + extRotVel (rebvio.cpp:172-177), LM's last accept/reject in the prologue
-  launch_ext_rot_vel(s, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
-                     c->part + (size_t)(calls - 1) * part_call_stride(c), c->xrv_part, v0);
-  HIPCHK(hipGetLastError());
-  const int nbmax = c->maxblocks;
-  HIPCHK(hipMemcpyAsync(&c->h_lm[0], c->lm + calls + 1, sizeof(LmState), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(c->h_xrv, c->xrv_part, (size_t)nbmax * kXrvStride * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(&c->h_st[1], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-
-  nm->n_host = c->h_st[1].n;
-  nm->thr_host = c->h_st[1].threshold;
+namespace {
+// Host glue between extRotVel and directedMatch (rebvio.cpp:177-233, accelerometer/SAB branch excluded): 6x6 solve,
+// gyroBiasCorrection, SO3 correction, covariance. R is the prior rotation used for the first rotateKeylines.
+struct GlueOut {
+  float R0a[9], Rgva[9], V[3], P_V[9];
+  bool nan_v;
+};
+GlueOut pair_glue(rebvio_hip_ctx* c, const LmState& lm, const float* xrv, int n_new, float frame_dt, hm::M3 R,
+                  rebvio_hip_pair_out* out) {
+  GlueOut g;
   float Vg[3], P_Vg[9];
-  lm_to_out(c->h_lm[0], Vg, P_Vg, &out->F, &out->lm_accept_mask, &out->sigma_rho_min);
+  lm_to_out(lm, Vg, P_Vg, &out->F, &out->lm_accept_mask, &out->sigma_rho_min);
   float Xv[6], W_Xv[36], JtF6[6];
-  sum_xrv(c->h_xrv, div_up(nm->n_host, 256), W_Xv, JtF6, nullptr);
+  sum_xrv(xrv, div_up(n_new, 256), W_Xv, JtF6, nullptr);
   hm::sym6_pinv_solve(W_Xv, JtF6, Xv);
   out->ext_ok = 1;
   for (int i = 0; i < 6; ++i)
     if (std::isnan(Xv[i])) out->ext_ok = 0;
-
   float Xgv[6], W_Xgv[36];
   std::memcpy(Xgv, Xv, sizeof(Xv));
   std::memcpy(W_Xgv, W_Xv, sizeof(W_Xv));
@@ -807,40 +857,75 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   // rebvio.cpp:195-203
   const hm::M3 R0 = hm::so3_exp(dWgv);
   R = hm::transpose(hm::mul(R0, hm::transpose(R)));
-  float V[3];
-  hm::mulv(R0, Vg, V);
-  for (int i = 0; i < 3; ++i) V[i] += dVgv[i];
+  hm::mulv(R0, Vg, g.V);
+  for (int i = 0; i < 3; ++i) g.V[i] += dVgv[i];
   float R_Xgv[36];
   hm::cholesky6_inverse(W_Xgv, R_Xgv);
-  float P_V[9];
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) P_V[i * 3 + j] = R_Xgv[i * 6 + j];
-  float Rgva[9], R0a[9];
-  hm::store3(R, Rgva);  // rebvio.cpp:228
-  hm::store3(R0, R0a);
-
-  for (int i = 0; i < 3; ++i) { out->Vg[i] = Vg[i]; out->V[i] = V[i]; }
+    for (int j = 0; j < 3; ++j) g.P_V[i * 3 + j] = R_Xgv[i * 6 + j];
+  hm::store3(R, g.Rgva);  // rebvio.cpp:228
+  hm::store3(R0, g.R0a);
+  for (int i = 0; i < 3; ++i) { out->Vg[i] = Vg[i]; out->V[i] = g.V[i]; }
   std::memcpy(out->P_Vg, P_Vg, sizeof(P_Vg));
   std::memcpy(out->Xv, Xv, sizeof(Xv));
   std::memcpy(out->W_Xv, W_Xv, sizeof(W_Xv));
   std::memcpy(out->Xgv, Xgv, sizeof(Xgv));
-  std::memcpy(out->R, Rgva, sizeof(Rgva));
-  std::memcpy(out->P_V, P_V, sizeof(P_V));
+  std::memcpy(out->R, g.Rgva, sizeof(g.Rgva));
+  std::memcpy(out->P_V, g.P_V, sizeof(g.P_V));
+  g.nan_v = std::isnan(g.V[0]) || std::isnan(g.V[1]) || std::isnan(g.V[2]);
+  return g;
+}
 
-  launch_rotate(s, c->K, om->d, R0a, nullptr, 0);  // rebvio.cpp:232
-  if (std::isnan(V[0]) || std::isnan(V[1]) || std::isnan(V[2])) {  // rebvio.cpp:236
+// rotate by R0, directedMatch, regularize1Iter, updateInverseDepth (rebvio.cpp:232-259) on the track stream
+void enqueue_b_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const GlueOut& g) {
+  hipStream_t s = c->s_trk;
+  launch_rotate(s, c->K, om->d, g.R0a, nullptr, 0);  // rebvio.cpp:232
+  if (g.nan_v) return;                                // rebvio.cpp:236
+  float vel_r[3], Rvel_r[9];
+  rotate_inputs(c, g.V, g.P_V, g.Rgva, vel_r, Rvel_r);
+  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, g.Rgva, c->P.search_range, c->dm_work, c->dm_work_n);  // :245
+  const int gate = (int)c->P.global_min_matches_threshold;
+  launch_regularize(s, c->K, nm->d, gate > 0 ? gate : 0, c->dm_work_n);  // rebvio.cpp:256 (skipped on device when klm < gate)
+  launch_depth_ekf(s, c->K, nm->d, g.V, 1, gate > 0 ? gate : 0);   // rebvio.cpp:259
+}
+
+hm::M3 prior_rotation(rebvio_hip_ctx* c, const float* R_prior) {
+  // R = imu.R(); R.T() = SO3(Bg) * R.T()  (rebvio.cpp:163-164)
+  hm::M3 R = R_prior ? hm::load3(R_prior) : hm::identity3();
+  return hm::transpose(hm::mul(hm::so3_exp(c->Bg), hm::transpose(R)));
+}
+}  // namespace
+
+int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float* R_prior, float frame_dt,
+                          rebvio_hip_pair_out* out) {
+  HIPCHK(hipSetDevice(c->device));
+  std::memset(out, 0, sizeof(*out));
+  hipStream_t s = c->s_trk;
+  HIPCHK(hipStreamWaitEvent(s, om->ready, 0));
+  HIPCHK(hipStreamWaitEvent(s, nm->ready, 0));
+  int rc = rebvio_hip_build_distance_field(c, nm);  // rebvio.cpp:142 (no-op when detect already built it)
+  if (rc) return rc;
+  const hm::M3 R = prior_rotation(c, R_prior);
+  float RT[9];
+  hm::store3(hm::transpose(R), RT);
+  launch_rotate(s, c->K, om->d, RT, c->hist, 0);  // rebvio.cpp:165 (+ histogram for estimateQuantile; hist is zero here)
+  const float v0[3] = {0, 0, 0};                  // imu_state_.Vg = Zeros (rebvio.cpp:167)
+  enqueue_lm_chain(c, om, nm, v0);                // minimizeVel (rebvio.cpp:169)
+  const int calls = (int)c->P.iterations + 1;
+  // forwardMatch + extRotVel (rebvio.cpp:172-177), LM's last accept/reject in the prologue; results land in slot 0
+  PairSlot* slot = c->slot[0];
+  launch_ext_rot_vel(s, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
+                     c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, v0, slot, c->hist);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  nm->n_host = slot->new_st.n;
+  nm->thr_host = slot->new_st.threshold;
+  const GlueOut g = pair_glue(c, slot->lm, slot->xrv, nm->n_host, frame_dt, R, out);
+  enqueue_b_chain(c, om, nm, g);
+  HIPCHK(hipGetLastError());
+  if (g.nan_v) {
     out->status = 1;
     return 0;
-  }
-  float vel_r[3], Rvel_r[9];
-  rotate_inputs(c, V, P_V, Rgva, vel_r, Rvel_r);
-  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, Rgva, c->P.search_range);  // rebvio.cpp:245
-  const int gate = (int)c->P.global_min_matches_threshold;
-  launch_regularize(s, c->K, nm->d, gate > 0 ? gate : 0);  // rebvio.cpp:256 (skipped on device when klm < gate)
-  launch_depth_ekf(s, c->K, nm->d, V, 1, gate > 0 ? gate : 0);  // rebvio.cpp:259
-  HIPCHK(hipGetLastError());
-  if (gate <= 0) {
-    // no gate: regularize always ran; depth filter consumed rs_tmp
   }
   HIPCHK(hipMemcpyAsync(&c->h_st[1], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -851,35 +936,120 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   return 0;
 }
 
+namespace {
+int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
+  hipStream_t s = c->s_trk;
+  HIPCHK(hipStreamWaitEvent(s, pp.om->ready, 0));
+  HIPCHK(hipStreamWaitEvent(s, pp.nm->ready, 0));
+  c->df_map = pp.nm;
+  pp.R = prior_rotation(c, nullptr);
+  float RT[9];
+  hm::store3(hm::transpose(pp.R), RT);
+  launch_rotate(s, c->K, pp.om->d, RT, c->hist, 0);
+  const float v0[3] = {0, 0, 0};
+  enqueue_lm_chain(c, pp.om, pp.nm, v0);
+  const int calls = (int)c->P.iterations + 1;
+  PairSlot* slot = c->slot[pp.slot];
+  launch_ext_rot_vel(s, c->K, pp.om->d, pp.nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
+                     c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, v0, slot, c->hist);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->slot_ev[pp.slot], s));
+  pp.a_enqueued = true;
+  return 0;
+}
+
+// Completes the pair whose A-chain is in flight: waits for its slot, runs the glue, enqueues its B-chain.
+// The directedMatch / regularize counters of the PREVIOUS pair arrive with this slot (old map of this pair).
+int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* completed_keylines, bool* have_completed) {
+  rebvio_hip_ctx::PendingPair& cur = c->cur;
+  HIPCHK(hipEventSynchronize(c->slot_ev[cur.slot]));
+  PairSlot* slot = c->slot[cur.slot];
+  if (c->has_prev) {
+    rebvio_hip_pair_out& po = c->prev.out;
+    if (po.status != 1) {
+      po.klm_num = slot->old_st.dm_matches;
+      po.kf_matches = slot->old_st.dm_kf;
+      po.reg_num = slot->old_st.reg_count;
+      if ((unsigned)po.klm_num < c->P.global_min_matches_threshold) po.status = 2;
+    }
+    if (completed) *completed = po;
+    if (completed_keylines) *completed_keylines = slot->old_st.n;
+    if (have_completed) *have_completed = true;
+    c->has_prev = false;
+  }
+  cur.nm->n_host = slot->new_st.n;
+  cur.nm->thr_host = slot->new_st.threshold;
+  std::memset(&cur.out, 0, sizeof(cur.out));
+  const GlueOut g = pair_glue(c, slot->lm, slot->xrv, cur.nm->n_host, cur.frame_dt, cur.R, &cur.out);
+  enqueue_b_chain(c, cur.om, cur.nm, g);
+  HIPCHK(hipGetLastError());
+  if (g.nan_v) cur.out.status = 1;
+  rebvio_hip_map_release(cur.om);  // stream-ordered: reusable once the B-chain has drained
+  c->prev = cur;
+  c->has_prev = true;
+  c->has_cur = false;
+  return 0;
+}
+}  // namespace
+
 int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
                                     int* keylines) {
+  // Software pipeline over three HIP streams (one host sync per frame):
+  //   detect stream : scale space + keylines of frame f            (this call)
+  //   df stream     : distance field of frame f                     (this call, after detect)
+  //   track stream  : B-chain of pair (f-3, f-2) then A-chain of pair (f-2, f-1)
+  // The returned record is the most recent COMPLETE pair (its match counters travel with the next pair's slot),
+  // i.e. pair (f-4, f-3) in steady state; status -1 while the pipeline fills.
   rebvio_hip_map* m = nullptr;
-  int rc = rebvio_hip_detect_u8_device(c, frame_dev, ts_us, &m);  // asynchronous on the detect stream
+  int rc = rebvio_hip_detect_u8_device(c, frame_dev, ts_us, &m);
   if (rc) return rc;
+  c->frames.push_back(m);
   if (out) {
     std::memset(out, 0, sizeof(*out));
     out->status = -1;
   }
   if (keylines) *keylines = -1;
-  if (c->pend_old && c->pend_new) {
-    rebvio_hip_pair_out tmp;
-    const float dt = (float)((double)(float)(c->pend_new->ts - c->pend_old->ts) / 1000000.0);  // rebvio.cpp:183
-    rc = rebvio_hip_track_pair(c, c->pend_old, c->pend_new, nullptr, dt, out ? out : &tmp);
+  if (c->has_cur) {
+    bool have = false;
+    rebvio_hip_pair_out done;
+    int nk = -1;
+    rc = finish_current(c, &done, &nk, &have);
     if (rc) return rc;
-    if (keylines) *keylines = c->pend_new->n_host;
-    rebvio_hip_map_release(c->pend_old);
+    if (have) {
+      if (out) *out = done;
+      if (keylines) *keylines = nk;
+    }
   }
-  c->pend_old = c->pend_new;
-  c->pend_new = m;
+  if (c->frames.size() >= 3) {  // frames[1] was detected at least one call ago: the track stream will not stall on it
+    rebvio_hip_ctx::PendingPair pp;
+    pp.om = c->frames[0];
+    pp.nm = c->frames[1];
+    pp.slot = (int)(c->pair_seq++ % rebvio_hip_ctx::kSlots);
+    pp.frame_dt = (float)((double)(float)(pp.nm->ts - pp.om->ts) / 1000000.0);  // rebvio.cpp:183
+    rc = enqueue_a_chain(c, pp);
+    if (rc) return rc;
+    c->cur = pp;
+    c->has_cur = true;
+    c->frames.erase(c->frames.begin());
+  }
   return 0;
 }
 
 int rebvio_hip_flush(rebvio_hip_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
-  if (c->pend_old) rebvio_hip_map_release(c->pend_old);
-  if (c->pend_new) rebvio_hip_map_release(c->pend_new);
-  c->pend_old = c->pend_new = nullptr;
+  if (c->has_cur) {
+    int rc = finish_current(c, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  if (c->has_prev) {
+    rebvio_hip_map_release(c->prev.nm);
+    c->has_prev = false;
+  }
+  for (auto* m : c->frames)
+    if (m->in_use) rebvio_hip_map_release(m);
+  c->frames.clear();
   HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_trk));
   return 0;
 }
@@ -888,6 +1058,12 @@ int rebvio_hip_profile_enable(rebvio_hip_ctx* c, int on) {
   (void)c;
   std::lock_guard<std::mutex> g(g_prof.mu);
   g_prof.on = on != 0;
+  g_prof.stride = on > 1 ? on : 1;  // on = N > 1: sample every N-th launch of each kernel
+  if (g_prof.on && g_prof.free_events.size() < 256)
+    for (int i = 0; i < 512; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) == hipSuccess) g_prof.free_events.push_back(e);
+    }
   return 0;
 }
 

@@ -18,6 +18,7 @@ constexpr unsigned kDfSeqMask = (1u << kDfSeqBits) - 1u;
 constexpr int kPartStride = 16;     // floats per block record of k_try_vel
 constexpr int kXrvStride = 32;      // floats per block record of k_ext_rot_vel
 constexpr int kMaxLmCalls = 8;
+constexpr int kDetRing = 4;         // DetState ring depth (distance-field stream may lag the detect stream)
 constexpr float kResidualCarry = -1.0f;  // marker: "|fi| carried in from an earlier block" (see try_vel)
 
 // Device-resident per-map scalars.
@@ -125,8 +126,8 @@ void upload_tables(const float* recip128, const float* pinv75);
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
                         const int widths[2][3], int* rowcount_to_zero);
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
-                     const DetState* det_in, DetState* det_out, uint64_t frame_index);
-void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, DetState* det_cur);
+                     const DetState* det_in, DetState* det_out, const MapState* prev_st);
+void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev);
 void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out);
 
 void launch_rotate(hipStream_t s, const KParams& p, const MapDev& m, const float R[9], int* hist_or_null,
@@ -135,14 +136,21 @@ void launch_quantile(hipStream_t s, const KParams& p, const MapDev& m, int* hist
 void launch_try_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int mode_lm, int call,
                     int last, LmState* st_in, LmState* st_out, const float* part_prev, float* part_out, const int* hist,
                     int frame_count);
+// Host-visible result slot of one frame pair, written directly by k_ext_rot_vel (zero-copy, pinned memory).
+struct PairSlot {
+  LmState lm;          // final minimizeVel state
+  MapState new_st;     // snapshot of the new map's scalars
+  MapState old_st;     // snapshot of the old map's scalars (directedMatch / regularize counters of the previous pair)
+  float xrv[1];        // [nblocks][kXrvStride] block records follow
+};
 void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
-                        float* xrv_part, const float* vel_manual);
+                        float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero);
 void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm);
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
-                           const float Rvel[9], const float Rback[9], float max_radius);
-void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate);
+                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n);
+void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate, int* work_n_reset);
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp,
                       int min_matches_gate);
 void launch_map_pack(hipStream_t s, const KParams& p, const MapDev& m, rebvio_hip_keyline* aos_dev);

@@ -50,13 +50,79 @@ __device__ __forceinline__ float box_avg(const float* __restrict__ II, int r, in
   return acc * div;
 }
 
+// Straight-line form of box_avg for border pixels: four unconditional (clamped) taps, absent terms replaced by
+// +0 (x - 0 and x + 0 are exact and no -0 can arise from the differences), the operand order of the bottom rows
+// selected by swapping B and C. Same bits as box_avg, no control flow, so the taps of several pixels overlap.
+__device__ __forceinline__ float box_avg_flat(const float* __restrict__ II, int r, int c, int d, int R, int C) {
+  const int d2 = d >> 1;
+  const bool top = r < d2 + 1, bot = r >= R - d2;
+  const bool left = c < d2 + 1, right = c >= C - d2;
+  const int r1 = (bot && !top) ? R - 1 : r + d2;
+  const int c1 = (right && !left) ? C - 1 : c + d2;
+  const int r2 = max(r - d2 - 1, 0), c2 = max(c - d2 - 1, 0);
+  const int ny = top ? r + d2 + 1 : (bot ? R - r + d2 : d);
+  const int nx = left ? c + d2 + 1 : (right ? C - c + d2 : d);
+  const float div = c_recip[nx * ny];
+  const float A = II[(size_t)r1 * C + c1];
+  const float Bv = II[(size_t)r1 * C + c2];
+  const float Cv = II[(size_t)r2 * C + c1];
+  const float Dv = II[(size_t)r2 * C + c2];
+  const float B = left ? 0.0f : Bv;
+  const float Cc = top ? 0.0f : Cv;
+  const float D = (left || top) ? 0.0f : Dv;
+  const float X = (bot && !top) ? Cc : B;
+  const float Y = (bot && !top) ? B : Cc;
+  return (((A - X) - Y) + D) * div;
+}
+
 // ---- row prefix (scale_space.cpp:50-57) ---------------------------------------------------------------
 // One workgroup stages a strip of kStrip rows in LDS with coalesced 16-byte accesses (for passes 2 and 3
 // the box average of the previous integral image is evaluated on the fly), then one lane per row walks
 // its row left to right: a sequential fp32 chain, which is what keeps the result bit-identical to the
-// CPU. LDS row pitch = cols + pad with (pitch/4) odd: the 16 row-lanes' ds_read/write_b128 hit 16
-// distinct 4-bank groups.
-constexpr int kStrip = 16;
+// CPU. LDS row pitch = cols + pad with (pitch/4) odd: the row-lanes' ds_read/write_b128 hit distinct
+// 4-bank groups. Measured (in-kernel stamps): the chain costs ~20 cycles per element on its lone wave
+// (LDS b128 issue, not the 4.8-cycle dependent add), the staging phase is bound by per-CU load bandwidth,
+// hence short strips on many CUs.
+constexpr int kStrip = 4;   // rows per workgroup: 120 workgroups per 480-row image spread the tap traffic over the CUs
+
+// Interior fast path of box_avg for four consecutive columns: rows r1 = r+d2 and r2 = r-d2-1 are read as two
+// 4-float windows each (dword-aligned 16-byte loads) instead of 16 scalar taps. Same operand order as box_avg.
+__device__ __forceinline__ float4 box_avg4_interior(const float* __restrict__ II, int r, int c, int d, int C) {
+  const int d2 = d >> 1;
+  const float* p1 = II + (size_t)(r + d2) * C + c;
+  const float* p2 = II + (size_t)(r - d2 - 1) * C + c;
+  const float4 A = *reinterpret_cast<const float4*>(p1 + d2);
+  const float4 B = *reinterpret_cast<const float4*>(p1 - d2 - 1);
+  const float4 Cc = *reinterpret_cast<const float4*>(p2 + d2);
+  const float4 D = *reinterpret_cast<const float4*>(p2 - d2 - 1);
+  const float a = c_recip[d * d];
+  float4 o;
+  o.x = (((A.x - B.x) - Cc.x) + D.x) * a;
+  o.y = (((A.y - B.y) - Cc.y) + D.y) * a;
+  o.z = (((A.z - B.z) - Cc.z) + D.z) * a;
+  o.w = (((A.w - B.w) - Cc.w) + D.w) * a;
+  return o;
+}
+
+template <int MODE>
+__device__ __forceinline__ float4 rowscan_fetch(const void* __restrict__ src, int r, int c4, int d, int d2, int R, int C) {
+  const int C4 = C >> 2, c = c4 * 4;
+  if (MODE == 0) {
+    const uchar4 u = reinterpret_cast<const uchar4*>(src)[(size_t)r * C4 + c4];
+    return make_float4((float)u.x * 3.0f, (float)u.y * 3.0f, (float)u.z * 3.0f, (float)u.w * 3.0f);
+  } else if (MODE == 1) {
+    return reinterpret_cast<const float4*>(src)[(size_t)r * C4 + c4];
+  } else {
+    const float* II = reinterpret_cast<const float*>(src);
+    if (r > d2 && r < R - d2 && c > d2 && c + 3 < C - d2) return box_avg4_interior(II, r, c, d, C);
+    float4 v;
+    v.x = box_avg_flat(II, r, c, d, R, C);
+    v.y = box_avg_flat(II, r, c + 1, d, R, C);
+    v.z = box_avg_flat(II, r, c + 2, d, R, C);
+    v.w = box_avg_flat(II, r, c + 3, d, R, C);
+    return v;
+  }
+}
 
 template <int MODE>  // 0: u8 image * 3.0f, 1: fp32 image, 2: box average (width d) of an integral image
 __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, const void* __restrict__ src1,
@@ -68,30 +134,34 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
   const void* __restrict__ src = f ? src1 : src0;
   float* __restrict__ dst = f ? dst1 : dst0;
   const int d = f ? d1 : d0;
+  const int d2 = d >> 1;
   const int r0 = blockIdx.x * kStrip;
   const int nrows = min(kStrip, R - r0);
   const int C4 = C >> 2;
-  const int total = nrows * C4;
-  for (int i = threadIdx.x; i < total; i += 256) {
-    const int lr = i / C4, c4 = i - lr * C4;
-    const int r = r0 + lr, c = c4 * 4;
-    float4 v;
-    if (MODE == 0) {
-      const uchar4 u = reinterpret_cast<const uchar4*>(src)[(size_t)r * C4 + c4];
-      v = make_float4((float)u.x * 3.0f, (float)u.y * 3.0f, (float)u.z * 3.0f, (float)u.w * 3.0f);
-    } else if (MODE == 1) {
-      v = reinterpret_cast<const float4*>(src)[(size_t)r * C4 + c4];
-    } else {
-      const float* II = reinterpret_cast<const float*>(src);
-      v.x = box_avg(II, r, c, d, R, C);
-      v.y = box_avg(II, r, c + 1, d, R, C);
-      v.z = box_avg(II, r, c + 2, d, R, C);
-      v.w = box_avg(II, r, c + 3, d, R, C);
+  // thread -> (strip row, 16-byte chunk): one wave per row, 64 chunks (1 KiB) per pass; no divisions.
+  const int lr = (int)threadIdx.x >> 6;  // kStrip == 4 rows, 256 threads
+  const int cb = (int)threadIdx.x & 63;
+  const int r = min(r0 + lr, R - 1);
+  const bool rvalid = lr < nrows;
+  constexpr int kBatch = 3;  // 640 columns = 160 chunks = 2.5 passes
+  constexpr int kCPP = 64;   // chunks per pass
+  for (int base = 0; base < C4; base += kCPP * kBatch) {
+    // named registers, not an array (arrays of float4 end up in scratch with this compiler)
+    const float4 v0 = rowscan_fetch<MODE>(src, r, min(base + 0 * kCPP + cb, C4 - 1), d, d2, R, C);
+    const float4 v1 = rowscan_fetch<MODE>(src, r, min(base + 1 * kCPP + cb, C4 - 1), d, d2, R, C);
+    const float4 v2 = rowscan_fetch<MODE>(src, r, min(base + 2 * kCPP + cb, C4 - 1), d, d2, R, C);
+    __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first LDS write
+#define RH_RS_ST(k, v)                                                                  \
+    {                                                                                   \
+      const int c4 = base + (k) * kCPP + cb;                                            \
+      if (c4 < C4 && rvalid) *reinterpret_cast<float4*>(&tile[lr * ldw + c4 * 4]) = v;  \
     }
-    *reinterpret_cast<float4*>(&tile[lr * ldw + c]) = v;
+    RH_RS_ST(0, v0) RH_RS_ST(1, v1) RH_RS_ST(2, v2)
+#undef RH_RS_ST
   }
   __syncthreads();
   if ((int)threadIdx.x < nrows) {
+    // sequential chain over the row; LDS reads run four float4 ahead of the adds (two register groups)
     float* rowp = tile + threadIdx.x * ldw;
     float4 v = *reinterpret_cast<float4*>(rowp);
     v.y = v.x + v.y;
@@ -99,8 +169,39 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
     v.w = v.z + v.w;
     *reinterpret_cast<float4*>(rowp) = v;
     float s = v.w;
-#pragma unroll 4
-    for (int c = 4; c < C; c += 4) {
+    constexpr int G = 4;
+    float4 a[G], bq[G];
+    int c = 4;
+    const int lastc = C - 4;
+#pragma unroll
+    for (int k = 0; k < G; ++k) a[k] = *reinterpret_cast<float4*>(rowp + min(c + 4 * k, lastc));
+    for (; c + 8 * G <= C; c += 8 * G) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) bq[k] = *reinterpret_cast<float4*>(rowp + c + 4 * G + 4 * k);
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        float4 w = a[k];
+        w.x = s + w.x;
+        w.y = w.x + w.y;
+        w.z = w.y + w.z;
+        w.w = w.z + w.w;
+        s = w.w;
+        *reinterpret_cast<float4*>(rowp + c + 4 * k) = w;
+      }
+#pragma unroll
+      for (int k = 0; k < G; ++k) a[k] = *reinterpret_cast<float4*>(rowp + min(c + 8 * G + 4 * k, lastc));
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        float4 w = bq[k];
+        w.x = s + w.x;
+        w.y = w.x + w.y;
+        w.z = w.y + w.z;
+        w.w = w.z + w.w;
+        s = w.w;
+        *reinterpret_cast<float4*>(rowp + c + 4 * G + 4 * k) = w;
+      }
+    }
+    for (; c < C; c += 4) {
       float4 w = *reinterpret_cast<float4*>(rowp + c);
       w.x = s + w.x;
       w.y = w.x + w.y;
@@ -111,34 +212,125 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < total; i += 256) {
-    const int lr = i / C4, c4 = i - lr * C4;
-    reinterpret_cast<float4*>(dst)[(size_t)(r0 + lr) * C4 + c4] = *reinterpret_cast<float4*>(&tile[lr * ldw + c4 * 4]);
+  for (int base = 0; base < C4; base += kCPP * kBatch) {
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int c4 = base + k * kCPP + cb;
+      if (c4 < C4 && rvalid)
+        reinterpret_cast<float4*>(dst)[(size_t)(r0 + lr) * C4 + c4] = *reinterpret_cast<float4*>(&tile[lr * ldw + c4 * 4]);
+    }
   }
 }
 
-// ---- column accumulation (scale_space.cpp:59-65): one lane per column, coalesced rows, sequential chain
-__global__ __launch_bounds__(64) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C) {
+// ---- column accumulation (scale_space.cpp:59-65) --------------------------------------------------------------
+// The row pass transposed: a workgroup stages a strip of kColStrip columns x all rows in LDS, TRANSPOSED
+// (tile[col][row]), so that the lane that owns a column walks down it with ds_read/write_b128 (four rows per LDS
+// instruction; the chain is LDS-issue bound on its lone wave). Column pitch = rows + pad with (pitch/4) odd.
+// Narrow strips spread the staging traffic over many CUs. No global-memory latency sits on the chain.
+constexpr int kColStrip = 16;
+
+__global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
+  extern __shared__ float4 smem4[];
+  float* tile = reinterpret_cast<float*>(smem4);  // [kColStrip][ldh]
   float* __restrict__ buf = blockIdx.y ? buf1 : buf0;
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  float* p = buf + c;
-  float s = p[0];
-  int r = 1;
-  constexpr int U = 16;
-  for (; r + U <= R; r += U) {
-    float v[U];
+  const int c0 = blockIdx.x * kColStrip;
+  const int ncols = min(kColStrip, C - c0);  // multiple of 4 (cols % 4 == 0)
+  const int q = ncols >> 2;                  // float4 per row of the strip (<= 4)
+  // thread -> (row offset, 16-byte column chunk): 4 chunks per strip row, 64 rows per pass of the 256 threads
+  const int c4 = min((int)threadIdx.x & 3, q - 1);
+  const bool cvalid = ((int)threadIdx.x & 3) < q;
+  const int rb = (int)threadIdx.x >> 2;
+  const float* gsrc = buf + c0 + c4 * 4;
+  constexpr int kBatch = 4;
+  constexpr int kRowsPerPass = 64;
+  for (int base = 0; base < R; base += kRowsPerPass * kBatch) {
+    // named registers, not an array: hipcc sends even a 4-entry float4 staging array to scratch here
+#define RH_CS_LD(k) *reinterpret_cast<const float4*>(gsrc + (size_t)min(base + (k) * kRowsPerPass + rb, R - 1) * C)
+    const float4 v0 = RH_CS_LD(0), v1 = RH_CS_LD(1), v2 = RH_CS_LD(2), v3 = RH_CS_LD(3);
+#undef RH_CS_LD
+    __builtin_amdgcn_sched_barrier(0);  // keep every load of the batch in flight before the first LDS write
+#define RH_CS_ST(k, v)                                   \
+    {                                                    \
+      const int r = base + (k) * kRowsPerPass + rb;      \
+      if (r < R && cvalid) {                             \
+        float* t = tile + (c4 * 4) * ldh + r;            \
+        t[0] = v.x;                                      \
+        t[ldh] = v.y;                                    \
+        t[2 * ldh] = v.z;                                \
+        t[3 * ldh] = v.w;                                \
+      }                                                  \
+    }
+    RH_CS_ST(0, v0) RH_CS_ST(1, v1) RH_CS_ST(2, v2) RH_CS_ST(3, v3)
+#undef RH_CS_ST
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ncols) {
+    // sequential chain down the column; LDS reads run four float4 (16 rows) ahead of the adds
+    float* colp = tile + threadIdx.x * ldh;
+    float4 v = *reinterpret_cast<float4*>(colp);
+    v.y = v.x + v.y;
+    v.z = v.y + v.z;
+    v.w = v.z + v.w;
+    *reinterpret_cast<float4*>(colp) = v;
+    float s = v.w;
+    constexpr int G = 4;
+    float4 a[G], bq[G];
+    int r = 4;
+    const int R4 = R & ~3;
+    const int lastr = R4 - 4;
 #pragma unroll
-    for (int k = 0; k < U; ++k) v[k] = p[(size_t)(r + k) * C];
+    for (int k = 0; k < G; ++k) a[k] = *reinterpret_cast<float4*>(colp + min(r + 4 * k, lastr));
+    for (; r + 8 * G <= R4; r += 8 * G) {
 #pragma unroll
-    for (int k = 0; k < U; ++k) {
-      s = v[k] + s;
-      p[(size_t)(r + k) * C] = s;
+      for (int k = 0; k < G; ++k) bq[k] = *reinterpret_cast<float4*>(colp + r + 4 * G + 4 * k);
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        float4 w = a[k];
+        w.x = s + w.x;
+        w.y = w.x + w.y;
+        w.z = w.y + w.z;
+        w.w = w.z + w.w;
+        s = w.w;
+        *reinterpret_cast<float4*>(colp + r + 4 * k) = w;
+      }
+#pragma unroll
+      for (int k = 0; k < G; ++k) a[k] = *reinterpret_cast<float4*>(colp + min(r + 8 * G + 4 * k, lastr));
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        float4 w = bq[k];
+        w.x = s + w.x;
+        w.y = w.x + w.y;
+        w.z = w.y + w.z;
+        w.w = w.z + w.w;
+        s = w.w;
+        *reinterpret_cast<float4*>(colp + r + 4 * G + 4 * k) = w;
+      }
+    }
+    for (; r < R4; r += 4) {
+      float4 w = *reinterpret_cast<float4*>(colp + r);
+      w.x = s + w.x;
+      w.y = w.x + w.y;
+      w.z = w.y + w.z;
+      w.w = w.z + w.w;
+      s = w.w;
+      *reinterpret_cast<float4*>(colp + r) = w;
+    }
+    for (; r < R; ++r) {  // rows % 4 tail
+      s = s + colp[r];
+      colp[r] = s;
     }
   }
-  for (; r < R; ++r) {
-    s = p[(size_t)r * C] + s;
-    p[(size_t)r * C] = s;
+  __syncthreads();
+  float* gdst = buf + c0 + c4 * 4;
+  for (int base = 0; base < R; base += kRowsPerPass * kBatch) {
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int r = base + k * kRowsPerPass + rb;
+      if (r < R && cvalid) {
+        const float* t = tile + (c4 * 4) * ldh + r;
+        *reinterpret_cast<float4*>(gdst + (size_t)r * C) = make_float4(t[0], t[ldh], t[2 * ldh], t[3 * ldh]);
+      }
+    }
   }
 }
 
@@ -251,6 +443,16 @@ __device__ __forceinline__ int wave_sum(int v) {
   return v;
 }
 
+// tuneThreshold (edge_detector.cpp:167-186). With size() <= keylines_max the cumulative loop can never
+// reach keylines_max (bin 0 always holds the maximum), so it always ends at i = num_bins and the result
+// depends on min/max only; the histogram itself is dead code there.
+__device__ __forceinline__ float auto_threshold_from(const MapState& st, float previous) {
+  if (st.n <= 0) return previous;
+  const float max_dog = __uint_as_float(st.gmax_bits);
+  const float min_dog = __uint_as_float(st.gmin_bits);
+  return max_dog - float(kNumBins * (max_dog - min_dog)) / float(kNumBins);
+}
+
 // ---- ordered emission (edge_detector.cpp:109-119) -------------------------------------------------------
 // rank = (#candidates in earlier rows) + (#candidates in earlier segments of this row) + (#lower lanes):
 // the raster rank of the reference's sequential loop, with truncation at keylines_max. Also rewrites the
@@ -258,7 +460,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const float4* __restrict__ stash,
                                                       const unsigned long long* __restrict__ bits,
                                                       const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
-                                                      DetState* __restrict__ det_out) {
+                                                      DetState* __restrict__ det_out, const MapState* __restrict__ prev_st) {
   const int R = p.rows, C = p.cols;
   const int r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.x * 64 + threadIdx.x;
   const int lane = threadIdx.x;
@@ -282,7 +484,8 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
       m.st->reg_count = 0;
       det_out->threshold = servo_threshold(p, *det_in);
       det_out->count = n;
-      det_out->auto_threshold = det_in->auto_threshold;
+      // auto_threshold_ as left by the previous detect's tuneThreshold (its min/max are final: same stream)
+      det_out->auto_threshold = prev_st ? auto_threshold_from(*prev_st, det_in->auto_threshold) : det_in->auto_threshold;
     }
   }
   if (c >= C) return;
@@ -339,9 +542,10 @@ __global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m) {
     }
     int nxt = -1;
     if (x >= 1 && x < C - 1 && y >= 1 && y < p.rows - 1) {  // always true for detected keylines
-      nxt = m.mask[(size_t)y * C + x + dx1];
-      if (nxt < 0) nxt = m.mask[(size_t)(y + dy2) * C + x];
-      if (nxt < 0) nxt = m.mask[(size_t)(y + dy2) * C + x + dx1];
+      const int a = m.mask[(size_t)y * C + x + dx1];  // three independent loads, first hit in probe order wins
+      const int b = m.mask[(size_t)(y + dy2) * C + x];
+      const int c3 = m.mask[(size_t)(y + dy2) * C + x + dx1];
+      nxt = (a >= 0) ? a : ((b >= 0) ? b : c3);
     }
     if (nxt >= 0) {
       atomicMax(&m.id_prev[nxt], idx);  // sequential last-writer-wins == largest index
@@ -360,27 +564,13 @@ __global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m) {
   }
 }
 
-// tuneThreshold (edge_detector.cpp:167-186). With size() <= keylines_max the cumulative loop can never
-// reach keylines_max (bin 0 always holds the maximum), so it always ends at i = num_bins and the result
-// depends on min/max only; the histogram itself is dead code there.
-__device__ __forceinline__ float auto_threshold_from(const MapState& st, float previous) {
-  if (st.n <= 0) return previous;
-  const float max_dog = __uint_as_float(st.gmax_bits);
-  const float min_dog = __uint_as_float(st.gmin_bits);
-  return max_dog - float(kNumBins * (max_dog - min_dog)) / float(kNumBins);
-}
-
 // ---- DistanceField::build (core.hpp:37-59) ---------------------------------------------------------------
 // One thread per (keyline, r). Sequential semantics "smallest |r| wins, ties -> last (idx, r) visited" become
 // an order-independent atomicMin on key = |r| << 23 | (2^23-1 - (idx*nr + r+range)).
-__global__ __launch_bounds__(256) void k_df_build(KParams p, MapDev m, const DetState* __restrict__ det_prev,
-                                                  DetState* __restrict__ det_cur) {
+__global__ __launch_bounds__(256) void k_df_build(KParams p, MapDev m, const DetState* __restrict__ det_prev) {
   const int n = m.st->n;
   const float thr = auto_threshold_from(*m.st, det_prev->auto_threshold);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    m.st->threshold = thr;
-    det_cur->auto_threshold = thr;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int nr = p.df_nr;
   const int idx = gid / nr;
@@ -475,42 +665,45 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colscan), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const dim3 g1(div_up(R, kStrip), 1), g2(div_up(R, kStrip), 2);
-  const dim3 c1(div_up(C, 64), 1), c2(div_up(C, 64), 2);
+  const dim3 c1(div_up(C, kColStrip), 1), c2(div_up(C, kColStrip), 2);
+  const int ldh = lds_pitch(R + (4 - R % 4) % 4);
+  const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
   // pass 1: both filters share the integral image of the input (scale_space.cpp:175)
   if (img_is_u8)
     RH_LAUNCH(k_rowscan<0>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
   else
     RH_LAUNCH(k_rowscan<1>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
-  RH_LAUNCH(k_colscan, c1, dim3(64), 0, s, sb.a[0], sb.a[0], R, C);
+  RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, sb.a[0], sb.a[0], R, C, ldh);
   // pass 2: average(width[0]) fused into the row scan, per filter
   RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.a[0], (const void*)sb.a[0], sb.b[0], sb.b[1], R,
                      C, widths[0][0], widths[1][0], ldw);
-  RH_LAUNCH(k_colscan, c2, dim3(64), 0, s, sb.b[0], sb.b[1], R, C);
+  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.b[0], sb.b[1], R, C, ldh);
   // pass 3: filter f averages its own integral image
   RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R,
                      C, widths[0][1], widths[1][1], ldw);
-  RH_LAUNCH(k_colscan, c2, dim3(64), 0, s, sb.a[0], sb.a[1], R, C);
+  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.a[0], sb.a[1], R, C, ldh);
   const dim3 gt(div_up(C, 64), div_up(R, 4));
   RH_LAUNCH(k_dog_mag, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2],
                      widths[1][2], sb.dog, sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
 }
 
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
-                     const DetState* det_in, DetState* det_out, uint64_t) {
+                     const DetState* det_in, DetState* det_out, const MapState* prev_st) {
   const dim3 gt(div_up(p.cols, 64), div_up(p.rows, 4));
   RH_LAUNCH(k_keyline_flag, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in,
                      db.stash, db.bits, db.rowcount);
   RH_LAUNCH(k_keyline_emit, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash,
-                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out);
+                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st);
   RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m);
 }
 
-void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, DetState* det_cur) {
+void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev) {
   const long long threads = (long long)p.kmax * p.df_nr;
-  RH_LAUNCH(k_df_build, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, m, det_prev, det_cur);
+  RH_LAUNCH(k_df_build, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, m, det_prev);
 }
 
 void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out) {

@@ -46,8 +46,11 @@ __device__ __forceinline__ unsigned order_key(float f) {
 __global__ __launch_bounds__(256) void k_rotate(KParams p, MapDev m, Mat3 R, int* __restrict__ hist, int hist_bins,
                                                 int zero_dm) {
   __shared__ int sh[128];
-  const int n = m.st->n;
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  float2 pi = m.pos_img[idx];  // bound-free early loads
+  float2 rs = m.rs[idx];
+  const float2 g = m.grad[idx];
+  const int n = m.st->n;
   if (hist) {
     if (threadIdx.x < 128) sh[threadIdx.x] = 0;
     __syncthreads();
@@ -58,9 +61,6 @@ __global__ __launch_bounds__(256) void k_rotate(KParams p, MapDev m, Mat3 R, int
     m.st->reg_count = 0;
   }
   if (idx < n) {
-    float2 pi = m.pos_img[idx];
-    float2 rs = m.rs[idx];
-    const float2 g = m.grad[idx];
     const double v0 = (double)(pi.x / p.fm), v1 = (double)(pi.y / p.fm);
     float q[3];
 #pragma unroll
@@ -249,18 +249,27 @@ __device__ void lm_step(LmState& s, const float* red, int call, bool final_only)
 }
 
 // Shared prologue: fixed-order reduction of the previous tryVel call's block records + carry-in of the
-// "last written fi" (oracle header, H3) for this workgroup.
-__device__ void reduce_prev_records(const float* __restrict__ part_prev, int nblocks, float* red /*shared[16]*/,
-                                    float* carry_in /*shared*/) {
+// "last written fi" (oracle header, H3) for this workgroup. The records are staged in LDS by one coalesced
+// pass of the whole workgroup (one memory round trip), then summed in block order from LDS.
+constexpr int kMaxRecBlocks = 256;  // keylines_max <= 65536
+
+// Stages the records of ALL launched workgroups (grid size is known without reading the keyline count, so these
+// loads are in flight together with the first own-keyline loads); records beyond the live count are never summed.
+__device__ void stage_prev_records(const float* __restrict__ part_prev, int grid_blocks, float* rec /*LDS*/) {
+  const int total = min(grid_blocks, kMaxRecBlocks) * kPartStride;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) rec[i] = part_prev[i];
+}
+
+__device__ void reduce_staged_records(const float* rec, int nblocks, float* red /*shared[16]*/, float* carry_in) {
   if (threadIdx.x < 10) {
     float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += part_prev[b * kPartStride + threadIdx.x];
+    for (int b = 0; b < nblocks; ++b) acc += rec[b * kPartStride + threadIdx.x];
     red[threadIdx.x] = acc;
   } else if (threadIdx.x == 10) {
     float cv = 0.f;
     for (int b = (int)blockIdx.x - 1; b >= 0; --b)
-      if (part_prev[b * kPartStride + 10] != 0.f) {
-        cv = part_prev[b * kPartStride + 11];
+      if (rec[b * kPartStride + 10] != 0.f) {
+        cv = rec[b * kPartStride + 11];
         break;
       }
     *carry_in = fabsf(cv);
@@ -282,17 +291,34 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
   __shared__ float wsum[4][10];
   __shared__ float wlast[4];
   __shared__ int whas[4];
+  __shared__ float rec[kMaxRecBlocks * kPartStride];
+  __shared__ int shist[128];
 
+  // Own-keyline loads are issued before anything else (arrays are padded to the grid, so no bound is needed):
+  // their latency overlaps the prologue instead of following it.
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float gn = om.gnorm[idx];
+  const float2 rs = om.rs[idx];
+  const float2 pi = om.pos_img[idx];
+  const float2 g2 = om.grad[idx];
+  const unsigned nmatches = om.matches[idx];
+  const float res_in = om.residual[idx];
+  if (mode_lm && call >= 1) stage_prev_records(part_prev, gridDim.x, rec);
   const int n = om.st->n;
+  const float thr = om.st->threshold;
   const int nblocks = (n + 255) / 256;
-  if (threadIdx.x == 0) carry_in = 0.f;
-  if (mode_lm && call >= 1) reduce_prev_records(part_prev, nblocks, red, &carry_in);
+  if (mode_lm && call == 0 && threadIdx.x < 128) shist[threadIdx.x] = (threadIdx.x < (unsigned)p.quantile_num_bins) ? hist[threadIdx.x] : 0;
+  if (threadIdx.x == 0) {
+    carry_in = 0.f;
+    s = *st_in;
+  }
+  __syncthreads();
+  if (mode_lm && call >= 1) reduce_staged_records(rec, nblocks, red, &carry_in);
   __syncthreads();
   if (threadIdx.x == 0) {
-    s = *st_in;
     if (mode_lm) {
       if (call == 0) {
-        s.sigma_rho_min = quantile_from_hist(hist, p.quantile_num_bins, p.quantile_cutoff, n);
+        s.sigma_rho_min = quantile_from_hist(shist, p.quantile_num_bins, p.quantile_cutoff, n);
         for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
       } else {
         lm_step(s, red, call, false);
@@ -307,25 +333,20 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
   const float srm = s.sigma_rho_min;
   const float cin = carry_in;
   const unsigned min_matches = min(p.min_match_threshold, frame_count);
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 
   float f = 0.f, jx = 0.f, jy = 0.f, jz = 0.f, fi = 0.f;
   bool contrib = false, matched = false, need_carry = false;
   if (idx < n) {
     int mfwd = -1;
-    const float gn = om.gnorm[idx];
-    const float thr = om.st->threshold;
-    const float2 rs = om.rs[idx];
-    const bool skip = (thr > 0.0f && gn < thr) || (rs.y > srm) || (om.matches[idx] < min_matches);
+    const bool skip = (thr > 0.0f && gn < thr) || (rs.y > srm) || (nmatches < min_matches);
     if (!skip) {
-      float res = om.residual[idx];
+      float res = res_in;
       if (res == kResidualCarry) res = cin;
       float res_out = res;
       float weight = 1.0f;
       if (res > p.reweight_distance) weight = p.reweight_distance / res;
       const float z_p = (float)(1.0 / (double)rs.x + (double)vz);
-      const float2 pi = om.pos_img[idx];
       bool penalty1 = false;
       float rho_p = 0.f, p_x = 0.f, p_y = 0.f, p_xc = 0.f, p_yc = 0.f;
       int x = 0, y = 0;
@@ -349,13 +370,12 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
         const unsigned key = nm.df[(size_t)y * p.cols + x];
         if (key != kDfEmpty) {
           const int id = (int)((kDfSeqMask - (key & kDfSeqMask)) / (unsigned)p.df_nr);
-          const float2 g2 = om.grad[idx];
           const float2 g1 = nm.grad[id];
+          const float2 pn = nm.pos[id];   // issued with g1: one gather round trip
+          const float gnn = nm.gnorm[id];
           const float norm_squared = gn * gn;
           const float dot_product = g1.x * g2.x + g1.y * g2.y;
           if (!(fabsf(dot_product - norm_squared) > p.match_treshold * norm_squared)) {
-            const float2 pn = nm.pos[id];
-            const float gnn = nm.gnorm[id];
             const float dx = p_xc - pn.x;
             const float dy = p_yc - pn.y;
             const float gnx = g1.x / gnn;
@@ -444,7 +464,11 @@ __global__ __launch_bounds__(64) void k_lm_final(MapDev om, int calls, const LmS
                                                  LmState* __restrict__ st_out, const float* __restrict__ part_prev) {
   __shared__ float red[16];
   __shared__ float carry_in;
-  reduce_prev_records(part_prev, (om.st->n + 255) / 256, red, &carry_in);
+  __shared__ float rec[kMaxRecBlocks * kPartStride];
+  stage_prev_records(part_prev, kMaxRecBlocks, rec);
+  const int nb = (om.st->n + 255) / 256;
+  __syncthreads();
+  reduce_staged_records(rec, nb, red, &carry_in);
   __syncthreads();
   if (threadIdx.x == 0) {
     LmState s = *st_in;
@@ -471,38 +495,55 @@ __global__ __launch_bounds__(256) void k_forward_keys(MapDev om, MapDev nm) {
 __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDev nm, int do_forward, int do_lm_final,
                                                      int calls, const LmState* __restrict__ st_in,
                                                      LmState* __restrict__ st_out, const float* __restrict__ part_prev,
-                                                     float* __restrict__ xrv_part, Vec3 vel_manual) {
+                                                     float* __restrict__ xrv_part, Vec3 vel_manual,
+                                                     PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero) {
   __shared__ LmState s;
   __shared__ float red[16];
   __shared__ float carry_in;
   __shared__ float wsum[4][28];
+  __shared__ float rec[kMaxRecBlocks * kPartStride];
+  // early, bound-free loads of this thread's own keyline (arrays are padded to the grid)
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long key = nm.fwd_key[idx];
+  int mid = nm.match_id[idx];
+  float2 rs = nm.rs[idx];
+  float2 mpi = nm.mpos_img[idx];
+  const float2 g = nm.grad[idx];
+  const float gn = nm.gnorm[idx];
+  const float2 q = nm.pos_img[idx];
   const int n = nm.st->n;
   if (do_lm_final) {
+    stage_prev_records(part_prev, gridDim.x, rec);
     const int nb_old = (om.st->n + 255) / 256;
-    reduce_prev_records(part_prev, nb_old, red, &carry_in);
+    if (threadIdx.x == 0) s = *st_in;
+    __syncthreads();
+    reduce_staged_records(rec, nb_old, red, &carry_in);
     __syncthreads();
     if (threadIdx.x == 0) {
-      s = *st_in;
       lm_step(s, red, calls, true);
-      if (blockIdx.x == 0) *st_out = s;
+      if (blockIdx.x == 0) {
+        *st_out = s;
+        if (slot) {  // zero-copy: the host reads these after the pair's event
+          slot->lm = s;
+          slot->new_st = *nm.st;
+          slot->old_st = *om.st;
+        }
+      }
     }
     __syncthreads();
   }
+  // every tryVel call of this pair has consumed the sigma_rho histogram: clear it for the next pair
+  if (hist_to_zero && blockIdx.x == 0 && threadIdx.x < 128) hist_to_zero[threadIdx.x] = 0;
   const float vx = do_lm_final ? s.vel[0] : vel_manual.a[0];
   const float vy = do_lm_final ? s.vel[1] : vel_manual.a[1];
   const float vz = do_lm_final ? s.vel[2] : vel_manual.a[2];
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 
   float row[6] = {0, 0, 0, 0, 0, 0};
   float Y = 0.f;
   int cnt = 0;
   if (idx < n) {
-    int mid = nm.match_id[idx];
-    float2 rs = nm.rs[idx];
-    float2 mpi = nm.mpos_img[idx];
     if (do_forward) {
-      const unsigned long long key = nm.fwd_key[idx];
       if (key != 0ull) {
         const int o = (int)(unsigned)(key & 0xFFFFFFFFull);
         rs = om.rs[o];
@@ -518,9 +559,6 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
       }
     }
     if (mid >= 0) {
-      const float2 g = nm.grad[idx];
-      const float gn = nm.gnorm[idx];
-      const float2 q = nm.pos_img[idx];
       const float u_x = g.x / gn;
       const float u_y = g.y / gn;
       const float rho_t = (float)(1.0 / (1.0 / (double)rs.x + (double)vz));
@@ -571,120 +609,174 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
 }
 
 // ---- EdgeMap::directedMatch / searchMatch (edge_map.cpp:101-218) ----------------------------------------------
-// One thread per keyline of the NEW map; probes the OLD map's dense mask along the epipolar line, first hit in
-// the reference's alternating order wins. vel / Rvel are already rotated by Rback on the host (:193-194).
+// Probe geometry of one query keyline (edge_map.cpp:104-147): everything up to the probe loop.
+struct SearchSetup {
+  float t_x, t_y, norm_t, pi0x, pi0y, sigma2_t, dq_min, dq_max, dq_rho;
+  int t_steps;
+};
+
+__device__ __forceinline__ SearchSetup search_setup(const KParams& p, float2 pi, float2 rsq, float2 gq, float gnq,
+                                                    const Vec3& vel, const Mat3& Rvel, const Mat3& Rback, float max_radius) {
+  SearchSetup S;
+  float p_m3[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float s = 0.f;
+    s += Rback.a[i * 3 + 0] * pi.x;
+    s += Rback.a[i * 3 + 1] * pi.y;
+    s += Rback.a[i * 3 + 2] * p.fm;
+    p_m3[i] = s;
+  }
+  const float pmx = p_m3[0] * p.fm / p_m3[2];
+  const float pmy = p_m3[1] * p.fm / p_m3[2];
+  const float k_rho = rsq.x * p.fm / p_m3[2];
+  S.pi0x = pmx + p.cx;
+  S.pi0y = pmy + p.cy;
+  float t_x = -(vel.a[0] * p.fm - vel.a[2] * pmx);
+  float t_y = -(vel.a[1] * p.fm - vel.a[2] * pmy);
+  float norm_t = sqrtf(t_x * t_x + t_y * t_y);
+  const float DrDv[3] = {p.fm, p.fm, -(pmx + pmy)};
+  float rowv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float s = 0.f;
+    s += DrDv[0] * Rvel.a[0 * 3 + j];
+    s += DrDv[1] * Rvel.a[1 * 3 + j];
+    s += DrDv[2] * Rvel.a[2 * 3 + j];
+    rowv[j] = s;
+  }
+  float sigma2_t = 0.f;
+  sigma2_t += rowv[0] * DrDv[0];
+  sigma2_t += rowv[1] * DrDv[1];
+  sigma2_t += rowv[2] * DrDv[2];
+  S.sigma2_t = sigma2_t;
+  // std::max / std::min on NaN operands keep the first argument when the comparison is false; fmaxf/fminf return the
+  // non-NaN one. The operands here are finite whenever rho/sigma are, which the depth filter guarantees (core.cpp:451-455).
+  if ((double)norm_t > 1e-6) {
+    t_x /= norm_t;
+    t_y /= norm_t;
+    S.dq_rho = norm_t * k_rho;
+    S.dq_min = fmaxf(0.0f, norm_t * (k_rho - rsq.y)) - p.pixel_uncertainty_match;
+    S.dq_max = fminf(max_radius, norm_t * (k_rho + rsq.y)) + p.pixel_uncertainty_match;
+    if (S.dq_rho > S.dq_max) {
+      S.dq_rho = (float)(0.5 * (double)(S.dq_max + S.dq_min));
+      S.t_steps = cvtt_f64((double)S.dq_rho + 0.5);
+    } else {
+      S.t_steps = cvtt_f32(fmaxf(S.dq_max - S.dq_rho, S.dq_rho - S.dq_min));
+    }
+  } else {
+    t_x = gq.x;
+    t_y = gq.y;
+    norm_t = gnq;
+    t_x /= norm_t;
+    t_y /= norm_t;
+    norm_t = 1.0f;
+    S.dq_min = -max_radius - p.pixel_uncertainty_match;
+    S.dq_max = max_radius + p.pixel_uncertainty_match;
+    S.dq_rho = 0.0f;
+    S.t_steps = cvtt_f32(S.dq_max);
+  }
+  S.t_x = t_x;
+  S.t_y = t_y;
+  S.norm_t = norm_t;
+  return S;
+}
+
+// Acceptance test of one candidate (edge_map.cpp:170-177)
+__device__ __forceinline__ bool search_accept(const KParams& p, const SearchSetup& S, float t, float2 cg, float cgn, float2 crs,
+                                              float2 gq, float gnq) {
+  const float cang = (cg.x * gq.x + cg.y * gq.y) / (cgn * gnq);
+  if (cang < p.cang_min_edge || fabs((double)(cgn / gnq) - 1.0) > (double)p.match_threshold_norm) return false;
+  const float v_rho_dr = (p.pixel_uncertainty_match * p.pixel_uncertainty_match + crs.y * crs.y * S.norm_t * S.norm_t +
+                          S.sigma2_t * crs.x * crs.x);
+  if ((t - S.norm_t * crs.x) * (t - S.norm_t * crs.x) > v_rho_dr) return false;
+  return true;
+}
+
+__device__ __forceinline__ void search_commit(MapDev& nm, const MapDev& om, int idx, int found, int* kf) {
+  nm.rs[idx] = om.rs[found];
+  nm.match_id[idx] = found;
+  nm.matches[idx] = om.matches[found] + 1u;
+  nm.mpos_img[idx] = om.pos_img[found];
+  nm.mgrad[idx] = om.grad[found];
+  nm.mgnorm[idx] = om.gnorm[found];
+  const int k = om.match_kf[found];
+  nm.match_kf[idx] = k;
+  *kf = (k >= 0) ? 1 : 0;
+}
+
+constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-keyline pass
+
+// Pass 1: one thread per keyline of the NEW map, the first kHeadSteps steps of the reference's alternating probe
+// order (edge_map.cpp:149-181). Their mask lookups are independent loads, the candidate keylines of all hits are
+// fetched together, acceptance runs in the reference's order. Keylines whose search is longer and still open are
+// queued for pass 2 (a wave with one such lane would otherwise idle 63 lanes for up to 40 more dependent steps).
+// vel / Rvel are already rotated by Rback on the host (:193-194).
 __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel, Mat3 Rvel, Mat3 Rback,
-                                                        float max_radius) {
-  const int n = nm.st->n;
+                                                        float max_radius, int* __restrict__ work, int* __restrict__ work_n) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid)
+  const float2 rsq = nm.rs[idx];
+  const float2 gq = nm.grad[idx];
+  const float gnq = nm.gnorm[idx];
+  const int n = nm.st->n;
   int found = -1;
   int kf = 0;
+  bool more = false;
   if (idx < n) {
-    const float2 pi = nm.pos_img[idx];
-    const float2 rsq = nm.rs[idx];
-    const float2 gq = nm.grad[idx];
-    const float gnq = nm.gnorm[idx];
-    float p_m3[3];
+    const SearchSetup S = search_setup(p, pi, rsq, gq, gnq, vel, Rvel, Rback, max_radius);
+    float tn = S.dq_rho;
+    float tp = S.dq_rho + 1.0f;
+    float tq[2 * kHeadSteps];
+    int pix[2 * kHeadSteps];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float s = 0.f;
-      s += Rback.a[i * 3 + 0] * pi.x;
-      s += Rback.a[i * 3 + 1] * pi.y;
-      s += Rback.a[i * 3 + 2] * p.fm;
-      p_m3[i] = s;
-    }
-    const float pmx = p_m3[0] * p.fm / p_m3[2];
-    const float pmy = p_m3[1] * p.fm / p_m3[2];
-    const float k_rho = rsq.x * p.fm / p_m3[2];
-    const float pi0x = pmx + p.cx;
-    const float pi0y = pmy + p.cy;
-    float t_x = -(vel.a[0] * p.fm - vel.a[2] * pmx);
-    float t_y = -(vel.a[1] * p.fm - vel.a[2] * pmy);
-    float norm_t = sqrtf(t_x * t_x + t_y * t_y);
-    const float DrDv[3] = {p.fm, p.fm, -(pmx + pmy)};
-    float rowv[3];
+    for (int j = 0; j < kHeadSteps; ++j) {
+      const bool active = j < S.t_steps;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float s = 0.f;
-      s += DrDv[0] * Rvel.a[0 * 3 + j];
-      s += DrDv[1] * Rvel.a[1 * 3 + j];
-      s += DrDv[2] * Rvel.a[2 * 3 + j];
-      rowv[j] = s;
-    }
-    float sigma2_t = 0.f;
-    sigma2_t += rowv[0] * DrDv[0];
-    sigma2_t += rowv[1] * DrDv[1];
-    sigma2_t += rowv[2] * DrDv[2];
-
-    float dq_min = 0.f, dq_max = 0.f, dq_rho = 0.f;
-    int t_steps = 0;
-    if ((double)norm_t > 1e-6) {
-      t_x /= norm_t;
-      t_y /= norm_t;
-      dq_rho = norm_t * k_rho;
-      dq_min = fmaxf(0.0f, norm_t * (k_rho - rsq.y)) - p.pixel_uncertainty_match;
-      dq_max = fminf(max_radius, norm_t * (k_rho + rsq.y)) + p.pixel_uncertainty_match;
-      if (dq_rho > dq_max) {
-        dq_rho = (float)(0.5 * (double)(dq_max + dq_min));
-        t_steps = cvtt_f64((double)dq_rho + 0.5);
-      } else {
-        t_steps = cvtt_f32(fmaxf(dq_max - dq_rho, dq_rho - dq_min));
-      }
-    } else {
-      t_x = gq.x;
-      t_y = gq.y;
-      norm_t = gnq;
-      t_x /= norm_t;
-      t_y /= norm_t;
-      norm_t = 1.0f;
-      dq_min = -max_radius - p.pixel_uncertainty_match;
-      dq_max = max_radius + p.pixel_uncertainty_match;
-      dq_rho = 0.0f;
-      t_steps = cvtt_f32(dq_max);
-    }
-    // std::max / std::min on NaN operands keep the first argument when the comparison is false; fmaxf/fminf
-    // return the non-NaN one. The operands here are finite whenever rho/sigma are, which the depth filter
-    // guarantees (core.cpp:451-455).
-    float tn = dq_rho;
-    float tp = dq_rho + 1.0f;
-    for (int t_i = 0; t_i < t_steps && found < 0; ++t_i, tp += 1.0f, tn -= 1.0f) {
       for (int i_idx = 0; i_idx < 2; ++i_idx) {
-        float t;
-        if (i_idx) {
-          t = tp;
-          if (t > dq_max) continue;
-        } else {
-          t = tn;
-          if (t < dq_min) continue;
+        const float t = i_idx ? tp : tn;
+        const bool ok = active && (i_idx ? !(t > S.dq_max) : !(t < S.dq_min));
+        int px = -1;
+        if (ok) {
+          const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
+          const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
+          if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) px = row * p.cols + col;
         }
-        const int row = cvtt_f32(roundf(t_y * t + pi0y));
-        const int col = cvtt_f32(roundf(t_x * t + pi0x));
-        if ((unsigned)row >= (unsigned)p.rows || (unsigned)col >= (unsigned)p.cols) continue;
-        const int cand = om.mask[(size_t)row * p.cols + col];
-        if (cand < 0) continue;
-        const float2 g = om.grad[cand];
-        const float gnc = om.gnorm[cand];
-        const float cang = (g.x * gq.x + g.y * gq.y) / (gnc * gnq);
-        if (cang < p.cang_min_edge || fabs((double)(gnc / gnq) - 1.0) > (double)p.match_threshold_norm) continue;
-        const float2 rsc = om.rs[cand];
-        const float v_rho_dr = (p.pixel_uncertainty_match * p.pixel_uncertainty_match + rsc.y * rsc.y * norm_t * norm_t +
-                                sigma2_t * rsc.x * rsc.x);
-        if ((t - norm_t * rsc.x) * (t - norm_t * rsc.x) > v_rho_dr) continue;
-        found = cand;
-        break;
+        tq[j * 2 + i_idx] = t;
+        pix[j * 2 + i_idx] = px;
+      }
+      tp += 1.0f;
+      tn -= 1.0f;
+    }
+    int cand[2 * kHeadSteps];
+#pragma unroll
+    for (int k = 0; k < 2 * kHeadSteps; ++k) cand[k] = (pix[k] >= 0) ? om.mask[pix[k]] : -1;
+    float2 cg[2 * kHeadSteps], crs[2 * kHeadSteps];
+    float cgn[2 * kHeadSteps];
+#pragma unroll
+    for (int k = 0; k < 2 * kHeadSteps; ++k) {
+      if (cand[k] >= 0) {
+        cg[k] = om.grad[cand[k]];
+        cgn[k] = om.gnorm[cand[k]];
+        crs[k] = om.rs[cand[k]];
       }
     }
-    if (found >= 0) {
-      nm.rs[idx] = om.rs[found];
-      nm.match_id[idx] = found;
-      nm.matches[idx] = om.matches[found] + 1u;
-      nm.mpos_img[idx] = om.pos_img[found];
-      nm.mgrad[idx] = om.grad[found];
-      nm.mgnorm[idx] = om.gnorm[found];
-      const int k = om.match_kf[found];
-      nm.match_kf[idx] = k;
-      kf = (k >= 0) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 2 * kHeadSteps; ++k) {
+      if (found >= 0 || cand[k] < 0) continue;
+      if (search_accept(p, S, tq[k], cg[k], cgn[k], crs[k], gq, gnq)) found = cand[k];
     }
+    if (found >= 0) search_commit(nm, om, idx, found, &kf);
+    more = (found < 0) && (S.t_steps > kHeadSteps);
+  }
+  // queue the open long searches (order in the queue is irrelevant: each entry only touches its own keyline)
+  const unsigned long long mm = __ballot(more);
+  if (mm) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(work_n, __popcll(mm));
+    base = __shfl(base, 0);
+    if (more) work[base + __popcll(mm & ((1ull << lane) - 1ull))] = idx;
   }
   const int c1 = wave_sum_i(found >= 0 ? 1 : 0);
   const int c2 = wave_sum_i(kf);
@@ -694,16 +786,67 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
   }
 }
 
+// Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
+// sequence; the first accepted slot in that order (lowest slot index) is the match, found with a ballot.
+// tn/tp are produced by the same repeated -1.0f / +1.0f steps as the sequential loop (not dq_rho -/+ k).
+__global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev nm, MapDev om, Vec3 vel, Mat3 Rvel, Mat3 Rback,
+                                                             float max_radius, const int* __restrict__ work,
+                                                             const int* __restrict__ work_n) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int total = *work_n;
+  int nfound = 0, nkf = 0;
+  for (int w = wave; w < total; w += (gridDim.x * 256) >> 6) {
+    const int idx = work[w];
+    const float2 gq = nm.grad[idx];
+    const float gnq = nm.gnorm[idx];
+    const SearchSetup S = search_setup(p, nm.pos_img[idx], nm.rs[idx], gq, gnq, vel, Rvel, Rback, max_radius);
+    int found = -1;
+    for (int slot0 = 2 * kHeadSteps; slot0 < 2 * S.t_steps && found < 0; slot0 += 64) {
+      const int slot = slot0 + lane;
+      const int step = slot >> 1, i_idx = slot & 1;
+      float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
+      for (int j = 0; j < step; ++j) {
+        tp += 1.0f;
+        tn -= 1.0f;
+      }
+      const float t = i_idx ? tp : tn;
+      bool ok = (step < S.t_steps) && (i_idx ? !(t > S.dq_max) : !(t < S.dq_min));
+      int cand = -1;
+      if (ok) {
+        const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
+        const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
+        if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) cand = om.mask[(size_t)row * p.cols + col];
+      }
+      bool acc = false;
+      if (cand >= 0) acc = search_accept(p, S, t, om.grad[cand], om.gnorm[cand], om.rs[cand], gq, gnq);
+      const unsigned long long am = __ballot(acc);
+      if (am) found = __shfl(cand, __ffsll((long long)am) - 1);
+    }
+    if (found >= 0 && lane == 0) {
+      int kf = 0;
+      search_commit(nm, om, idx, found, &kf);
+      nfound += 1;
+      nkf += kf;
+    }
+  }
+  if (lane == 0) {
+    if (nfound) atomicAdd(&nm.st->dm_matches, nfound);
+    if (nkf) atomicAdd(&nm.st->dm_kf, nkf);
+  }
+}
+
 // ---- EdgeMap::regularize1Iter (edge_map.cpp:220-259): Jacobi step, results staged in rs_tmp ----------------------
-__global__ __launch_bounds__(256) void k_regularize(KParams p, MapDev m, int gate_min_matches) {
+__global__ __launch_bounds__(256) void k_regularize(KParams p, MapDev m, int gate_min_matches, int* __restrict__ work_n_reset) {
+  if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;  // directedMatch queue of this pair is consumed
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float2 rs = m.rs[idx];  // bound-free early loads
+  const int in = m.id_next[idx], ip = m.id_prev[idx];
   const int n = m.st->n;
   if (gate_min_matches > 0 && m.st->dm_matches < gate_min_matches) return;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   int set = 0;
   if (idx < n) {
-    const float2 rs = m.rs[idx];
     float2 out = rs;
-    const int in = m.id_next[idx], ip = m.id_prev[idx];
     if (in >= 0 && ip >= 0) {
       const float2 rn = m.rs[in], rp = m.rs[ip];
       if (!((rn.x - rp.x) * (rn.x - rp.x) > (rn.y * rn.y + rp.y * rp.y))) {
@@ -729,16 +872,17 @@ __global__ __launch_bounds__(256) void k_regularize(KParams p, MapDev m, int gat
 
 // ---- Core::updateInverseDepth[ARLU] (core.cpp:417-456): scalar EKF per matched keyline ----------------------------
 __global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel, int use_tmp, int gate_min_matches) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  float2 rs = use_tmp ? m.rs_tmp[idx] : m.rs[idx];  // bound-free early loads
+  const int mid = m.match_id[idx];
+  const float2 q = m.pos_img[idx];
+  const float2 q0 = m.mpos_img[idx];
+  const float2 mg = m.mgrad[idx];
+  const float mgn = m.mgnorm[idx];
   const int n = m.st->n;
   if (gate_min_matches > 0 && m.st->dm_matches < gate_min_matches) return;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
-  float2 rs = use_tmp ? m.rs_tmp[idx] : m.rs[idx];
-  if (m.match_id[idx] >= 0) {
-    const float2 q = m.pos_img[idx];
-    const float2 q0 = m.mpos_img[idx];
-    const float2 mg = m.mgrad[idx];
-    const float mgn = m.mgnorm[idx];
+  if (mid >= 0) {
     const float vx = vel.a[0], vy = vel.a[1], vz = vel.a[2];
     float v_rho = rs.y * rs.y;
     const float ux = mg.x / mgn;
@@ -808,19 +952,22 @@ void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, co
 
 void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
-                        float* xrv_part, const float* vel_manual) {
+                        float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero) {
   RH_LAUNCH(k_ext_rot_vel, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, oldm, newm, do_forward, do_lm_final,
-                     calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual));
+                     calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual), slot, hist_to_zero);
 }
 
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
-                           const float Rvel[9], const float Rback[9], float max_radius) {
+                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n) {
+  // *work_n is zero on entry (kept zero by k_dm_reset below)
   RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
-                     mat3(Rback), max_radius);
+                     mat3(Rback), max_radius, work, work_n);
+  RH_LAUNCH(k_directed_match_tail, dim3(256), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
+            (const int*)work, (const int*)work_n);
 }
 
-void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate) {
-  RH_LAUNCH(k_regularize, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, gate);
+void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate, int* work_n_reset) {
+  RH_LAUNCH(k_regularize, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, gate, work_n_reset);
 }
 
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp, int gate) {

@@ -1,0 +1,42 @@
+"""Multi-GPU sharding of the hot path: independent camera streams, one per rank/GPU, no data-path collective
+(each rebvio::Rebvio instance owns its detector, tracker and queues - reference rebvio.hpp:91-112).
+torch.distributed is used only for the bench's barrier and the max-over-ranks of the timed region."""
+from __future__ import annotations
+
+import os
+
+
+def env_ranks():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def stream_id_for_rank(rank: int) -> int:
+    """Rank r processes camera stream r (its own scene seed, frames, detector servo and tracker state)."""
+    return rank
+
+
+def init_group(backend: str, rank: int, world: int, device=None):
+    import torch.distributed as dist
+    if world <= 1:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = {}
+    if device is not None and backend == "nccl":
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def max_over_ranks(seconds: float, world: int, device="cpu") -> float:
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_fps(world: int, steps_per_rank: int, tmax: float) -> float:
+    """Every rank pushes `steps_per_rank` frames of its own stream: aggregate = all frames / slowest rank's time."""
+    return world * steps_per_rank / tmax
