@@ -1,0 +1,63 @@
+// rebvio::Core — the reference's "edge tracker" (core.hpp:82-205): distance field, translation LM (tryVel /
+// minimizeVel), 6-DoF linear step (extRotVel), per-keyline depth EKF; plus the O(1) inertial helpers that stay on
+// the host. Hot methods forward to the gfx950 backend through the C-ABI.
+#pragma once
+
+#include <memory>
+
+#include "rebvio/edge_map.hpp"
+
+namespace rebvio {
+
+struct CoreConfig {
+  types::Float search_range{40.0};
+  types::Float reweight_distance{2.0};
+  types::Float match_treshold{0.5};
+  unsigned int min_match_threshold{0};
+  unsigned int iterations{5};
+  unsigned int global_min_matches_threshold{500};
+  types::Float pixel_uncertainty{1};
+  types::Float quantile_cutoff{0.9};
+  int quantile_num_bins{100};
+  types::Float reshape_q_abs{1e-4};
+  using SharedPtr = std::shared_ptr<CoreConfig>;
+};
+
+namespace backend {
+class Session;
+}
+
+class Core {
+ public:
+  Core(rebvio::Camera::SharedPtr camera, rebvio::CoreConfig::SharedPtr config = std::make_shared<rebvio::CoreConfig>());
+  Core() = delete;
+  ~Core();
+
+  CoreConfig::SharedPtr config();
+  void buildDistanceField(rebvio::EdgeMap::SharedPtr map);
+  types::Float tryVel(rebvio::EdgeMap::SharedPtr map, rebvio::types::Matrix3f& JtJ, rebvio::types::Vector3f& JtF,
+                      const rebvio::types::Vector3f& vel, types::Float sigma_rho_min, types::Float* residuals);
+  types::Float minimizeVel(rebvio::EdgeMap::SharedPtr map, rebvio::types::Vector3f& vel, rebvio::types::Matrix3f& Rvel);
+  bool extRotVel(rebvio::EdgeMap::SharedPtr map, const rebvio::types::Vector3f& vel, rebvio::types::Matrix6f& Wx,
+                 rebvio::types::Vector6f& X);
+  rebvio::types::Vector3f gyroBiasCorrection(rebvio::types::Vector6f& X, rebvio::types::Matrix6f& Wx, rebvio::types::Matrix3f& Wb,
+                                             const rebvio::types::Matrix3f& Rg, const rebvio::types::Matrix3f& Rb);
+  void estimateLs4Acceleration(const rebvio::types::Vector3f& vel, rebvio::types::Vector3f& acc, const rebvio::types::Matrix3f& R,
+                               types::Float dt);
+  void estimateMeanAcceleration(const rebvio::types::Vector3f sacc, rebvio::types::Vector3f& acc, const rebvio::types::Matrix3f& R);
+  void updateInverseDepth(rebvio::types::Vector3f& vel);
+
+  std::shared_ptr<backend::Session> session() { return session_; }
+
+ private:
+  rebvio::CoreConfig::SharedPtr config_;
+  rebvio::Camera::SharedPtr camera_;
+  std::shared_ptr<backend::Session> session_;
+  rebvio::EdgeMap::SharedPtr df_map_;
+  // per-instance history of the two acceleration estimators (function-static in the reference, core.cpp:287-293,335-338)
+  types::Vector3f ls4_V_[5];
+  types::Float ls4_T_[5], ls4_Dt_[4];
+  types::Vector3f mean_A_[4];
+};
+
+}  // namespace rebvio

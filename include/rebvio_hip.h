@@ -157,6 +157,10 @@ int rebvio_hip_update_inverse_depth(rebvio_hip_ctx* ctx, const float vel[3]);
 
 /* Gyro-bias state of the frame-pair glue (types/imu.hpp:180-183) back to its initial value. */
 void rebvio_hip_reset_state(rebvio_hip_ctx* ctx);
+/* imu_state_.Bg / imu_state_.W_Bg (types/imu.hpp:180-182): read / set by the orchestrator's gyro-bias initialisation
+ * (rebvio.cpp:146-160). */
+int rebvio_hip_get_gyro_state(rebvio_hip_ctx* ctx, float Bg[3], float W_Bg[9]);
+int rebvio_hip_set_gyro_state(rebvio_hip_ctx* ctx, const float Bg[3], const float W_Bg[9]);
 /* One frame pair, rebvio.cpp:142-259 (accelerometer/SAB branch excluded): distance field of new_map
  * (if not yet built), rotate, minimizeVel, forwardMatch, extRotVel, gyroBiasCorrection, rotate,
  * directedMatch, regularize1Iter, updateInverseDepth. R_prior = IMU inter-frame rotation or NULL. */

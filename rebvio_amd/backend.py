@@ -78,6 +78,8 @@ SIGNATURES = {
     "rebvio_hip_regularize": (C.c_int, [_vp, _vp, _ip]),
     "rebvio_hip_update_inverse_depth": (C.c_int, [_vp, _fp]),
     "rebvio_hip_reset_state": (None, [_vp]),
+    "rebvio_hip_get_gyro_state": (C.c_int, [_vp, _fp, _fp]),
+    "rebvio_hip_set_gyro_state": (C.c_int, [_vp, _fp, _fp]),
     "rebvio_hip_track_pair": (C.c_int, [_vp, _vp, _vp, _fp, C.c_float, C.POINTER(PairOut)]),
     "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_flush": (C.c_int, [_vp]),

@@ -380,6 +380,18 @@ void rebvio_hip_reset_state(rebvio_hip_ctx* c) {
   c->W_Bg = hm::invert3(hm::diag3(100.0f));  // W_Bg{invert(100.0*RGBias)} (types/imu.hpp:181)
 }
 
+int rebvio_hip_get_gyro_state(rebvio_hip_ctx* c, float Bg[3], float W_Bg[9]) {
+  for (int i = 0; i < 3; ++i) Bg[i] = c->Bg[i];
+  hm::store3(c->W_Bg, W_Bg);
+  return 0;
+}
+
+int rebvio_hip_set_gyro_state(rebvio_hip_ctx* c, const float Bg[3], const float W_Bg[9]) {
+  for (int i = 0; i < 3; ++i) c->Bg[i] = Bg[i];
+  c->W_Bg = hm::load3(W_Bg);
+  return 0;
+}
+
 int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   *out = nullptr;
   if (p->rows < 32 || p->cols < 32 || (p->cols % 4) != 0) return fail_msg("rows/cols must be >= 32 and cols % 4 == 0", -3);

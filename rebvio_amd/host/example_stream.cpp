@@ -1,0 +1,60 @@
+// Drives rebvio::Rebvio exactly the way ros_rebvio does (ros_rebvio/src/ros_rebvio.cpp:15-82): register an odometry
+// and an edge-image callback, push MONO8 frames (and optionally IMU samples), print "ts wx wy wz px py pz" lines in
+// the format of the reference's golden odometry file.
+//   rebvio_stream_example frames.u8 width height n_frames [fm cx cy keylines_ref keylines_max]
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <mutex>
+#include <vector>
+
+#include "rebvio/rebvio.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 5) {
+    std::fprintf(stderr, "usage: %s frames.u8 width height n_frames [fm cx cy keylines_ref keylines_max]\n", argv[0]);
+    return 2;
+  }
+  const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), N = std::atoi(argv[4]);
+  std::vector<unsigned char> buf((size_t)W * H * N);
+  std::ifstream f(argv[1], std::ios::binary);
+  if (!f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size())) {
+    std::fprintf(stderr, "cannot read %s\n", argv[1]);
+    return 2;
+  }
+  rebvio::RebvioConfig config;
+  const float fm = argc > 5 ? std::atof(argv[5]) : 458.0f * W / 640.0f;
+  const float cx = argc > 6 ? std::atof(argv[6]) : W / 2.0f, cy = argc > 7 ? std::atof(argv[7]) : H / 2.0f;
+  config.camera = rebvio::Camera(H, W, fm, fm, cx, cy);
+  if (argc > 8) config.edge_detector.keylines_ref = std::atoi(argv[8]);
+  if (argc > 9) config.edge_detector.keylines_max = std::atoi(argv[9]);
+  if (W * H < 640 * 480) config.core.global_min_matches_threshold = 50;
+
+  rebvio::Rebvio rebvio(config);
+  std::mutex mu;
+  int n_odo = 0, n_edge = 0, last_keylines = 0;
+  rebvio.registerOdometryCallback([&](rebvio::types::Odometry& o) {
+    std::lock_guard<std::mutex> g(mu);
+    std::printf("%llu %.6f %.6f %.6f %.6f %.6f %.6f\n", (unsigned long long)o.ts_us, o.orientation[0], o.orientation[1],
+                o.orientation[2], o.position[0], o.position[1], o.position[2]);
+    ++n_odo;
+  });
+  rebvio.registerEdgeImageCallback([&](cv::Mat& img, rebvio::EdgeMap::SharedPtr& map) {
+    std::lock_guard<std::mutex> g(mu);
+    ++n_edge;
+    last_keylines = map->size();  // as ros_rebvio.cpp:44 does: size() and (*map)[i].pos[...]
+    if (last_keylines > 0) (void)(*map)[0].pos[0];
+    (void)img;
+  });
+  for (int i = 0; i < N; ++i) {
+    cv::Mat frame(H, W, CV_8UC1, buf.data() + (size_t)i * W * H);
+    rebvio.imageCallback(rebvio::types::Image{(uint64_t)i * 50000ull, frame.clone()});
+    for (int k = 0; k < 10; ++k)  // 200 Hz IMU next to the 20 Hz camera: a still gyro, gravity on y
+      rebvio.imuCallback(rebvio::types::Imu{(uint64_t)i * 50000ull + (uint64_t)k * 5000ull + 1ull, TooN::makeVector(0.0f, 0.0f, 0.0f),
+                                            TooN::makeVector(0.0f, 9.81f, 0.0f)});
+  }
+  rebvio.waitIdle();
+  std::fprintf(stderr, "frames=%d edge_callbacks=%d odometry_callbacks=%d last_keylines=%d running=%d\n", N, n_edge, n_odo,
+               last_keylines, (int)rebvio.running());
+  return (n_odo == N - 1 && n_edge == N) ? 0 : 1;
+}
