@@ -1,12 +1,18 @@
 // C-ABI of the gfx950 backend (include/rebvio_hip.h): context / edge-map pool management, stream ordering
 // between the detect stream and the track stream, and the O(1) host glue of one frame pair. All heavy work
 // is in detect.hip / track.hip; nothing here falls back to a CPU implementation of the hot path.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -118,6 +124,8 @@ struct rebvio_hip_map {
   hipEvent_t done{};   // last track-stream consumer finished, recorded at release
   bool has_done = false;
   bool df_built = false;
+  std::atomic<int> enqueued{1};  // 0 while the detect worker still has to record `ready` (streaming driver)
+  bool pre_rotated = false;  // the next pair's first rotateKeylines (+ histogram) was already applied by the fused B-chain
   int n_host = -1;
   float thr_host = -1.0f;
 };
@@ -126,7 +134,15 @@ struct rebvio_hip_ctx {
   rebvio_hip_params P{};
   KParams K{};
   int device = 0;
-  hipStream_t s_det{}, s_df{}, s_trk{}, s_cpy{};
+  hipStream_t s_det{}, s_key{}, s_df{}, s_trk{}, s_cpy{};
+  // scale-space outputs (DoG, squared gradient, per-row counts) are double buffered: the scans of frame f+1 (s_det)
+  // overlap the keyline extraction of frame f (s_key)
+  float* dog2[2]{};
+  float* mag2[2]{};
+  int* rowcount2[2]{};
+  hipEvent_t ev_scan[2]{}, ev_flag[2]{};
+  bool ev_flag_used[2] = {false, false};
+  uint64_t launch_index = 0;
   ScaleBufs sb{};
   DetectBufs db{};
   DetState* det = nullptr;  // [kDetRing] servo-state ring + [kDetRing]: scratch sink
@@ -179,9 +195,38 @@ struct rebvio_hip_ctx {
   PendingPair prev{};                   // pair whose B-chain is in flight (counters arrive with cur's slot)
   bool has_cur = false, has_prev = false;
   uint64_t pair_seq = 0;
+  // detect-enqueue worker (the reference's data-acquisition thread, rebvio.cpp:28): launches the detect kernels so
+  // that the caller thread's launches (track chains) and the detect launches proceed in parallel on the host
+  struct DetJob {
+    rebvio_hip_map* m;
+    const void* img;
+    int is_u8;
+    const DetState* det_in;
+    DetState* det_out;
+    const MapState* prev_st;
+  };
+  std::thread det_thread;
+  std::mutex det_mu;
+  std::condition_variable det_cv;
+  std::deque<DetJob> det_jobs;
+  std::atomic<int> det_pending{0};
+  bool det_stop = false;
+  std::string det_error;
+  // host-side phase timing of the streaming driver (printed by flush when REBVIO_HIP_DEBUG is set)
+  double t_detect_enq = 0, t_wait = 0, t_glue = 0, t_b_enq = 0, t_a_enq = 0;
+  bool dbg = false;
+  hipEvent_t dbg_ev[3]{};  // B start, B end / A start, A end
+  double dbg_b = 0, dbg_a = 0;
+  uint64_t dbg_n = 0;
+  uint64_t t_frames = 0;
 };
 
 namespace {
+
+// events of a map may only be waited on once the detect worker has recorded them
+inline void wait_enqueued(rebvio_hip_map* m) {
+  while (!m->enqueued.load(std::memory_order_acquire)) std::this_thread::yield();
+}
 
 size_t part_call_stride(const rebvio_hip_ctx* c) { return (size_t)c->maxblocks * kPartStride; }
 
@@ -198,6 +243,7 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipMalloc(&d.mgnorm, M * sizeof(float)));
   HIPCHK(hipMalloc(&d.rs, M * sizeof(float2)));
   HIPCHK(hipMalloc(&d.rs_tmp, M * sizeof(float2)));
+  HIPCHK(hipMalloc(&d.grad_tmp, M * sizeof(float2)));
   HIPCHK(hipMalloc(&d.id_prev, M * sizeof(int)));
   HIPCHK(hipMalloc(&d.id_next, M * sizeof(int)));
   HIPCHK(hipMalloc(&d.match_id, M * sizeof(int)));
@@ -220,7 +266,7 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
 
 void free_map(rebvio_hip_map* m) {
   MapDev& d = m->d;
-  void* ptrs[] = {d.pos, d.pos_img, d.mpos_img, d.grad, d.mgrad, d.gnorm, d.mgnorm, d.rs, d.rs_tmp, d.id_prev, d.id_next,
+  void* ptrs[] = {d.pos, d.pos_img, d.mpos_img, d.grad, d.grad_tmp, d.mgrad, d.gnorm, d.mgnorm, d.rs, d.rs_tmp, d.id_prev, d.id_next,
                   d.match_id, d.match_fwd, d.match_kf, d.matches, d.fwd_key, d.residual, d.mask, d.df, d.st};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -230,21 +276,35 @@ void free_map(rebvio_hip_map* m) {
   delete m;
 }
 
+int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m);
 rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
   for (auto* m : c->pool)
     if (!m->in_use) {
       m->in_use = true;
       m->df_built = false;
+      m->pre_rotated = false;
       m->n_host = -1;
       m->thr_host = -1.0f;
       return m;
     }
-  return nullptr;
+  // every pooled map is alive (a caller queues detections faster than it tracks, like the reference's unbounded
+  // edge_map_buffer_): grow the pool, ~4 MB per map at 640x480, bounded
+  if (c->pool.size() >= 256) return nullptr;
+  rebvio_hip_map* m = new rebvio_hip_map;
+  m->ctx = c;
+  if (alloc_map(c, m) != 0) {
+    delete m;
+    return nullptr;
+  }
+  c->pool.push_back(m);
+  m->in_use = true;
+  return m;
 }
 
 int fetch_map_state(rebvio_hip_map* m, MapState* out, hipStream_t after) {
   // copy stream: wait for the producer, copy, block the host only on this small transfer
   rebvio_hip_ctx* c = m->ctx;
+  wait_enqueued(m);
   HIPCHK(hipStreamWaitEvent(c->s_cpy, m->ready, 0));
   if (after) {
     hipEvent_t e;
@@ -267,28 +327,99 @@ int ensure_size(rebvio_hip_map* m) {
   return fetch_map_state(m, &st, nullptr);
 }
 
-int detect_common(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_map** out) {
-  rebvio_hip_map* m = acquire_map(c);
-  if (!m) return fail_msg("edge-map pool exhausted (release maps or raise map_pool)", -2);
-  if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_det, m->done, 0));
-  m->ts = ts;
-  const DetState* det_in = c->det + (c->frame_index % kDetRing);
-  DetState* det_out = c->det + ((c->frame_index + 1) % kDetRing);
+int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
+  rebvio_hip_map* m = j.m;
+  const int b = (int)(c->launch_index & 1);
+  c->launch_index++;
   ScaleBufs sb = c->sb;
   sb.scale0 = sb.scale1 = nullptr;
-  launch_scale_space(c->s_det, c->K, img_dev, is_u8, sb, c->widths, c->db.rowcount);
-  launch_keylines(c->s_det, c->K, sb, c->db, m->d, det_in, det_out, c->last_detected ? c->last_detected->d.st : nullptr);
+  sb.dog = c->dog2[b];
+  sb.mag = c->mag2[b];
+  DetectBufs db = c->db;
+  db.rowcount = c->rowcount2[b];
+  // scans of this frame (s_det); its DoG / gradient buffers were last read by the candidate kernel two frames ago
+  if (c->ev_flag_used[b]) HIPCHK(hipStreamWaitEvent(c->s_det, c->ev_flag[b], 0));
+  launch_scale_space(c->s_det, c->K, j.img, j.is_u8, sb, c->widths, db.rowcount);
+  HIPCHK(hipEventRecord(c->ev_scan[b], c->s_det));
+  // keyline extraction + chaining (s_key), overlapping the next frame's scans
+  HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
+  if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done, 0));
+  launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st);
   HIPCHK(hipGetLastError());
-  // distance field of this map on its own stream: overlaps the next frame's scan kernels
-  HIPCHK(hipEventRecord(m->detected, c->s_det));
+  HIPCHK(hipEventRecord(c->ev_flag[b], c->s_key));  // (after join: coarser than needed, same stream order)
+  c->ev_flag_used[b] = true;
+  // distance field of this map on its own stream
+  HIPCHK(hipEventRecord(m->detected, c->s_key));
   HIPCHK(hipStreamWaitEvent(c->s_df, m->detected, 0));
-  launch_df_build(c->s_df, c->K, m->d, det_out);
-  m->df_built = true;
+  launch_df_build(c->s_df, c->K, m->d, j.det_out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(m->ready, c->s_df));
+  m->enqueued.store(1, std::memory_order_release);
+  return 0;
+}
+
+// caller-thread half: takes a pooled map and fixes the servo-state ring slots of this frame
+int detect_prepare(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_ctx::DetJob* job) {
+  rebvio_hip_map* m = acquire_map(c);
+  if (!m) return fail_msg("edge-map pool exhausted (release maps or raise map_pool)", -2);
+  m->ts = ts;
+  m->df_built = true;
+  job->m = m;
+  job->img = img_dev;
+  job->is_u8 = is_u8;
+  job->det_in = c->det + (c->frame_index % kDetRing);
+  job->det_out = c->det + ((c->frame_index + 1) % kDetRing);
+  job->prev_st = c->last_detected ? c->last_detected->d.st : nullptr;
   c->frame_index++;
   c->last_detected = m;
-  *out = m;
+  return 0;
+}
+
+int detect_common(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_map** out) {
+  rebvio_hip_ctx::DetJob job;
+  int rc = detect_prepare(c, img_dev, is_u8, ts, &job);
+  if (rc) return rc;
+  // a queued asynchronous detect must be launched first (stream order = frame order)
+  while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  rc = detect_launch(c, job);
+  if (rc) return rc;
+  *out = job.m;
+  return 0;
+}
+
+void det_worker_main(rebvio_hip_ctx* c) {
+  (void)hipSetDevice(c->device);
+  for (;;) {
+    rebvio_hip_ctx::DetJob j;
+    {
+      std::unique_lock<std::mutex> lk(c->det_mu);
+      c->det_cv.wait(lk, [&] { return c->det_stop || !c->det_jobs.empty(); });
+      if (c->det_jobs.empty()) return;
+      j = c->det_jobs.front();
+      c->det_jobs.pop_front();
+    }
+    if (detect_launch(c, j) != 0) {
+      std::lock_guard<std::mutex> lk(c->det_mu);
+      c->det_error = g_err;
+      j.m->enqueued.store(1, std::memory_order_release);
+    }
+    c->det_pending.fetch_sub(1, std::memory_order_release);
+  }
+}
+
+int detect_async(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_map** out) {
+  rebvio_hip_ctx::DetJob job;
+  int rc = detect_prepare(c, img_dev, is_u8, ts, &job);
+  if (rc) return rc;
+  if (!c->det_thread.joinable()) c->det_thread = std::thread(det_worker_main, c);
+  job.m->enqueued.store(0, std::memory_order_relaxed);
+  c->det_pending.fetch_add(1, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(c->det_mu);
+    c->det_jobs.push_back(job);
+  }
+  c->det_cv.notify_one();
+  *out = job.m;
   return 0;
 }
 
@@ -443,9 +574,15 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   hm::plane_fit_pinv(pinv);
   upload_tables(recip, pinv);
 
-  HIPCHK(hipStreamCreateWithFlags(&c->s_det, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->s_df, hipStreamNonBlocking));
+  // the tracking chain is the serial dependency of the pipeline: highest priority; the atomics-bound distance field is
+  // needed one frame later: lowest
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const int prio_mid = (prio_least + prio_greatest) / 2;
+  HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
+  HIPCHK(hipStreamCreateWithPriority(&c->s_key, hipStreamNonBlocking, prio_mid));
+  HIPCHK(hipStreamCreateWithPriority(&c->s_trk, hipStreamNonBlocking, prio_greatest));
+  HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, prio_least));
   HIPCHK(hipStreamCreateWithFlags(&c->s_cpy, hipStreamNonBlocking));
   const size_t Pn = (size_t)p->rows * p->cols;
   for (int f = 0; f < 2; ++f) {
@@ -458,6 +595,17 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->db.bits, (size_t)p->rows * K.nseg * sizeof(unsigned long long)));
   HIPCHK(hipMalloc(&c->db.rowcount, (size_t)p->rows * sizeof(int)));
   HIPCHK(hipMemset(c->db.rowcount, 0, (size_t)p->rows * sizeof(int)));
+  for (int i = 0; i < 2; ++i) {
+    c->dog2[i] = i ? nullptr : c->sb.dog;
+    c->mag2[i] = i ? nullptr : c->sb.mag;
+    c->rowcount2[i] = i ? nullptr : c->db.rowcount;
+    HIPCHK(hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_flag[i], hipEventDisableTiming));
+  }
+  HIPCHK(hipMalloc(&c->dog2[1], Pn * sizeof(float)));
+  HIPCHK(hipMalloc(&c->mag2[1], Pn * sizeof(float)));
+  HIPCHK(hipMalloc(&c->rowcount2[1], (size_t)p->rows * sizeof(int)));
+  HIPCHK(hipMemset(c->rowcount2[1], 0, (size_t)p->rows * sizeof(int)));
   HIPCHK(hipMalloc(&c->det, (kDetRing + 1) * sizeof(DetState)));
   DetState d0[kDetRing + 1];
   for (int i = 0; i < kDetRing + 1; ++i) {
@@ -508,6 +656,9 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     if (rc) return rc;
   }
   rebvio_hip_reset_state(c);
+  c->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
+  if (c->dbg)
+    for (auto& e : c->dbg_ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipDeviceSynchronize());
   *out = c;
   return 0;
@@ -516,6 +667,14 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
 void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->det_thread.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(c->det_mu);
+      c->det_stop = true;
+    }
+    c->det_cv.notify_all();
+    c->det_thread.join();
+  }
   (void)hipDeviceSynchronize();
   {
     std::lock_guard<std::mutex> g(g_prof.mu);
@@ -533,6 +692,14 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   (void)hipStreamDestroy(c->s_det);
   (void)hipStreamDestroy(c->s_trk);
   (void)hipStreamDestroy(c->s_df);
+  (void)hipStreamDestroy(c->s_key);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
+    if (c->ev_flag[i]) (void)hipEventDestroy(c->ev_flag[i]);
+  }
+  if (c->dog2[1]) (void)hipFree(c->dog2[1]);
+  if (c->mag2[1]) (void)hipFree(c->mag2[1]);
+  if (c->rowcount2[1]) (void)hipFree(c->rowcount2[1]);
   for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
     if (c->slot[i]) (void)hipHostFree(c->slot[i]);
     if (c->slot_ev[i]) (void)hipEventDestroy(c->slot_ev[i]);
@@ -580,7 +747,9 @@ int rebvio_hip_detect_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uin
 
 int rebvio_hip_detector_state(rebvio_hip_ctx* c, float* threshold, float* auto_threshold, int* count) {
   HIPCHK(hipSetDevice(c->device));
+  while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   DetState d;
   HIPCHK(hipMemcpy(&d, c->det + (c->frame_index % kDetRing), sizeof(d), hipMemcpyDeviceToHost));
   float at = d.auto_threshold;
@@ -617,6 +786,7 @@ int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int
   if (rc) return rc;
   // mirror reflects everything enqueued so far on every stream
   HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_trk));
   if (keylines && m->n_host > 0) {
@@ -637,6 +807,7 @@ int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines,
   if (n != m->n_host) return fail_msg("map_upload: count differs from map size", -6);
   HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_trk));
   if (n > 0) {
     HIPCHK(hipMemcpyAsync(c->aos_dev, keylines, (size_t)n * sizeof(rebvio_hip_keyline), hipMemcpyHostToDevice, c->s_cpy));
@@ -651,6 +822,7 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
   if (!m || !m->in_use) return;
   rebvio_hip_ctx* c = m->ctx;
   (void)hipSetDevice(c->device);
+  wait_enqueued(m);
   (void)hipEventRecord(m->done, c->s_trk);
   m->has_done = true;
   if (c->df_map == m) c->df_map = nullptr;
@@ -802,7 +974,7 @@ int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, vel, Rvel, Rback, vel_r, Rvel_r);
   HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 3 * sizeof(int), c->s_trk));
-  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, c->dm_work, c->dm_work_n);
+  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, c->dm_work, c->dm_work_n, nullptr);
   HIPCHK(hipMemsetAsync(c->dm_work_n, 0, sizeof(int), c->s_trk));
   HIPCHK(hipGetLastError());
   MapState st;
@@ -849,7 +1021,7 @@ GlueOut pair_glue(rebvio_hip_ctx* c, const LmState& lm, const float* xrv, int n_
   lm_to_out(lm, Vg, P_Vg, &out->F, &out->lm_accept_mask, &out->sigma_rho_min);
   float Xv[6], W_Xv[36], JtF6[6];
   sum_xrv(xrv, div_up(n_new, 256), W_Xv, JtF6, nullptr);
-  hm::sym6_pinv_solve(W_Xv, JtF6, Xv);
+  hm::sym6_solve(W_Xv, JtF6, Xv);
   out->ext_ok = 1;
   for (int i = 0; i < 6; ++i)
     if (std::isnan(Xv[i])) out->ext_ok = 0;
@@ -888,17 +1060,29 @@ GlueOut pair_glue(rebvio_hip_ctx* c, const LmState& lm, const float* xrv, int n_
   return g;
 }
 
-// rotate by R0, directedMatch, regularize1Iter, updateInverseDepth (rebvio.cpp:232-259) on the track stream
-void enqueue_b_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const GlueOut& g) {
+// rotate by R0, directedMatch, regularize1Iter, updateInverseDepth (rebvio.cpp:232-259) on the track stream:
+// three launches - the rotation of the old map is applied on the fly inside directedMatch (the old map is dead
+// afterwards), regularize + depth EKF are one kernel. RT_next (streaming driver only) additionally applies the next
+// pair's first rotateKeylines to the new map and bins its sigma_rho histogram.
+void enqueue_b_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const GlueOut& g, const float* RT_next) {
   hipStream_t s = c->s_trk;
-  launch_rotate(s, c->K, om->d, g.R0a, nullptr, 0);  // rebvio.cpp:232
-  if (g.nan_v) return;                                // rebvio.cpp:236
+  if (g.nan_v) {  // rebvio.cpp:236: no matching / depth update
+    if (RT_next) {
+      launch_rotate(s, c->K, nm->d, RT_next, c->hist, 0);
+      nm->pre_rotated = true;
+    }
+    return;
+  }
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, g.V, g.P_V, g.Rgva, vel_r, Rvel_r);
-  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, g.Rgva, c->P.search_range, c->dm_work, c->dm_work_n);  // :245
+  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, g.Rgva, c->P.search_range, c->dm_work, c->dm_work_n, g.R0a);
   const int gate = (int)c->P.global_min_matches_threshold;
-  launch_regularize(s, c->K, nm->d, gate > 0 ? gate : 0, c->dm_work_n);  // rebvio.cpp:256 (skipped on device when klm < gate)
-  launch_depth_ekf(s, c->K, nm->d, g.V, 1, gate > 0 ? gate : 0);   // rebvio.cpp:259
+  launch_regularize_ekf(s, c->K, nm->d, g.V, gate > 0 ? gate : 0, c->dm_work_n, RT_next, c->hist);  // rebvio.cpp:256-259
+  std::swap(nm->d.rs, nm->d.rs_tmp);
+  if (RT_next) {
+    std::swap(nm->d.grad, nm->d.grad_tmp);
+    nm->pre_rotated = true;
+  }
 }
 
 hm::M3 prior_rotation(rebvio_hip_ctx* c, const float* R_prior) {
@@ -933,7 +1117,7 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   nm->n_host = slot->new_st.n;
   nm->thr_host = slot->new_st.threshold;
   const GlueOut g = pair_glue(c, slot->lm, slot->xrv, nm->n_host, frame_dt, R, out);
-  enqueue_b_chain(c, om, nm, g);
+  enqueue_b_chain(c, om, nm, g, nullptr);
   HIPCHK(hipGetLastError());
   if (g.nan_v) {
     out->status = 1;
@@ -951,13 +1135,15 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
 namespace {
 int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   hipStream_t s = c->s_trk;
+  wait_enqueued(pp.om);
+  wait_enqueued(pp.nm);
   HIPCHK(hipStreamWaitEvent(s, pp.om->ready, 0));
   HIPCHK(hipStreamWaitEvent(s, pp.nm->ready, 0));
   c->df_map = pp.nm;
-  pp.R = prior_rotation(c, nullptr);
+  pp.R = prior_rotation(c, nullptr);  // equals the rotation a fused B-chain applied: Bg has not changed since
   float RT[9];
   hm::store3(hm::transpose(pp.R), RT);
-  launch_rotate(s, c->K, pp.om->d, RT, c->hist, 0);
+  if (!pp.om->pre_rotated) launch_rotate(s, c->K, pp.om->d, RT, c->hist, 0);  // else done by the previous B-chain
   const float v0[3] = {0, 0, 0};
   enqueue_lm_chain(c, pp.om, pp.nm, v0);
   const int calls = (int)c->P.iterations + 1;
@@ -966,6 +1152,7 @@ int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
                      c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, v0, slot, c->hist);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->slot_ev[pp.slot], s));
+  if (c->dbg) (void)hipEventRecord(c->dbg_ev[2], s);
   pp.a_enqueued = true;
   return 0;
 }
@@ -974,7 +1161,15 @@ int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
 // The directedMatch / regularize counters of the PREVIOUS pair arrive with this slot (old map of this pair).
 int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* completed_keylines, bool* have_completed) {
   rebvio_hip_ctx::PendingPair& cur = c->cur;
+  const auto tw0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventSynchronize(c->slot_ev[cur.slot]));
+  const auto tw1 = std::chrono::steady_clock::now();
+  c->t_wait += std::chrono::duration<double, std::micro>(tw1 - tw0).count();
+  if (c->dbg && c->dbg_n > 0) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->dbg_ev[0], c->dbg_ev[1]) == hipSuccess) c->dbg_b += ms * 1e3;
+    if (hipEventElapsedTime(&ms, c->dbg_ev[1], c->dbg_ev[2]) == hipSuccess) c->dbg_a += ms * 1e3;
+  }
   PairSlot* slot = c->slot[cur.slot];
   if (c->has_prev) {
     rebvio_hip_pair_out& po = c->prev.out;
@@ -993,7 +1188,18 @@ int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* compl
   cur.nm->thr_host = slot->new_st.threshold;
   std::memset(&cur.out, 0, sizeof(cur.out));
   const GlueOut g = pair_glue(c, slot->lm, slot->xrv, cur.nm->n_host, cur.frame_dt, cur.R, &cur.out);
-  enqueue_b_chain(c, cur.om, cur.nm, g);
+  const auto tg1 = std::chrono::steady_clock::now();
+  c->t_glue += std::chrono::duration<double, std::micro>(tg1 - tw1).count();
+  // the new map becomes the next pair's old map: its first rotation (prior after this glue's bias update) rides along
+  float RT_next[9];
+  hm::store3(hm::transpose(prior_rotation(c, nullptr)), RT_next);
+  if (c->dbg) (void)hipEventRecord(c->dbg_ev[0], c->s_trk);
+  enqueue_b_chain(c, cur.om, cur.nm, g, RT_next);
+  if (c->dbg) {
+    (void)hipEventRecord(c->dbg_ev[1], c->s_trk);
+    c->dbg_n++;
+  }
+  c->t_b_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tg1).count();
   HIPCHK(hipGetLastError());
   if (g.nan_v) cur.out.status = 1;
   rebvio_hip_map_release(cur.om);  // stream-ordered: reusable once the B-chain has drained
@@ -1013,8 +1219,13 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   // The returned record is the most recent COMPLETE pair (its match counters travel with the next pair's slot),
   // i.e. pair (f-4, f-3) in steady state; status -1 while the pipeline fills.
   rebvio_hip_map* m = nullptr;
-  int rc = rebvio_hip_detect_u8_device(c, frame_dev, ts_us, &m);
+  const auto td0 = std::chrono::steady_clock::now();
+  HIPCHK(hipSetDevice(c->device));
+  int rc = detect_async(c, frame_dev, 1, ts_us, &m);
   if (rc) return rc;
+  if (!c->det_error.empty()) return fail_msg(c->det_error.c_str(), -8);
+  c->t_detect_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td0).count();
+  c->t_frames++;
   c->frames.push_back(m);
   if (out) {
     std::memset(out, 0, sizeof(*out));
@@ -1038,8 +1249,10 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
     pp.nm = c->frames[1];
     pp.slot = (int)(c->pair_seq++ % rebvio_hip_ctx::kSlots);
     pp.frame_dt = (float)((double)(float)(pp.nm->ts - pp.om->ts) / 1000000.0);  // rebvio.cpp:183
+    const auto ta0 = std::chrono::steady_clock::now();
     rc = enqueue_a_chain(c, pp);
     if (rc) return rc;
+    c->t_a_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta0).count();
     c->cur = pp;
     c->has_cur = true;
     c->frames.erase(c->frames.begin());
@@ -1049,6 +1262,15 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
 
 int rebvio_hip_flush(rebvio_hip_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
+  if (std::getenv("REBVIO_HIP_DEBUG") && c->t_frames) {
+    const double n = (double)c->t_frames;
+    std::fprintf(stderr, "[rebvio_hip] per frame (us): detect-enqueue %.1f  wait %.1f  glue %.1f  B-enqueue %.1f  A-enqueue %.1f\n",
+                 c->t_detect_enq / n, c->t_wait / n, c->t_glue / n, c->t_b_enq / n, c->t_a_enq / n);
+    if (c->dbg_n > 1)
+      std::fprintf(stderr, "[rebvio_hip] GPU spans on the track stream (us): B-chain %.1f  A-chain %.1f\n", c->dbg_b / (c->dbg_n - 1),
+                   c->dbg_a / (c->dbg_n - 1));
+  }
+  while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   if (c->has_cur) {
     int rc = finish_current(c, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -1061,6 +1283,7 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     if (m->in_use) rebvio_hip_map_release(m);
   c->frames.clear();
   HIPCHK(hipStreamSynchronize(c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_trk));
   return 0;

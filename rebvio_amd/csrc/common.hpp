@@ -52,7 +52,8 @@ struct MapDev {
   float* gnorm;      // KeyLine::gradient_norm
   float* mgnorm;     // KeyLine::match_gradient_norm
   float2* rs;        // (rho, sigma_rho)
-  float2* rs_tmp;    // regularize1Iter staging
+  float2* rs_tmp;    // regularize1Iter staging / ping-pong partner of rs
+  float2* grad_tmp;  // ping-pong partner of grad (fused regularize+EKF+rotate)
   int* id_prev;
   int* id_next;
   int* match_id;
@@ -149,7 +150,12 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
 void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm);
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
-                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n);
+                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
+                           const float* R0_on_the_fly);
+// fused regularize1Iter + depth EKF: reads m.rs, writes m.rs_tmp (caller swaps the pointers); Rnext != null also
+// applies the next pair's first rotation and bins sigma_rho into hist
+void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, int* work_n_reset,
+                           const float* Rnext, int* hist);
 void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate, int* work_n_reset);
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp,
                       int min_matches_gate);

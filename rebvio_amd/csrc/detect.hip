@@ -8,6 +8,9 @@
 //
 // Bound: HBM/L2 bandwidth for the per-pixel sweeps; the two scan kernels are additionally bound by
 // their sequential fp32 add chains (cols resp. rows dependent adds) which bit-exactness requires.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace rh {
@@ -571,24 +574,28 @@ __global__ __launch_bounds__(256) void k_df_build(KParams p, MapDev m, const Det
   const int n = m.st->n;
   const float thr = auto_threshold_from(*m.st, det_prev->auto_threshold);
   if (blockIdx.x == 0 && threadIdx.x == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  // Persistent, deliberately small grid (grid-stride over the (keyline, r) pairs): this kernel is bound by the
+  // memory-side atomic rate, not by CUs, and it runs on a low-priority stream beside the latency-critical tracking
+  // kernels - it must not occupy every CU.
   const int nr = p.df_nr;
-  const int idx = gid / nr;
-  if (idx >= n) return;
-  const int ri = gid - idx * nr;
-  const int r = ri - (nr >> 1);
-  const float gn = m.gnorm[idx];
-  if (thr > 0.0f && gn < thr) return;
-  const float2 g = m.grad[idx];
-  const float2 pos = m.pos[idx];
-  const float fr = (g.y / gn) * float(r) + pos.y;
-  const float fc = (g.x / gn) * float(r) + pos.x;
-  const int row = cvtt_f32(roundf(fr));
-  const int col = cvtt_f32(roundf(fc));
-  if ((unsigned)row >= (unsigned)p.rows || (unsigned)col >= (unsigned)p.cols) return;
-  const unsigned seq = (unsigned)(idx * nr + ri);
-  const unsigned key = ((unsigned)abs(r) << kDfSeqBits) | (kDfSeqMask - seq);
-  atomicMin(&m.df[(size_t)row * p.cols + col], key);
+  const int total = n * nr;
+  for (int gid = blockIdx.x * 256 + threadIdx.x; gid < total; gid += gridDim.x * 256) {
+    const int idx = gid / nr;
+    const int ri = gid - idx * nr;
+    const int r = ri - (nr >> 1);
+    const float gn = m.gnorm[idx];
+    if (thr > 0.0f && gn < thr) continue;
+    const float2 g = m.grad[idx];
+    const float2 pos = m.pos[idx];
+    const float fr = (g.y / gn) * float(r) + pos.y;
+    const float fc = (g.x / gn) * float(r) + pos.x;
+    const int row = cvtt_f32(roundf(fr));
+    const int col = cvtt_f32(roundf(fc));
+    if ((unsigned)row >= (unsigned)p.rows || (unsigned)col >= (unsigned)p.cols) continue;
+    const unsigned seq = (unsigned)(idx * nr + ri);
+    const unsigned key = ((unsigned)abs(r) << kDfSeqBits) | (kDfSeqMask - seq);
+    atomicMin(&m.df[(size_t)row * p.cols + col], key);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_df_decode(KParams p, MapDev m, int* __restrict__ id_out, int* __restrict__ dist_out) {
@@ -703,7 +710,11 @@ void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const
 
 void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev) {
   const long long threads = (long long)p.kmax * p.df_nr;
-  RH_LAUNCH(k_df_build, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, m, det_prev);
+  // measured (MI355X, 640x480 pipeline): 16 workgroups -> 316 us/frame (the field itself becomes the bottleneck), 32 -> 172, 64..128 -> 132, 512 -> 156, 2048 -> 162: the kernel is bound by
+  // the memory-side atomic rate and a larger grid only takes CUs and memory queues from the latency-critical streams
+  static const int kDfBlocks = std::getenv("REBVIO_HIP_DF_BLOCKS") ? std::max(1, std::atoi(std::getenv("REBVIO_HIP_DF_BLOCKS"))) : 128;
+  const unsigned blocks = (unsigned)std::min<long long>((threads + 255) / 256, kDfBlocks);
+  RH_LAUNCH(k_df_build, dim3(blocks), dim3(256), 0, s, p, m, det_prev);
 }
 
 void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out) {

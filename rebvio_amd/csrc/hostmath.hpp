@@ -240,6 +240,44 @@ inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
   for (int i = 0; i < N; ++i) x_[i] = bad ? std::numeric_limits<float>::quiet_NaN() : (float)x[i];
 }
 
+// SVD<6>::backsub stand-in used by the pipeline: for a well-conditioned SPD JtJ (the normal case) the pseudo-inverse
+// IS the inverse, so solve by an LDL^T factorisation in double (~300 flops); if a pivot falls below the 1e9 condition
+// cut relative to the largest diagonal, use the Jacobi pseudo-inverse (minimum-norm solution like the SVD).
+inline void sym6_solve(const float* A_, const float* b_, float* x_) {
+  constexpr int N = 6;
+  double L[N][N], d[N], dmax = 0;
+  bool ok = true;
+  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs((double)A_[i * N + i]));
+  for (int j = 0; j < N && ok; ++j) {
+    double v = 0.5 * ((double)A_[j * N + j] + (double)A_[j * N + j]);
+    for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * d[k];
+    if (!(v * 1e7 > dmax)) ok = false;
+    d[j] = v;
+    for (int i = j + 1; i < N && ok; ++i) {
+      double s = 0.5 * ((double)A_[i * N + j] + (double)A_[j * N + i]);
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k] * d[k];
+      L[i][j] = s / v;
+    }
+  }
+  if (!ok) {
+    sym6_pinv_solve(A_, b_, x_);
+    return;
+  }
+  double y[N], x[N];
+  for (int i = 0; i < N; ++i) {
+    double s = (double)b_[i];
+    for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+    y[i] = s;
+  }
+  for (int i = 0; i < N; ++i) y[i] /= d[i];
+  for (int i = N - 1; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < N; ++k) s -= L[k][i] * x[k];
+    x[i] = s;
+  }
+  for (int i = 0; i < N; ++i) x_[i] = (float)x[i];
+}
+
 // Core::gyroBiasCorrection (core.cpp:264-284); dgbias is zero on entry, as in the reference.
 inline void gyro_bias_correction(float X[6], float Wx[36], M3& Wb, const M3& Rg, const M3& Rb, float dgbias_out[3]) {
   float dgbias[3] = {0, 0, 0};

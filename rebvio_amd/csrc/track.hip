@@ -40,6 +40,38 @@ __device__ __forceinline__ unsigned order_key(float f) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// rotateKeylines for one keyline (edge_map.cpp:59-70). makeVector(float, float, 1.0) mixes float and double
+// arguments: TooN's double overload is selected, so the matrix-vector product is accumulated in double and rounded
+// to float once per component.
+__device__ __forceinline__ void rotate_one(const Mat3& R, float fm, float2& pi, float2& rs, float2& g) {
+  const double v0 = (double)(pi.x / fm), v1 = (double)(pi.y / fm);
+  float q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double s = 0.0;
+    s += (double)R.a[i * 3 + 0] * v0;
+    s += (double)R.a[i * 3 + 1] * v1;
+    s += (double)R.a[i * 3 + 2] * 1.0;
+    q[i] = (float)s;
+  }
+  if (fabsf(q[2]) > 0.0f) {
+    pi.x = q[0] / q[2] * fm;
+    pi.y = q[1] / q[2] * fm;
+    rs.x /= q[2];
+    rs.y /= q[2];
+  }
+  float gq[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    double s = 0.0;
+    s += (double)R.a[i * 3 + 0] * (double)g.x;
+    s += (double)R.a[i * 3 + 1] * (double)g.y;
+    s += (double)R.a[i * 3 + 2] * 0.0;
+    gq[i] = (float)s;
+  }
+  g = make_float2(gq[0], gq[1]);
+}
+
 // ---- EdgeMap::rotateKeylines (edge_map.cpp:58-71) [+ estimateQuantile histogram, :39-46] -------------------
 // makeVector(float, float, 1.0) mixes float and double arguments: TooN's double overload is selected, so the
 // matrix-vector product is accumulated in double and rounded to float once per component.
@@ -49,7 +81,7 @@ __global__ __launch_bounds__(256) void k_rotate(KParams p, MapDev m, Mat3 R, int
   const int idx = blockIdx.x * 256 + threadIdx.x;
   float2 pi = m.pos_img[idx];  // bound-free early loads
   float2 rs = m.rs[idx];
-  const float2 g = m.grad[idx];
+  float2 g = m.grad[idx];
   const int n = m.st->n;
   if (hist) {
     if (threadIdx.x < 128) sh[threadIdx.x] = 0;
@@ -61,34 +93,10 @@ __global__ __launch_bounds__(256) void k_rotate(KParams p, MapDev m, Mat3 R, int
     m.st->reg_count = 0;
   }
   if (idx < n) {
-    const double v0 = (double)(pi.x / p.fm), v1 = (double)(pi.y / p.fm);
-    float q[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      double s = 0.0;
-      s += (double)R.a[i * 3 + 0] * v0;
-      s += (double)R.a[i * 3 + 1] * v1;
-      s += (double)R.a[i * 3 + 2] * 1.0;
-      q[i] = (float)s;
-    }
-    if (fabsf(q[2]) > 0.0f) {
-      pi.x = q[0] / q[2] * p.fm;
-      pi.y = q[1] / q[2] * p.fm;
-      rs.x /= q[2];
-      rs.y /= q[2];
-      m.pos_img[idx] = pi;
-      m.rs[idx] = rs;
-    }
-    float gq[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      double s = 0.0;
-      s += (double)R.a[i * 3 + 0] * (double)g.x;
-      s += (double)R.a[i * 3 + 1] * (double)g.y;
-      s += (double)R.a[i * 3 + 2] * 0.0;
-      gq[i] = (float)s;
-    }
-    m.grad[idx] = make_float2(gq[0], gq[1]);
+    rotate_one(R, p.fm, pi, rs, g);
+    m.pos_img[idx] = pi;
+    m.rs[idx] = rs;
+    m.grad[idx] = g;
     if (hist) {
       m.residual[idx] = 0.f;  // minimizeVel starts from residuals[] = {0} (core.cpp:158)
       int i = cvtt_f32(hist_bins * (rs.y - kRhoMin) / (kRhoMax - kRhoMin));
@@ -693,16 +701,32 @@ __device__ __forceinline__ bool search_accept(const KParams& p, const SearchSetu
   return true;
 }
 
-__device__ __forceinline__ void search_commit(MapDev& nm, const MapDev& om, int idx, int found, int* kf) {
-  nm.rs[idx] = om.rs[found];
+// Old-map keyline as directedMatch sees it: stored fields, or (rot != 0) rotated on the fly by R0 - the second
+// rotateKeylines of rebvio.cpp:232 folded into the match (the old map is dead afterwards, rebvio.cpp:126-127).
+struct OldKl {
+  float2 pi, rs, g;
+  float gn;
+};
+__device__ __forceinline__ OldKl load_old(const MapDev& om, int i, int rot, const Mat3& R0, float fm) {
+  OldKl k;
+  k.pi = om.pos_img[i];
+  k.rs = om.rs[i];
+  k.g = om.grad[i];
+  k.gn = om.gnorm[i];
+  if (rot) rotate_one(R0, fm, k.pi, k.rs, k.g);
+  return k;
+}
+
+__device__ __forceinline__ void search_commit(MapDev& nm, const MapDev& om, int idx, int found, const OldKl& k, int* kf) {
+  nm.rs[idx] = k.rs;
   nm.match_id[idx] = found;
   nm.matches[idx] = om.matches[found] + 1u;
-  nm.mpos_img[idx] = om.pos_img[found];
-  nm.mgrad[idx] = om.grad[found];
-  nm.mgnorm[idx] = om.gnorm[found];
-  const int k = om.match_kf[found];
-  nm.match_kf[idx] = k;
-  *kf = (k >= 0) ? 1 : 0;
+  nm.mpos_img[idx] = k.pi;
+  nm.mgrad[idx] = k.g;
+  nm.mgnorm[idx] = k.gn;
+  const int kfi = om.match_kf[found];
+  nm.match_kf[idx] = kfi;
+  *kf = (kfi >= 0) ? 1 : 0;
 }
 
 constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-keyline pass
@@ -713,7 +737,8 @@ constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-
 // queued for pass 2 (a wave with one such lane would otherwise idle 63 lanes for up to 40 more dependent steps).
 // vel / Rvel are already rotated by Rback on the host (:193-194).
 __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel, Mat3 Rvel, Mat3 Rback,
-                                                        float max_radius, int* __restrict__ work, int* __restrict__ work_n) {
+                                                        float max_radius, int* __restrict__ work, int* __restrict__ work_n,
+                                                        int rot, Mat3 R0) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid)
   const float2 rsq = nm.rs[idx];
@@ -751,22 +776,20 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
     int cand[2 * kHeadSteps];
 #pragma unroll
     for (int k = 0; k < 2 * kHeadSteps; ++k) cand[k] = (pix[k] >= 0) ? om.mask[pix[k]] : -1;
-    float2 cg[2 * kHeadSteps], crs[2 * kHeadSteps];
-    float cgn[2 * kHeadSteps];
+    OldKl ck[2 * kHeadSteps];
 #pragma unroll
-    for (int k = 0; k < 2 * kHeadSteps; ++k) {
-      if (cand[k] >= 0) {
-        cg[k] = om.grad[cand[k]];
-        cgn[k] = om.gnorm[cand[k]];
-        crs[k] = om.rs[cand[k]];
-      }
-    }
+    for (int k = 0; k < 2 * kHeadSteps; ++k)
+      if (cand[k] >= 0) ck[k] = load_old(om, cand[k], rot, R0, p.fm);
+    OldKl hit;
 #pragma unroll
     for (int k = 0; k < 2 * kHeadSteps; ++k) {
       if (found >= 0 || cand[k] < 0) continue;
-      if (search_accept(p, S, tq[k], cg[k], cgn[k], crs[k], gq, gnq)) found = cand[k];
+      if (search_accept(p, S, tq[k], ck[k].g, ck[k].gn, ck[k].rs, gq, gnq)) {
+        found = cand[k];
+        hit = ck[k];
+      }
     }
-    if (found >= 0) search_commit(nm, om, idx, found, &kf);
+    if (found >= 0) search_commit(nm, om, idx, found, hit, &kf);
     more = (found < 0) && (S.t_steps > kHeadSteps);
   }
   // queue the open long searches (order in the queue is irrelevant: each entry only touches its own keyline)
@@ -791,7 +814,7 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
 // tn/tp are produced by the same repeated -1.0f / +1.0f steps as the sequential loop (not dq_rho -/+ k).
 __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev nm, MapDev om, Vec3 vel, Mat3 Rvel, Mat3 Rback,
                                                              float max_radius, const int* __restrict__ work,
-                                                             const int* __restrict__ work_n) {
+                                                             const int* __restrict__ work_n, int rot, Mat3 R0) {
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int total = *work_n;
@@ -819,13 +842,16 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
         if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) cand = om.mask[(size_t)row * p.cols + col];
       }
       bool acc = false;
-      if (cand >= 0) acc = search_accept(p, S, t, om.grad[cand], om.gnorm[cand], om.rs[cand], gq, gnq);
+      if (cand >= 0) {
+        const OldKl ck = load_old(om, cand, rot, R0, p.fm);
+        acc = search_accept(p, S, t, ck.g, ck.gn, ck.rs, gq, gnq);
+      }
       const unsigned long long am = __ballot(acc);
       if (am) found = __shfl(cand, __ffsll((long long)am) - 1);
     }
     if (found >= 0 && lane == 0) {
       int kf = 0;
-      search_commit(nm, om, idx, found, &kf);
+      search_commit(nm, om, idx, found, load_old(om, found, rot, R0, p.fm), &kf);
       nfound += 1;
       nkf += kf;
     }
@@ -913,6 +939,100 @@ __global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel
   m.rs[idx] = rs;
 }
 
+// ---- regularize1Iter + updateInverseDepth fused (edge_map.cpp:220-259, core.cpp:417-456) ------------------------
+// Jacobi semantics need the neighbours' OLD depths: read rs, write rs_tmp; the host then swaps the two pointers of
+// this map. Optionally (streaming driver) the keyline is also put through the NEXT pair's first rotateKeylines
+// (rebvio.cpp:165) and binned for its estimateQuantile, which removes that pair's k_rotate launch.
+__global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec3 vel, int gate_min_matches,
+                                                        int* __restrict__ work_n_reset, int next_rot, Mat3 Rnext,
+                                                        int* __restrict__ hist, int hist_bins) {
+  __shared__ int sh[128];
+  if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float2 rs = m.rs[idx];  // bound-free early loads
+  const int in = m.id_next[idx], ip = m.id_prev[idx];
+  const int mid = m.match_id[idx];
+  float2 q = m.pos_img[idx];
+  const float2 q0 = m.mpos_img[idx];
+  const float2 mg = m.mgrad[idx];
+  const float mgn = m.mgnorm[idx];
+  float2 g = m.grad[idx];
+  const int n = m.st->n;
+  const bool gated = gate_min_matches > 0 && m.st->dm_matches < gate_min_matches;
+  if (next_rot) {
+    if (threadIdx.x < 128) sh[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  int set = 0;
+  if (idx < n) {
+    float2 out = rs;
+    if (!gated) {
+      if (in >= 0 && ip >= 0) {
+        const float2 rn = m.rs[in], rp = m.rs[ip];
+        if (!((rn.x - rp.x) * (rn.x - rp.x) > (rn.y * rn.y + rp.y * rp.y))) {
+          const float2 gn = m.grad[in], gp = m.grad[ip];
+          float alpha = (gn.x * gp.x + gn.y * gp.y) / (m.gnorm[in] * m.gnorm[ip]);
+          if (!(alpha < p.regularization_threshold)) {
+            alpha = (float)((double)(alpha - p.regularization_threshold) / (1.0 - (double)p.regularization_threshold));
+            alpha = (float)((double)alpha / ((double)(fabsf(rn.x - rp.x) / (rn.y + rp.y)) + 1.0));
+            const float wr = (float)(1.0 / (double)(rs.y * rs.y));
+            const float wrn = alpha / (rn.y * rn.y);
+            const float wrp = alpha / (rp.y * rp.y);
+            out.x = (rs.x * wr + rn.x * wrn + rp.x * wrp) / (wr + wrn + wrp);
+            out.y = (rs.y * wr + rn.y * wrn + rp.y * wrp) / (wr + wrn + wrp);
+            set = 1;
+          }
+        }
+      }
+      if (mid >= 0) {
+        const float vx = vel.a[0], vy = vel.a[1], vz = vel.a[2];
+        float v_rho = out.y * out.y;
+        const float ux = mg.x / mgn;
+        const float uy = mg.y / mgn;
+        const float Y = ux * (q.x - q0.x) + uy * (q.y - q0.y);
+        const float H = ux * (vx * p.fm - vz * q0.x) + uy * (vy * p.fm - vz * q0.y);
+        const float rho_p = (float)(1.0 / (1.0 / (double)out.x + (double)vz));
+        float F = (float)(1.0 / (1.0 + (double)(out.x * vz)));
+        F *= F;
+        const float p_p = F * v_rho * F + p.reshape_q_abs * p.reshape_q_abs;
+        const float e = Y - H * rho_p;
+        const float S = H * p_p * H + p.pixel_uncertainty * p.pixel_uncertainty;
+        const float K = (float)((double)(p_p * H) * (1.0 / (double)S));
+        float rho = rho_p + K * e;
+        v_rho = (float)((1.0 - (double)(K * H)) * (double)p_p);
+        float sig = sqrtf(v_rho);
+        if (rho < kRhoMin) {
+          sig += kRhoMin - rho;
+          rho = kRhoMin;
+        } else if (rho > kRhoMax) {
+          rho = kRhoMax;
+        } else if (isnan(rho) || isnan(sig) || isinf(rho) || isinf(sig)) {
+          rho = kRhoInit;
+          sig = kRhoMax;
+        }
+        out = make_float2(rho, sig);
+      }
+    }
+    if (next_rot) {
+      rotate_one(Rnext, p.fm, q, out, g);
+      m.pos_img[idx] = q;
+      m.grad_tmp[idx] = g;  // neighbours still read the un-rotated m.grad in this kernel: the caller swaps the pointers
+      m.residual[idx] = 0.f;
+      int i = cvtt_f32(hist_bins * (out.y - kRhoMin) / (kRhoMax - kRhoMin));
+      i = (i > hist_bins - 1) ? (hist_bins - 1) : i;
+      i = (i < 0) ? 0 : i;
+      atomicAdd(&sh[i], 1);
+    }
+    m.rs_tmp[idx] = out;
+  }
+  const int c = wave_sum_i(set);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&m.st->reg_count, c);
+  if (next_rot) {
+    __syncthreads();
+    if ((int)threadIdx.x < hist_bins && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 static Mat3 mat3(const float* r) {
   Mat3 m;
@@ -958,16 +1078,27 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
 }
 
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
-                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n) {
-  // *work_n is zero on entry (kept zero by k_dm_reset below)
+                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
+                           const float* R0_on_the_fly) {
+  // *work_n is zero on entry (reset by the kernel that follows the tail, or by the caller)
+  const int rot = R0_on_the_fly ? 1 : 0;
+  const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
   RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
-                     mat3(Rback), max_radius, work, work_n);
+                     mat3(Rback), max_radius, work, work_n, rot, R0);
   RH_LAUNCH(k_directed_match_tail, dim3(256), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
-            (const int*)work, (const int*)work_n);
+            (const int*)work, (const int*)work_n, rot, R0);
 }
 
 void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate, int* work_n_reset) {
   RH_LAUNCH(k_regularize, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, gate, work_n_reset);
+}
+
+void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, int* work_n_reset,
+                           const float* Rnext, int* hist) {
+  const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(vel), gate, work_n_reset, Rnext ? 1 : 0,
+            mat3(Rnext ? Rnext : I), hist, p.quantile_num_bins);
 }
 
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp, int gate) {
