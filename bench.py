@@ -25,6 +25,27 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
+
+def pmc_traffic_bytes(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/r01_pmc_hbm.json:
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs). Counters are in KiB; per
+    MI355X_MICROARCH.md §HBM FETCH_SIZE reads half of a wide coalesced stream on gfx950 -> doubled; other access
+    widths are uncalibrated, so this is an upper estimate for gather-style kernels. None when no pass is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path)).get(kernel)
+        if not d:
+            return None
+        f = d.get("FETCH_SIZE", {}).get("mean_KiB_per_launch")
+        w = d.get("WRITE_SIZE", {}).get("mean_KiB_per_launch")
+        if f is None or w is None:
+            return None
+        return (2.0 * f + w) * 1024.0
+    except Exception:
+        return None
+
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "c2": dict(width=640, height=480, keylines_ref=15000, keylines_max=16000,
@@ -83,8 +104,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    shard.init_group("nccl", rank, world, torch.device("cuda", local_rank))  # RCCL: barrier + max-time only
+    # rehearsal knobs (never set by the driver): run several ranks on ONE card over gloo to exercise the N>1 path
+    dev_index = int(os.environ.get("REBVIO_BENCH_DEVICE", local_rank))
+    backend_name = os.environ.get("REBVIO_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    shard.init_group(backend_name, rank, world, torch.device("cuda", dev_index))  # RCCL: barrier + max-time only
+    local_rank = dev_index
 
     from rebvio_amd import backend as B
     from rebvio_amd import synth
@@ -155,7 +180,7 @@ def main():
     ctx.profile(False)
     ctx.flush()
 
-    tmax = shard.max_over_ranks(elapsed, world, "cuda")
+    tmax = shard.max_over_ranks(elapsed, world, "cuda" if backend_name == "nccl" else "cpu")
     bad = sum(1 for s in statuses if s not in (0,))
     if bad:
         print(f"[rank {rank}] WARNING: {bad} of {steps} frame pairs ended with a non-zero tracking status", file=sys.stderr)
@@ -184,7 +209,7 @@ def main():
                        "mean_matches": float(np.mean([m for m in matches if m > 0])) if any(m > 0 for m in matches) else 0.0,
                        "frames_in_hbm": args.base_frames, "parallelism": f"{world} independent streams, 1 per GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dominant),
                          "avg_launch_us": dom_us, "launches": dom[1], "algorithmic_bytes_per_launch": ab,
                          "frame_algorithmic_bytes": 112 * npx + 1740 * n_keylines,
                          "frame_achieved_GBs": (112 * npx + 1740 * n_keylines) * (fps / world) / 1e9},

@@ -167,6 +167,8 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // Optional per-kernel timing with HIP events recorded on the launching stream (api.hip).
 void prof_begin(hipStream_t s, const char* name);
 void prof_end(hipStream_t s);
+void prof_group_begin(hipStream_t s, const char* name, int count);
+void prof_group_end(hipStream_t s);
 struct ProfScope {
   hipStream_t s;
   ProfScope(hipStream_t s_, const char* name) : s(s_) { prof_begin(s, name); }
