@@ -146,6 +146,13 @@ Matrix<R, C, P> operator*(const Matrix<R, C, P>& a, P s) {
   return r;
 }
 template <int R, int C, typename P>
+Matrix<R, C, P> operator/(const Matrix<R, C, P>& a, P s) {
+  Matrix<R, C, P> r;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) r.m[i][j] = a.m[i][j] / s;
+  return r;
+}
+template <int R, int C, typename P>
 Matrix<R, C, P> operator+(const Matrix<R, C, P>& a, const Matrix<R, C, P>& b) {
   Matrix<R, C, P> r;
   for (int i = 0; i < R; ++i)
@@ -199,6 +206,23 @@ class SO3 {
   SO3() : R_(Identity) {}
   explicit SO3(const Vector<3, P>& w) { R_ = exp(w); }
   explicit SO3(const Matrix<3, 3, P>& R) : R_(R) {}
+  // minimal rotation taking a to b
+  SO3(const Vector<3, P>& a, const Vector<3, P>& b) {
+    Vector<3, P> n = a ^ b;
+    if (n * n == 0) {
+      R_ = Matrix<3, 3, P>(Identity);
+      return;
+    }
+    n = n / std::sqrt(n * n);
+    const Vector<3, P> ua = a / std::sqrt(a * a), ub = b / std::sqrt(b * b);
+    const Vector<3, P> c1 = n ^ ua, c2 = n ^ ub;
+    Matrix<3, 3, P> R1, Rm;
+    for (int i = 0; i < 3; ++i) {
+      R1(i, 0) = ua[i]; R1(i, 1) = n[i]; R1(i, 2) = c1[i];
+      Rm(i, 0) = ub[i]; Rm(i, 1) = n[i]; Rm(i, 2) = c2[i];
+    }
+    R_ = Rm * R1.T();
+  }
   static Matrix<3, 3, P> exp(const Vector<3, P>& w) {
     const P one_6th = P(1.0 / 6.0), one_20th = P(1.0 / 20.0);
     P tsq = w * w, A, B;

@@ -45,6 +45,12 @@ class Core {
   void estimateLs4Acceleration(const rebvio::types::Vector3f& vel, rebvio::types::Vector3f& acc, const rebvio::types::Matrix3f& R,
                                types::Float dt);
   void estimateMeanAcceleration(const rebvio::types::Vector3f sacc, rebvio::types::Vector3f& acc, const rebvio::types::Matrix3f& R);
+  types::Float estimateBias(const rebvio::types::Vector3f& sacc, const rebvio::types::Vector3f& facc, types::Float kP,
+                            const rebvio::types::Matrix3f Rot, rebvio::types::Vector7f& X, rebvio::types::Matrix7f& P,
+                            const rebvio::types::Matrix3f& Qg, const rebvio::types::Matrix3f& Qrot, const rebvio::types::Matrix3f& Qbias,
+                            types::Float QKp, types::Float Rg, const rebvio::types::Matrix3f& Rs, const rebvio::types::Matrix3f& Rf,
+                            rebvio::types::Vector3f& g_est, rebvio::types::Vector3f& b_est, const rebvio::types::Matrix6f& Wvw,
+                            rebvio::types::Vector6f& Xvw, types::Float g_gravit);
   void updateInverseDepth(rebvio::types::Vector3f& vel);
 
   std::shared_ptr<backend::Session> session() { return session_; }

@@ -13,6 +13,7 @@
 #include "rebvio/camera.hpp"
 #include "rebvio/core.hpp"
 #include "rebvio/edge_detector.hpp"
+#include "rebvio/sab_estimator.hpp"
 #include "rebvio/types/definitions.hpp"
 #include "rebvio/types/image.hpp"
 #include "rebvio/types/imu.hpp"
@@ -54,6 +55,7 @@ class Rebvio {
   rebvio::EdgeDetector edge_detector_;
   rebvio::Core core_;
   rebvio::types::ImuState imu_state_;
+  rebvio::SABEstimator::State sab_state_;  // after core_ and config_ in construction order
 
   std::queue<rebvio::types::Image> image_buffer_;
   std::mutex image_buffer_mutex_;

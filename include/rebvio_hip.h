@@ -167,6 +167,31 @@ int rebvio_hip_set_gyro_state(rebvio_hip_ctx* ctx, const float Bg[3], const floa
 int rebvio_hip_track_pair(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, rebvio_hip_map* new_map, const float* R_prior,
                           float frame_dt, rebvio_hip_pair_out* out);
 
+/* The same step in two halves, for hosts that fuse inertial data between them (rebvio.cpp:206-233: accelerometer /
+ * scale-attitude-bias filter decides the final V, Rgva and the second rotation):
+ *   begin  = rebvio.cpp:142-191: distance field, rotate by the gyro prior, minimizeVel, forwardMatch, extRotVel,
+ *            gyroBiasCorrection. Returns Vg, P_Vg, Xv, W_Xv, Xgv, W_Xgv (after correction) and R (prior corrected by Bg).
+ *   finish = rebvio.cpp:223/232 + 236-259: rotate the old map by R_second, directedMatch with (V, P_V, Rgva),
+ *            regularize1Iter, updateInverseDepth; status 0 / 1 (NaN in V) / 2 (< global_min_matches_threshold). */
+typedef struct rebvio_hip_pair_mid {
+  float Vg[3];
+  float P_Vg[9];
+  float F;
+  float sigma_rho_min;
+  int lm_accept_mask;
+  int ext_ok;
+  float Xv[6];
+  float W_Xv[36];
+  float Xgv[6];
+  float W_Xgv[36];
+  float R[9];
+} rebvio_hip_pair_mid;
+int rebvio_hip_track_pair_begin(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, rebvio_hip_map* new_map, const float* R_prior,
+                                float frame_dt, rebvio_hip_pair_mid* mid);
+int rebvio_hip_track_pair_finish(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, rebvio_hip_map* new_map, const float V[3],
+                                 const float P_V[9], const float Rgva[9], const float R_second[9], int* klm_num,
+                                 int* kf_matches, int* reg_num, int* status);
+
 /* Streaming driver used by bench/Rebvio: detect(frame) on the detect stream overlapped with
  * track(previous pair) on the track stream. `out` describes the pair (previous, this) and is filled
  * when the call returns (status -1 for the very first frame). */

@@ -43,6 +43,12 @@ class PairOut(C.Structure):
         ("reg_num", C.c_int), ("lm_accept_mask", C.c_int), ("status", C.c_int)]
 
 
+class VioOut(C.Structure):
+    _fields_ = [("pair", PairOut), ("orientation", C.c_float * 3), ("position", C.c_float * 3), ("K", C.c_float),
+                ("g_est", C.c_float * 3), ("b_est", C.c_float * 3), ("Bg", C.c_float * 3), ("initialized", C.c_int),
+                ("sab_active", C.c_int)]
+
+
 def build(native: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile) and return the .so path."""
     target = ["native"] if native else []
@@ -98,6 +104,9 @@ def lib(path: str | None = None):
         "orc_update_inverse_depth": (None, [vp, fp]),
         "orc_reset_state": (None, [vp]),
         "orc_track_pair": (C.c_int, [vp, vp, vp, fp, C.c_float, C.POINTER(PairOut)]),
+        "orc_vio_reset": (None, [vp, fp, fp]),
+        "orc_vio_add_imu": (None, [vp, vp, C.c_uint64, fp, fp]),
+        "orc_vio_step": (C.c_int, [vp, vp, vp, C.POINTER(VioOut)]),
         "orc_ls4_reset": (None, [vp]),
         "orc_estimate_ls4_acceleration": (None, [vp, fp, fp, fp, C.c_float]),
         "orc_so3_exp": (None, [fp, fp]),
@@ -275,6 +284,22 @@ class Oracle:
         if R_prior is not None:
             R_prior, pr = _f(np.asarray(R_prior).reshape(9))
         self.L.orc_track_pair(self.h, old.h, new.h, pr, frame_dt, C.byref(out))
+        return out
+
+    # --- full VIO (config 5) -------------------------------------------------------------------
+    def vio_reset(self, R_c2i=None, t_c2i=None):
+        R, pr = _f(np.eye(3) if R_c2i is None else np.asarray(R_c2i).reshape(9))
+        t, pt = _f(np.zeros(3) if t_c2i is None else t_c2i)
+        self.L.orc_vio_reset(self.h, pr, pt)
+
+    def vio_add_imu(self, m: Map, ts_us, gyro, acc):
+        g, pg = _f(gyro)
+        a, pa = _f(acc)
+        self.L.orc_vio_add_imu(self.h, m.h, int(ts_us), pg, pa)
+
+    def vio_step(self, old: Map, new: Map) -> VioOut:
+        out = VioOut()
+        self.L.orc_vio_step(self.h, old.h, new.h, C.byref(out))
         return out
 
     def run_stream(self, frames_u8: np.ndarray, idx: np.ndarray, threads=1):

@@ -310,6 +310,360 @@ void sym_pinv_solve(const float* A_, const float* b_, float* x_) {
   for (int i = 0; i < N; ++i) x_[i] = bad ? std::numeric_limits<float>::quiet_NaN() : (float)x[i];
 }
 
+
+// ---- generic small dense helpers for the inertial glue (float, TooN evaluation order) -----------------------------
+template <int R, int C>
+struct Mat {
+  float a[R][C];
+  static Mat zeros() {
+    Mat m;
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < C; ++j) m.a[i][j] = 0;
+    return m;
+  }
+};
+template <int R, int K, int C>
+Mat<R, C> mmul(const Mat<R, K>& x, const Mat<K, C>& y) {
+  Mat<R, C> r;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) {
+      float s = 0;
+      for (int k = 0; k < K; ++k) s += x.a[i][k] * y.a[k][j];
+      r.a[i][j] = s;
+    }
+  return r;
+}
+template <int R, int C>
+Mat<C, R> mT(const Mat<R, C>& x) {
+  Mat<C, R> r;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) r.a[j][i] = x.a[i][j];
+  return r;
+}
+template <int R, int C>
+void mvec(const Mat<R, C>& m, const float* v, float* out) {
+  float t[R];
+  for (int i = 0; i < R; ++i) {
+    float s = 0;
+    for (int k = 0; k < C; ++k) s += m.a[i][k] * v[k];
+    t[i] = s;
+  }
+  for (int i = 0; i < R; ++i) out[i] = t[i];
+}
+template <int N>
+float vdot(const float* a, const float* b) {
+  float s = 0;
+  for (int i = 0; i < N; ++i) s += a[i] * b[i];
+  return s;
+}
+// x^T M y
+template <int N>
+float quad(const float* x, const Mat<N, N>& M, const float* y) {
+  float t[N];
+  for (int j = 0; j < N; ++j) {
+    float s = 0;
+    for (int k = 0; k < N; ++k) s += x[k] * M.a[k][j];
+    t[j] = s;
+  }
+  return vdot<N>(t, y);
+}
+template <int N>
+Mat<N, N> chol_inv(const Mat<N, N>& A) {
+  Mat<N, N> r;
+  cholesky_inverse<N>(&A.a[0][0], &r.a[0][0]);
+  return r;
+}
+
+// TooN SVD<N>(A).backsub(b) in DOUBLE precision (SVD<7> without a precision argument, sab_estimator.cpp:31) for a
+// symmetric A: Jacobi eigen-decomposition, singular values below max/1e9 dropped.
+template <int N>
+void sym_pinv_solve_d(const double* A_, const double* b_, double* x_) {
+  double A[N][N], V[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      A[i][j] = 0.5 * (A_[i * N + j] + A_[j * N + i]);
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 80; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        if (A[p][q] == 0.0) continue;
+        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        double t = ((theta >= 0) ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < N; ++k) {
+          double akp = A[k][p], akq = A[k][q];
+          A[k][p] = cs * akp - sn * akq;
+          A[k][q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < N; ++k) {
+          double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = cs * apk - sn * aqk;
+          A[q][k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < N; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = cs * vkp - sn * vkq;
+          V[k][q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  double dmax = 0;
+  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(A[i][i]));
+  for (int i = 0; i < N; ++i) x_[i] = 0;
+  for (int k = 0; k < N; ++k) {
+    double lam = A[k][k];
+    if (!(std::fabs(lam) * 1e9 > dmax)) continue;
+    double proj = 0;
+    for (int i = 0; i < N; ++i) proj += V[i][k] * b_[i];
+    proj /= lam;
+    for (int i = 0; i < N; ++i) x_[i] += V[i][k] * proj;
+  }
+}
+
+// TooN SO3(a, b): minimal rotation taking a to b (so3.h two-vector constructor)
+inline M3 so3_from_two(const float a[3], const float b[3]) {
+  auto cross = [](const float* x, const float* y, float* o) {
+    o[0] = x[1] * y[2] - x[2] * y[1];
+    o[1] = x[2] * y[0] - x[0] * y[2];
+    o[2] = x[0] * y[1] - x[1] * y[0];
+  };
+  auto unit = [](const float* x, float* o) {
+    float n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    for (int i = 0; i < 3; ++i) o[i] = x[i] / n;
+  };
+  float n[3];
+  cross(a, b, n);
+  if (n[0] * n[0] + n[1] * n[1] + n[2] * n[2] == 0) return m3_identity();
+  unit(n, n);
+  M3 R1, Rm;
+  float ua[3], ub[3], c1[3], c2[3];
+  unit(a, ua);
+  unit(b, ub);
+  cross(n, ua, c1);
+  cross(n, ub, c2);
+  for (int i = 0; i < 3; ++i) {  // columns: unit(a) | n | n ^ unit(a)
+    R1.a[i][0] = ua[i]; R1.a[i][1] = n[i]; R1.a[i][2] = c1[i];
+    Rm.a[i][0] = ub[i]; Rm.a[i][1] = n[i]; Rm.a[i][2] = c2[i];
+  }
+  return m3_mul(Rm, m3_T(R1));
+}
+
+// TooN SO3::ln()
+inline void so3_ln(const M3& R, float out[3]) {
+  const float cos_angle = (R.a[0][0] + R.a[1][1] + R.a[2][2] - 1.0f) * 0.5f;
+  float r[3] = {(R.a[2][1] - R.a[1][2]) / 2, (R.a[0][2] - R.a[2][0]) / 2, (R.a[1][0] - R.a[0][1]) / 2};
+  float sin_abs = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (cos_angle > (float)M_SQRT1_2) {
+    if (sin_abs > 0) {
+      float k = std::asin(sin_abs) / sin_abs;
+      for (int i = 0; i < 3; ++i) r[i] *= k;
+    }
+  } else if (cos_angle > -(float)M_SQRT1_2) {
+    if (sin_abs > 0) {
+      float k = std::acos(cos_angle) / sin_abs;
+      for (int i = 0; i < 3; ++i) r[i] *= k;
+    }
+  } else {
+    const float angle = (float)M_PI - std::asin(sin_abs);
+    const float d0 = R.a[0][0] - cos_angle, d1 = R.a[1][1] - cos_angle, d2 = R.a[2][2] - cos_angle;
+    float r2[3];
+    if (d0 * d0 > d1 * d1 && d0 * d0 > d2 * d2) {
+      r2[0] = d0; r2[1] = (R.a[1][0] + R.a[0][1]) / 2; r2[2] = (R.a[0][2] + R.a[2][0]) / 2;
+    } else if (d1 * d1 > d2 * d2) {
+      r2[0] = (R.a[1][0] + R.a[0][1]) / 2; r2[1] = d1; r2[2] = (R.a[2][1] + R.a[1][2]) / 2;
+    } else {
+      r2[0] = (R.a[0][2] + R.a[2][0]) / 2; r2[1] = (R.a[2][1] + R.a[1][2]) / 2; r2[2] = d2;
+    }
+    if (r2[0] * r[0] + r2[1] * r[1] + r2[2] * r[2] < 0)
+      for (int i = 0; i < 3; ++i) r2[i] = -r2[i];
+    float nrm = std::sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+    for (int i = 0; i < 3; ++i) r[i] = r2[i] * (angle / nrm);
+  }
+  for (int i = 0; i < 3; ++i) out[i] = r[i];
+}
+
+// types::IntegratedImu (types/imu.hpp:35-151)
+struct IntImu {
+  unsigned n = 0;
+  uint64_t last_ts = 0, init_ts = 0, dt = 0;
+  M3 R = m3_identity();
+  float gyro[3] = {0, 0, 0}, gyro_init[3] = {0, 0, 0}, gyro_last[3] = {0, 0, 0}, acc[3] = {0, 0, 0}, dgyro[3] = {0, 0, 0},
+        cacc[3] = {0, 0, 0};
+  float dt_s() const { return float(dt) / 1000000.0; }
+  void add(uint64_t ts, const float g[3], const float a[3], const M3& Rc2i) {
+    float tmp[3], at[3];
+    M3 RT = m3_T(Rc2i);
+    m3_vec(RT, g, tmp);
+    float dts;
+    if (last_ts == 0) {
+      n = 1;
+      init_ts = ts;
+      last_ts = init_ts;
+      dts = 0.005;
+      for (int i = 0; i < 3; ++i) gyro_init[i] = gyro_last[i] = g[i];
+      R = m3_identity();
+      for (int i = 0; i < 3; ++i) gyro[i] = tmp[i];
+      m3_vec(RT, a, acc);
+      for (int i = 0; i < 3; ++i) dgyro[i] = cacc[i] = 0;
+    } else {
+      ++n;
+      dts = float(ts - last_ts) / 1000000.0;
+      m3_vec(RT, a, at);
+      for (int i = 0; i < 3; ++i) {
+        gyro[i] += tmp[i];
+        acc[i] += at[i];
+      }
+    }
+    float w[3] = {tmp[0] * dts, tmp[1] * dts, tmp[2] * dts};
+    R = m3_mul(R, so3_exp(w));
+    last_ts = ts;
+    for (int i = 0; i < 3; ++i) gyro_last[i] = g[i];
+  }
+  void get(const M3& Rc2i, const float tc2i[3]) {
+    dt = (n == 1) ? 0 : (last_ts - init_ts) / (uint64_t)(unsigned)(n - 1) * n;  // n == 1: the reference divides 0 by 0
+    M3 RT = m3_T(Rc2i);
+    if (n > 1) {
+      for (int i = 0; i < 3; ++i) {
+        gyro[i] /= float(n);
+        acc[i] /= float(n);
+      }
+      float d[3] = {gyro_last[0] - gyro_init[0], gyro_last[1] - gyro_init[1], gyro_last[2] - gyro_init[2]}, t[3];
+      m3_vec(RT, d, t);
+      for (int i = 0; i < 3; ++i) dgyro[i] = t[i] / dt_s();
+    }
+    float rt[3];
+    m3_vec(RT, tc2i, rt);
+    for (int i = 0; i < 3; ++i) rt[i] = -rt[i];
+    cacc[0] = acc[0] + (dgyro[1] * rt[2] - dgyro[2] * rt[1]);
+    cacc[1] = acc[1] + (dgyro[2] * rt[0] - dgyro[0] * rt[2]);
+    cacc[2] = acc[2] + (dgyro[0] * rt[1] - dgyro[1] * rt[0]);
+    n = 0;
+    init_ts = 0;
+    last_ts = 0;
+  }
+};
+
+// SABEstimator::problem (sab_estimator.cpp:41-165): weighted least squares on the 11-vector F
+struct SabCfg {
+  float a_v[3], a_s[3], G, x_p[7], Rg;
+  M3 Rv, Rs;
+  Mat<7, 7> Pp;
+};
+inline void sab_problem(const SabCfg& cfg, Mat<7, 7>& JtJ, float JtF[7], const float X[7]) {
+  const float a = X[0];
+  const float g[3] = {X[1], X[2], X[3]}, b[3] = {X[4], X[5], X[6]};
+  float F[11];
+  for (int i = 0; i < 11; ++i) F[i] = 0;
+  const float ca = std::cos(a), sa = std::sin(a);
+  for (int i = 0; i < 3; ++i) F[i] = (cfg.a_s[i] + g[i]) * ca - cfg.a_v[i] * sa;
+  F[3] = vdot<3>(g, g) - cfg.G * cfg.G;
+  F[4] = X[0] - cfg.x_p[0];
+  if (F[4] > M_PI) F[4] -= 2.0 * M_PI;
+  else if (F[4] < -M_PI) F[4] += 2.0 * M_PI;
+  const M3 Rb = so3_exp(b);
+  float Rg3[3];
+  m3_vec(Rb, g, Rg3);
+  for (int i = 0; i < 3; ++i) F[5 + i] = Rg3[i] - cfg.x_p[1 + i];
+  for (int i = 0; i < 3; ++i) F[8 + i] = b[i] - cfg.x_p[4 + i];
+  float dFda[11];
+  for (int i = 0; i < 11; ++i) dFda[i] = 0;
+  for (int i = 0; i < 3; ++i) dFda[i] = -(cfg.a_s[i] + g[i]) * sa - cfg.a_v[i] * ca;
+  dFda[4] = 1.0;
+  Mat<11, 6> dFdx1 = Mat<11, 6>::zeros();
+  const float Gx[3][3] = {{0.0f, Rg3[2], -Rg3[1]}, {-Rg3[2], 0.0f, Rg3[0]}, {Rg3[1], -Rg3[0], 0.0f}};
+  for (int i = 0; i < 3; ++i) dFdx1.a[i][i] = ca;
+  for (int j = 0; j < 3; ++j) dFdx1.a[3][j] = 2.0 * g[j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      dFdx1.a[5 + i][j] = Rb.a[i][j];
+      dFdx1.a[5 + i][3 + j] = Gx[i][j];
+    }
+  for (int i = 0; i < 3; ++i) dFdx1.a[8 + i][3 + i] = 1.0f;
+  Mat<11, 11> P = Mat<11, 11>::zeros(), W = Mat<11, 11>::zeros(), dPda = Mat<11, 11>::zeros();
+  Mat<3, 3> Pz;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Pz.a[i][j] = sa * sa * cfg.Rv.a[i][j] + ca * ca * cfg.Rs.a[i][j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) P.a[i][j] = Pz.a[i][j];
+  P.a[3][3] = cfg.Rg;
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) P.a[4 + i][4 + j] = cfg.Pp.a[i][j];
+  const Mat<3, 3> Wz = chol_inv<3>(Pz);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) W.a[i][j] = Wz.a[i][j];
+  W.a[3][3] = 1.0 / cfg.Rg;
+  const Mat<7, 7> Wp = chol_inv<7>(cfg.Pp);
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) W.a[4 + i][4 + j] = Wp.a[i][j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) dPda.a[i][j] = 2.0 * sa * ca * (cfg.Rv.a[i][j] - cfg.Rs.a[i][j]);
+  Mat<11, 11> dWda = mmul(mmul(W, dPda), W);
+  for (int i = 0; i < 11; ++i)
+    for (int j = 0; j < 11; ++j) dWda.a[i][j] = -dWda.a[i][j];
+  // _JtJ(0,0) = 0.25*F*dWda*P*dWda*F + dFda*dWda*F + dFda*W*dFda
+  {
+    const Mat<11, 11> M = mmul(mmul(dWda, P), dWda);
+    JtJ.a[0][0] = 0.25 * quad<11>(F, M, F) + quad<11>(dFda, dWda, F) + quad<11>(dFda, W, dFda);
+  }
+  const Mat<6, 11> dT = mT(dFdx1);
+  {
+    float t1[11], t2[11], c1[6], c2[6];
+    mvec(dWda, F, t1);
+    mvec(W, dFda, t2);
+    mvec(dT, t1, c1);
+    mvec(dT, t2, c2);
+    for (int i = 0; i < 6; ++i) {
+      JtJ.a[1 + i][0] = 0.5 * c1[i] + c2[i];
+      JtJ.a[0][1 + i] = JtJ.a[1 + i][0];
+    }
+  }
+  {
+    const Mat<6, 6> B = mmul(mmul(dT, W), dFdx1);
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) JtJ.a[1 + i][1 + j] = B.a[i][j];
+  }
+  JtF[0] = 0.5 * quad<11>(F, dWda, F) + quad<11>(dFda, W, F);
+  {
+    float t[11], c[6];
+    mvec(W, F, t);
+    mvec(dT, t, c);
+    for (int i = 0; i < 6; ++i) JtF[1 + i] = c[i];
+  }
+}
+
+inline float sab_saturate(float t, float limit) { return (t > limit) ? limit : ((t < -limit) ? -limit : t); }
+
+// SABEstimator::gaussNewton (sab_estimator.cpp:21-39), SVD<7> in double
+inline int sab_gauss_newton(const SabCfg& cfg, float X[7], int iter_max) {
+  int i = 0;
+  for (; i < iter_max; ++i) {
+    Mat<7, 7> JtJ;
+    float JtF[7];
+    sab_problem(cfg, JtJ, JtF, X);
+    double A[49], b[7], h[7];
+    for (int r = 0; r < 7; ++r) {
+      b[r] = -(double)JtF[r];
+      for (int c2 = 0; c2 < 7; ++c2) A[r * 7 + c2] = (double)JtJ.a[r][c2];
+    }
+    sym_pinv_solve_d<7>(A, b, h);
+    for (int r = 0; r < 7; ++r) X[r] = (float)((double)X[r] + h[r]);  // _X += h with h a double vector
+    X[0] = std::atan2(std::sin(X[0]), std::cos(X[0]));
+    for (int r = 4; r < 7; ++r) X[r] = sab_saturate(X[r], 5e-1 / 25);
+    double nh = 0;
+    for (int r = 0; r < 7; ++r) nh += h[r] * h[r];
+    nh = std::sqrt(nh);
+    float nx = 0;
+    for (int r = 0; r < 7; ++r) nx += X[r] * X[r];
+    if (nh < 0.0 || nh / (std::sqrt(nx) + 1e-20) < 0.0) break;  // tolerances default to 0: never breaks early
+  }
+  return i;
+}
+
 // ---- scale space (scale_space.cpp) -------------------------------------------------------------
 struct BoxGaussian {
   int n = 3;
@@ -421,6 +775,7 @@ void box_average(int rows, int cols, int d, const float* ii, const float* div, f
 
 // ---- containers ---------------------------------------------------------------------------------
 struct orc_map {
+  IntImu imu;
   int rows = 0, cols = 0;
   uint64_t ts_us = 0;
   float threshold = -1.0f;  // edge_map.cpp:17
@@ -445,6 +800,21 @@ struct orc_ctx {
   // glue state (imu.hpp:171-187)
   float Bg[3];
   M3 W_Bg, RGBias, RGyro;
+  // full VIO glue state (rebvio.cpp:95-117, types/imu.hpp ImuState, sab_estimator.hpp State)
+  M3 R_c2i;
+  float t_c2i[3];
+  unsigned num_frames;
+  int initialized, num_gyro_init;
+  float gyro_init[3], g_init[3];
+  float Kscale, P_Kp;
+  float Pos[3], u_est[3];
+  M3 R_global;
+  float sabX[7], g_est[3], b_est[3];
+  Mat<7, 7> sabP;
+  M3 Qrot, Qg, Qbias, Rs, Rv;
+  float QKp, Rg_sab;
+  float Av[3], As[3];
+  float meanA[4][3];
   // estimateLs4Acceleration statics (core.cpp:287-293), per instance here
   float ls4_V[3], ls4_V0[3], ls4_V1[3], ls4_V2[3], ls4_V3[3], ls4_T[5], ls4_Dt[4];
 };
@@ -1510,3 +1880,277 @@ double orc_run_stream(orc_ctx* c, const uint8_t* frames, const int* idx, int nfr
 }
 
 }  // extern "C"
+
+// ---- full VIO glue (rebvio.cpp:92-293, core.cpp:335-414) ---------------------------------------------------------
+namespace {
+// ImuStateConfig defaults (types/imu.hpp:154-168)
+constexpr float kGNorm = 9.81, kGUnc = 2e-3, kGNormUnc = 0.2e3, kAccStd = 2.0e-3, kVbiasStd = 1e-7, kScaleStdInit = 1.2e-3;
+constexpr int kInitBiasFrameNum = 10;
+
+void mean_acceleration(orc_ctx* c, const float sacc[3], float acc[3], const M3& R) {
+  // Core::estimateMeanAcceleration (core.cpp:335-347)
+  M3 RT = m3_T(R);
+  m3_vec(RT, c->meanA[2], c->meanA[3]);
+  m3_vec(RT, c->meanA[1], c->meanA[2]);
+  m3_vec(RT, c->meanA[0], c->meanA[1]);
+  for (int i = 0; i < 3; ++i) c->meanA[0][i] = sacc[i];
+  for (int i = 0; i < 3; ++i) acc[i] = 0.25 * (((c->meanA[0][i] + c->meanA[1][i]) + c->meanA[2][i]) + c->meanA[3][i]);
+}
+
+// Core::estimateBias (core.cpp:350-414)
+float estimate_bias(orc_ctx* c, const float sacc[3], const float facc[3], float kP, const M3& Rot, const float Wvw[36],
+                    float Xvw[6]) {
+  float* X = c->sabX;
+  Mat<7, 7> F = Mat<7, 7>::zeros();
+  F.a[0][0] = kP;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) F.a[1 + i][1 + j] = Rot.a[j][i];
+  for (int i = 0; i < 3; ++i) F.a[4 + i][4 + i] = 1.0f;
+  const float G[3] = {X[1], X[2], X[3]};
+  M3 GProd;
+  const float gp[9] = {0.0f, G[2], -G[1], -G[2], 0.0f, G[0], G[1], -G[0], 0.0f};
+  GProd = m3_from(gp);
+  Mat<7, 7> Q = Mat<7, 7>::zeros();
+  const float tn = std::tan(X[0]);
+  Q.a[0][0] = c->QKp / (1.0 + tn * tn);
+  const M3 Qg2 = m3_add(m3_mul(m3_mul(m3_T(GProd), c->Qrot), GProd), c->Qg);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Q.a[1 + i][1 + j] = Qg2.a[i][j];
+      Q.a[4 + i][4 + j] = c->Qbias.a[i][j];
+    }
+  float Xp[7];
+  mvec(F, X, Xp);
+  for (int i = 0; i < 7; ++i) X[i] = Xp[i];
+  Mat<7, 7> Pp = mmul(mmul(F, c->sabP), mT(F));
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) Pp.a[i][j] = Pp.a[i][j] + Q.a[i][j];
+  SabCfg cfg;
+  for (int i = 0; i < 3; ++i) {
+    cfg.a_v[i] = facc[i];
+    cfg.a_s[i] = sacc[i];
+  }
+  cfg.G = kGNorm;
+  for (int i = 0; i < 7; ++i) cfg.x_p[i] = X[i];
+  cfg.Rv = c->Rv;
+  cfg.Rs = c->Rs;
+  cfg.Rg = c->Rg_sab;
+  cfg.Pp = Pp;
+  sab_gauss_newton(cfg, X, 20);
+  Mat<7, 7> JtJ;
+  float JtF[7];
+  sab_problem(cfg, JtJ, JtF, X);
+  c->sabP = chol_inv<7>(JtJ);
+  float k = std::tan(X[0]);
+  if (k < 0 || std::isnan(k) || std::isinf(k)) k = 0;
+  for (int i = 0; i < 3; ++i) {
+    c->g_est[i] = X[1 + i];
+    c->b_est[i] = X[4 + i];
+  }
+  M3 WVBias;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) WVBias.a[i][j] = JtJ.a[4 + i][4 + j];
+  float A6[36];
+  for (int i = 0; i < 36; ++i) A6[i] = 0.0f + Wvw[i];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) A6[(3 + i) * 6 + 3 + j] = WVBias.a[i][j] + Wvw[(3 + i) * 6 + 3 + j];
+  const float wc[3] = {Xvw[3] - c->b_est[0], Xvw[4] - c->b_est[1], Xvw[5] - c->b_est[2]};
+  float wx[3];
+  m3_vec(WVBias, wc, wx);
+  float rhs[6];
+  for (int i = 0; i < 6; ++i) {
+    float s2 = 0;
+    for (int k2 = 0; k2 < 6; ++k2) s2 += Wvw[i * 6 + k2] * Xvw[k2];
+    rhs[i] = s2 + ((i >= 3) ? wx[i - 3] : 0.0f);
+  }
+  float inv[36];
+  cholesky_inverse<6>(A6, inv);
+  for (int i = 0; i < 6; ++i) {
+    float s2 = 0;
+    for (int k2 = 0; k2 < 6; ++k2) s2 += inv[i * 6 + k2] * rhs[k2];
+    Xvw[i] = s2;
+  }
+  return k;
+}
+}  // namespace
+
+extern "C" void orc_vio_reset(orc_ctx* c, const float R_c2i[9], const float t_c2i[3]) {
+  orc_reset_state(c);
+  c->R_c2i = m3_from(R_c2i);
+  for (int i = 0; i < 3; ++i) c->t_c2i[i] = t_c2i[i];
+  c->num_frames = 0;
+  c->initialized = 0;
+  c->num_gyro_init = 0;
+  for (int i = 0; i < 3; ++i) c->gyro_init[i] = c->g_init[i] = c->Pos[i] = c->Av[i] = c->As[i] = c->g_est[i] = c->b_est[i] = 0;
+  c->Kscale = 1.0;
+  c->P_Kp = 5e-6;
+  c->u_est[0] = 1; c->u_est[1] = 0; c->u_est[2] = 0;
+  c->R_global = m3_identity();
+  // SABEstimator::State (sab_estimator.hpp:50-64)
+  const float x0[7] = {(float)M_PI_4, 0.0f, kGNorm, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = 0; i < 7; ++i) c->sabX[i] = x0[i];
+  c->sabP = Mat<7, 7>::zeros();
+  const float pd[7] = {kScaleStdInit * kScaleStdInit, 100.0f, 100.0f, 100.0f, (float)(kVbiasStd * kVbiasStd * 1e1),
+                       (float)(kVbiasStd * kVbiasStd * 1e1), (float)(kVbiasStd * kVbiasStd * 1e1)};
+  for (int i = 0; i < 7; ++i) c->sabP.a[i][i] = pd[i];
+  c->Qg = m3_scale(m3_identity(), kGUnc * kGUnc);
+  c->Rg_sab = kGNormUnc * kGNormUnc;
+  c->Rs = m3_scale(m3_identity(), kAccStd * kAccStd);
+  c->Qbias = m3_scale(m3_identity(), kVbiasStd * kVbiasStd);
+  c->Qrot = m3_identity();
+  c->Rv = m3_identity();
+  c->QKp = 5e-6;
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 3; ++i) c->meanA[k][i] = 0;
+}
+
+extern "C" void orc_vio_add_imu(orc_ctx* c, orc_map* m, uint64_t ts_us, const float gyro[3], const float acc[3]) {
+  m->imu.add(ts_us, gyro, acc, c->R_c2i);
+}
+
+extern "C" int orc_vio_step(orc_ctx* c, orc_map* old_map, orc_map* new_map, orc_vio_out* out) {
+  const orc_params& P = c->p;
+  std::memset(out, 0, sizeof(*out));
+  orc_pair_out* po = &out->pair;
+  const float FMAX = std::numeric_limits<float>::max();
+  M3 P_V = m3_scale(m3_identity(), FMAX), P_W = m3_scale(m3_identity(), FMAX);
+  orc_build_distance_field(c, new_map);  // rebvio.cpp:142
+
+  IntImu& imu = new_map->imu;  // rebvio.cpp:145-160
+  imu.get(c->R_c2i, c->t_c2i);
+  if (!c->initialized && c->num_frames > 0) {
+    for (int i = 0; i < 3; ++i) {
+      c->gyro_init[i] += imu.gyro[i] * imu.dt_s();
+      c->g_init[i] -= imu.cacc[i];
+    }
+    if (++c->num_gyro_init > kInitBiasFrameNum) {
+      for (int i = 0; i < 3; ++i) c->Bg[i] = c->gyro_init[i] / c->num_gyro_init;
+      c->W_Bg = m3_invert(m3_scale(c->RGBias, 1e2f));
+      for (int i = 0; i < 3; ++i) c->sabX[1 + i] = c->g_init[i] / c->num_gyro_init;
+      c->initialized = 1;
+    }
+  }
+  M3 R = imu.R;  // rebvio.cpp:163-165
+  R = m3_T(m3_mul(so3_exp(c->Bg), m3_T(R)));
+  {
+    float RT[9];
+    m3_to(m3_T(R), RT);
+    orc_rotate_keylines(c, old_map, RT);
+  }
+  float Vg[3] = {0, 0, 0};
+  M3 P_Vg;
+  po->F = minimize_vel(c, old_map, Vg, P_Vg, &po->lm_accept_mask, &po->sigma_rho_min);
+  forward_match(old_map, new_map);
+  float Xv[6], W_Xv[36];
+  po->ext_ok = ext_rot_vel(c, Vg, W_Xv, Xv, nullptr);
+  float Xgv[6], W_Xgv[36];
+  std::memcpy(Xgv, Xv, sizeof(Xv));
+  std::memcpy(W_Xgv, W_Xv, sizeof(W_Xv));
+  const float frame_dt = float(new_map->ts_us - old_map->ts_us) / 1000000.0;  // rebvio.cpp:183
+  const float s_b = P.gyro_bias_std_dev * P.gyro_bias_std_dev * frame_dt * frame_dt;
+  const float s_g = P.gyro_std_dev * P.gyro_std_dev * frame_dt * frame_dt;
+  c->RGBias = m3_scale(m3_identity(), s_b);
+  c->RGyro = m3_scale(m3_identity(), s_g);
+  float dg[3];
+  gyro_bias_correction(Xgv, W_Xgv, c->W_Bg, c->RGyro, c->RGBias, dg);
+  for (int i = 0; i < 3; ++i) c->Bg[i] += dg[i];
+  const float dVgv[3] = {Xgv[0], Xgv[1], Xgv[2]}, dWgv[3] = {Xgv[3], Xgv[4], Xgv[5]};
+  M3 Rgva = R;  // rebvio.cpp:196 (before the visual correction)
+  const M3 R0 = so3_exp(dWgv);
+  R = m3_T(m3_mul(R0, m3_T(R)));
+  float Vgv[3];
+  m3_vec(R0, Vg, Vgv);
+  for (int i = 0; i < 3; ++i) Vgv[i] += dVgv[i];
+  float V[3] = {Vgv[0], Vgv[1], Vgv[2]};
+  float R_Xgv[36];
+  cholesky_inverse<6>(W_Xgv, R_Xgv);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      P_V.a[i][j] = R_Xgv[i * 6 + j];
+      P_W.a[i][j] = R_Xgv[(3 + i) * 6 + 3 + j];
+    }
+  // rebvio.cpp:206-208
+  {
+    float negv[3] = {-Vgv[0] / frame_dt, -Vgv[1] / frame_dt, -Vgv[2] / frame_dt}, Rr[9];
+    m3_to(R, Rr);
+    orc_estimate_ls4_acceleration(c, negv, c->Av, Rr, frame_dt);
+    mean_acceleration(c, imu.cacc, c->As, R);
+  }
+  float Xgva[6];
+  std::memcpy(Xgva, Xgv, sizeof(Xgv));
+  {
+    const float d4 = frame_dt * frame_dt * frame_dt * frame_dt;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) c->Rv.a[i][j] = P_V.a[i][j] / d4;
+  }
+  c->Qrot = P_W;
+  c->QKp = c->P_Kp;
+  float Vgva[3];
+  if (c->num_frames > 4u + (unsigned)kInitBiasFrameNum) {  // rebvio.cpp:213-224
+    out->sab_active = 1;
+    c->Kscale = estimate_bias(c, c->As, c->Av, 1.0f, R, W_Xgv, Xgva);
+    const float dVgva[3] = {Xgva[0], Xgva[1], Xgva[2]}, dWgva[3] = {Xgva[3], Xgva[4], Xgva[5]};
+    const M3 R0gva = so3_exp(dWgva);
+    Rgva = m3_T(m3_mul(R0gva, m3_T(Rgva)));
+    m3_vec(R0gva, Vg, Vgva);
+    for (int i = 0; i < 3; ++i) Vgva[i] += dVgva[i];
+    for (int i = 0; i < 3; ++i) V[i] = Vgva[i];
+    float r[9];
+    m3_to(R0gva, r);
+    orc_rotate_keylines(c, old_map, r);
+  } else {  // rebvio.cpp:225-233
+    Rgva = R;
+    for (int i = 0; i < 3; ++i) Vgva[i] = Vgv[i];
+    float r[9];
+    m3_to(R0, r);
+    orc_rotate_keylines(c, old_map, r);
+  }
+  for (int i = 0; i < 3; ++i) { po->Vg[i] = Vg[i]; po->V[i] = V[i]; }
+  m3_to(P_Vg, po->P_Vg);
+  std::memcpy(po->Xv, Xv, sizeof(Xv));
+  std::memcpy(po->W_Xv, W_Xv, sizeof(W_Xv));
+  std::memcpy(po->Xgv, Xgv, sizeof(Xgv));
+  m3_to(Rgva, po->R);
+  m3_to(P_V, po->P_V);
+  if (std::isnan(V[0]) || std::isnan(V[1]) || std::isnan(V[2])) {  // rebvio.cpp:236-241
+    c->P_Kp = FMAX;
+    po->status = 1;
+  } else {
+    po->klm_num = directed_match(c, new_map, old_map, V, P_V, Rgva, &po->kf_matches, P.search_range);
+    if ((unsigned)po->klm_num < P.global_min_matches_threshold) {  // rebvio.cpp:247-252
+      c->P_Kp = FMAX;
+      po->status = 2;
+    } else {
+      po->reg_num = orc_regularize(new_map);
+      orc_update_inverse_depth(c, V);
+    }
+  }
+  if (c->num_frames > 4u + (unsigned)kInitBiasFrameNum) {  // rebvio.cpp:263-271
+    float u[3];
+    m3_vec(m3_T(Rgva), c->u_est, u);
+    const float k = vdot<3>(u, c->g_est) / vdot<3>(c->g_est, c->g_est);
+    for (int i = 0; i < 3; ++i) u[i] = u[i] - k * c->g_est[i];
+    const float nu = std::sqrt(vdot<3>(u, u));
+    for (int i = 0; i < 3; ++i) c->u_est[i] = u[i] / nu;
+    const float ey[3] = {0.0f, 1.0f, 0.0f}, ex[3] = {1.0f, 0.0f, 0.0f};
+    const M3 R1 = so3_from_two(c->g_est, ey);
+    float r1u[3];
+    m3_vec(R1, c->u_est, r1u);
+    const M3 R2 = so3_from_two(r1u, ex);
+    c->R_global = m3_mul(R2, R1);
+    float d[3];
+    m3_vec(c->R_global, Vgva, d);
+    for (int i = 0; i < 3; ++i) c->Pos[i] += -d[i] * c->Kscale;
+  }
+  so3_ln(c->R_global, out->orientation);
+  for (int i = 0; i < 3; ++i) {
+    out->position[i] = c->Pos[i];
+    out->g_est[i] = c->g_est[i];
+    out->b_est[i] = c->b_est[i];
+    out->Bg[i] = c->Bg[i];
+  }
+  out->K = c->Kscale;
+  out->initialized = c->initialized;
+  ++c->num_frames;
+  return po->status;
+}

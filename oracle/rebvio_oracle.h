@@ -131,6 +131,23 @@ void orc_reset_state(orc_ctx* c);
 int orc_track_pair(orc_ctx* c, orc_map* old_map, orc_map* new_map, const float* R_prior, float frame_dt,
                    orc_pair_out* out);
 
+/* ---- full VIO glue (SURVEY.md N2 / BASELINE config 5): rebvio.cpp:92-293 with IMU pre-integration (types/imu.hpp),
+ * gyro-bias initialisation, Core::estimateBias + SABEstimator (core.cpp:350-414, sab_estimator.cpp) and pose integration.
+ * IMU samples: ts[us], gyro[3], acc[3] in the IMU frame; R_c2i / t_c2i = camera->IMU extrinsics (camera.hpp:41-45). */
+typedef struct orc_vio_out {
+  orc_pair_out pair;
+  float orientation[3]; /* so3 log of R_global (odometry.orientation) */
+  float position[3];
+  float K;              /* scale tan(X[0]) */
+  float g_est[3], b_est[3], Bg[3];
+  int initialized;      /* imu_state_.initialized */
+  int sab_active;       /* estimateBias branch taken this frame */
+} orc_vio_out;
+void orc_vio_reset(orc_ctx* c, const float R_c2i[9], const float t_c2i[3]);
+/* attach the IMU samples with ts <= the map's frame timestamp to `m` (rebvio.cpp:77-84) */
+void orc_vio_add_imu(orc_ctx* c, orc_map* m, uint64_t ts_us, const float gyro[3], const float acc[3]);
+int orc_vio_step(orc_ctx* c, orc_map* old_map, orc_map* new_map, orc_vio_out* out);
+
 /* host glue pieces exposed for KATs */
 void orc_ls4_reset(orc_ctx* c);
 void orc_estimate_ls4_acceleration(orc_ctx* c, const float vel[3], float acc[3], const float R[9], float dt);

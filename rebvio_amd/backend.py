@@ -46,6 +46,12 @@ class PairOut(C.Structure):
         ("reg_num", C.c_int), ("lm_accept_mask", C.c_int), ("status", C.c_int)]
 
 
+class PairMid(C.Structure):
+    _fields_ = [("Vg", C.c_float * 3), ("P_Vg", C.c_float * 9), ("F", C.c_float), ("sigma_rho_min", C.c_float),
+                ("lm_accept_mask", C.c_int), ("ext_ok", C.c_int), ("Xv", C.c_float * 6), ("W_Xv", C.c_float * 36),
+                ("Xgv", C.c_float * 6), ("W_Xgv", C.c_float * 36), ("R", C.c_float * 9)]
+
+
 # every symbol include/rebvio_hip.h declares: (restype, argtypes)
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
@@ -81,6 +87,8 @@ SIGNATURES = {
     "rebvio_hip_get_gyro_state": (C.c_int, [_vp, _fp, _fp]),
     "rebvio_hip_set_gyro_state": (C.c_int, [_vp, _fp, _fp]),
     "rebvio_hip_track_pair": (C.c_int, [_vp, _vp, _vp, _fp, C.c_float, C.POINTER(PairOut)]),
+    "rebvio_hip_track_pair_begin": (C.c_int, [_vp, _vp, _vp, _fp, C.c_float, C.POINTER(PairMid)]),
+    "rebvio_hip_track_pair_finish": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _fp, _ip, _ip, _ip, _ip]),
     "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_flush": (C.c_int, [_vp]),
     "rebvio_hip_profile_enable": (C.c_int, [_vp, C.c_int]),

@@ -1157,6 +1157,79 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   return 0;
 }
 
+int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float* R_prior, float frame_dt,
+                                rebvio_hip_pair_mid* mid) {
+  HIPCHK(hipSetDevice(c->device));
+  std::memset(mid, 0, sizeof(*mid));
+  hipStream_t s = c->s_trk;
+  wait_enqueued(om);
+  wait_enqueued(nm);
+  HIPCHK(hipStreamWaitEvent(s, om->ready, 0));
+  HIPCHK(hipStreamWaitEvent(s, nm->ready, 0));
+  int rc = rebvio_hip_build_distance_field(c, nm);
+  if (rc) return rc;
+  const hm::M3 R = prior_rotation(c, R_prior);
+  float RT[9];
+  hm::store3(hm::transpose(R), RT);
+  launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+  const float v0[3] = {0, 0, 0};
+  enqueue_lm_chain(c, om, nm, v0);
+  const int calls = (int)c->P.iterations + 1;
+  PairSlot* slot = c->slot[0];
+  launch_ext_rot_vel(s, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
+                     c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, v0, slot, c->hist);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  nm->n_host = slot->new_st.n;
+  nm->thr_host = slot->new_st.threshold;
+  lm_to_out(slot->lm, mid->Vg, mid->P_Vg, &mid->F, &mid->lm_accept_mask, &mid->sigma_rho_min);
+  float JtF6[6];
+  sum_xrv(slot->xrv, div_up(nm->n_host, 256), mid->W_Xv, JtF6, nullptr);
+  hm::sym6_solve(mid->W_Xv, JtF6, mid->Xv);
+  mid->ext_ok = 1;
+  for (int i = 0; i < 6; ++i)
+    if (std::isnan(mid->Xv[i])) mid->ext_ok = 0;
+  std::memcpy(mid->Xgv, mid->Xv, sizeof(mid->Xv));
+  std::memcpy(mid->W_Xgv, mid->W_Xv, sizeof(mid->W_Xv));
+  const float s_b = c->P.gyro_bias_std_dev * c->P.gyro_bias_std_dev * frame_dt * frame_dt;
+  const float s_g = c->P.gyro_std_dev * c->P.gyro_std_dev * frame_dt * frame_dt;
+  c->RGBias = hm::diag3(s_b);
+  c->RGyro = hm::diag3(s_g);
+  float dg[3];
+  hm::gyro_bias_correction(mid->Xgv, mid->W_Xgv, c->W_Bg, c->RGyro, c->RGBias, dg);
+  for (int i = 0; i < 3; ++i) c->Bg[i] += dg[i];
+  hm::store3(R, mid->R);
+  return 0;
+}
+
+int rebvio_hip_track_pair_finish(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float V[3], const float P_V[9],
+                                 const float Rgva[9], const float R_second[9], int* klm_num, int* kf_matches, int* reg_num,
+                                 int* status) {
+  HIPCHK(hipSetDevice(c->device));
+  GlueOut g;
+  std::memcpy(g.V, V, sizeof(g.V));
+  std::memcpy(g.P_V, P_V, sizeof(g.P_V));
+  std::memcpy(g.Rgva, Rgva, sizeof(g.Rgva));
+  std::memcpy(g.R0a, R_second, sizeof(g.R0a));
+  g.nan_v = std::isnan(V[0]) || std::isnan(V[1]) || std::isnan(V[2]);
+  if (klm_num) *klm_num = 0;
+  if (kf_matches) *kf_matches = 0;
+  if (reg_num) *reg_num = 0;
+  enqueue_b_chain(c, om, nm, g, nullptr);
+  HIPCHK(hipGetLastError());
+  if (g.nan_v) {
+    if (status) *status = 1;
+    return 0;
+  }
+  HIPCHK(hipMemcpyAsync(&c->h_st[1], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  if (klm_num) *klm_num = c->h_st[1].dm_matches;
+  if (kf_matches) *kf_matches = c->h_st[1].dm_kf;
+  if (reg_num) *reg_num = c->h_st[1].reg_count;
+  if (status) *status = ((unsigned)c->h_st[1].dm_matches < c->P.global_min_matches_threshold) ? 2 : 0;
+  return 0;
+}
+
 namespace {
 int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   hipStream_t s = c->s_trk;

@@ -1,9 +1,12 @@
 // Drives rebvio::Rebvio exactly the way ros_rebvio does (ros_rebvio/src/ros_rebvio.cpp:15-82): register an odometry
 // and an edge-image callback, push MONO8 frames (and optionally IMU samples), print "ts wx wy wz px py pz" lines in
 // the format of the reference's golden odometry file.
-//   rebvio_stream_example frames.u8 width height n_frames [fm cx cy keylines_ref keylines_max]
+//   rebvio_stream_example frames.u8 width height n_frames [fm cx cy keylines_ref keylines_max [imu.bin [min_matches]]]
+// imu.bin: records of {int64 ts_us, float gyro[3], float acc[3]} (32 bytes); without it a still 200 Hz IMU is synthesised.
+// Each line carries, after the reference's seven columns, the scale K, gravity estimate, gyro bias and match count.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <mutex>
 #include <vector>
@@ -29,14 +32,38 @@ int main(int argc, char** argv) {
   if (argc > 8) config.edge_detector.keylines_ref = std::atoi(argv[8]);
   if (argc > 9) config.edge_detector.keylines_max = std::atoi(argv[9]);
   if (W * H < 640 * 480) config.core.global_min_matches_threshold = 50;
+  if (argc > 11) config.core.global_min_matches_threshold = (unsigned)std::atoi(argv[11]);
+  struct ImuRec {
+    long long ts;
+    float gyro[3], acc[3];
+    int pad;
+  };
+  static_assert(sizeof(ImuRec) == 40 || sizeof(ImuRec) == 32, "record layout");
+  std::vector<ImuRec> imu;
+  if (argc > 10 && argv[10][0] != '-') {
+    std::ifstream fi(argv[10], std::ios::binary);
+    char rec[32];
+    while (fi.read(rec, 32)) {
+      ImuRec r;
+      std::memcpy(&r.ts, rec, 8);
+      std::memcpy(r.gyro, rec + 8, 12);
+      std::memcpy(r.acc, rec + 20, 12);
+      imu.push_back(r);
+    }
+    if (imu.empty()) {
+      std::fprintf(stderr, "cannot read %s\n", argv[10]);
+      return 2;
+    }
+  }
 
   rebvio::Rebvio rebvio(config);
   std::mutex mu;
   int n_odo = 0, n_edge = 0, last_keylines = 0;
   rebvio.registerOdometryCallback([&](rebvio::types::Odometry& o) {
     std::lock_guard<std::mutex> g(mu);
-    std::printf("%llu %.6f %.6f %.6f %.6f %.6f %.6f\n", (unsigned long long)o.ts_us, o.orientation[0], o.orientation[1],
-                o.orientation[2], o.position[0], o.position[1], o.position[2]);
+    std::printf("%llu %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.5f %.5f %.5f %.7f %.7f %.7f %d\n", (unsigned long long)o.ts_us,
+                o.orientation[0], o.orientation[1], o.orientation[2], o.position[0], o.position[1], o.position[2], o.scale,
+                o.gravity[0], o.gravity[1], o.gravity[2], o.gyro_bias[0], o.gyro_bias[1], o.gyro_bias[2], o.klm_num);
     ++n_odo;
   });
   rebvio.registerEdgeImageCallback([&](cv::Mat& img, rebvio::EdgeMap::SharedPtr& map) {
@@ -46,10 +73,16 @@ int main(int argc, char** argv) {
     if (last_keylines > 0) (void)(*map)[0].pos[0];
     (void)img;
   });
+  size_t k_imu = 0;
   for (int i = 0; i < N; ++i) {
     cv::Mat frame(H, W, CV_8UC1, buf.data() + (size_t)i * W * H);
+    // samples up to this frame's stamp are queued before the frame, as a time-ordered bag replay delivers them
+    for (; k_imu < imu.size() && (uint64_t)imu[k_imu].ts <= (uint64_t)i * 50000ull; ++k_imu)
+      rebvio.imuCallback(rebvio::types::Imu{(uint64_t)imu[k_imu].ts,
+                                            TooN::makeVector(imu[k_imu].gyro[0], imu[k_imu].gyro[1], imu[k_imu].gyro[2]),
+                                            TooN::makeVector(imu[k_imu].acc[0], imu[k_imu].acc[1], imu[k_imu].acc[2])});
     rebvio.imageCallback(rebvio::types::Image{(uint64_t)i * 50000ull, frame.clone()});
-    for (int k = 0; k < 10; ++k)  // 200 Hz IMU next to the 20 Hz camera: a still gyro, gravity on y
+    for (int k = 0; imu.empty() && k < 10; ++k)  // 200 Hz IMU next to the 20 Hz camera: a still gyro, gravity on y
       rebvio.imuCallback(rebvio::types::Imu{(uint64_t)i * 50000ull + (uint64_t)k * 5000ull + 1ull, TooN::makeVector(0.0f, 0.0f, 0.0f),
                                             TooN::makeVector(0.0f, 9.81f, 0.0f)});
   }

@@ -2,17 +2,22 @@
 // (rebvio.cpp:17-313): the caller thread converts/undistorts and queues images; worker 1 detects edges and attaches the
 // pre-integrated IMU data; worker 2 runs one tracking step per frame pair and publishes odometry.
 //
-// Differences, stated once: (i) the frame-pair step is ONE call into the backend (rebvio_hip_track_pair: distance
-// field, rotate, minimizeVel, forwardMatch, extRotVel, gyroBiasCorrection, rotate, directedMatch, regularize, depth
-// EKF - rebvio.cpp:142-259); (ii) the accelerometer / scale-attitude-bias fusion (estimateBias + SABEstimator,
-// rebvio.cpp:206-224) is not built yet: the branch of rebvio.cpp:225-233 is always taken, scale K = 1
-// and the global attitude is integrated from the gyro/visual rotation alone; (iii) the reference's latent races
-// (unlocked queue peeks, plain-bool run flag) are not inherited.
+// The frame-pair step is TWO calls into the backend with the O(1) inertial fusion between them:
+//   rebvio_hip_track_pair_begin  - distance field, rotate by the gyro prior, minimizeVel, forwardMatch, extRotVel,
+//                                  gyroBiasCorrection (rebvio.cpp:142-192)
+//   host                         - Ls4 / mean acceleration, Core::estimateBias + SABEstimator, second rotation
+//                                  (rebvio.cpp:195-233)
+//   rebvio_hip_track_pair_finish - rotate, directedMatch, regularize, depth EKF (rebvio.cpp:222-259)
+// followed by the gravity-aligned pose integration (rebvio.cpp:263-271). The reference's latent races (unlocked queue
+// peeks, plain-bool run flag) are not inherited.
 #include "rebvio/rebvio.hpp"
 
 #include <chrono>
+#include <cmath>
 #include <iostream>
+#include <limits>
 
+#include "../csrc/hostmath.hpp"
 #include "rebvio/util/log.hpp"
 #include "session.hpp"
 
@@ -28,7 +33,8 @@ Rebvio::Rebvio(rebvio::RebvioConfig& config)
     : config_((ScopeOpener(config.device_id), config)), run_(true), num_frames_(0), num_detected_(0), num_images_(0),
       camera_(config.camera),
       edge_detector_(std::make_shared<rebvio::Camera>(camera_), std::make_shared<rebvio::EdgeDetectorConfig>(config.edge_detector)),
-      core_(std::make_shared<rebvio::Camera>(camera_), std::make_shared<rebvio::CoreConfig>(config.core)) {
+      core_(std::make_shared<rebvio::Camera>(camera_), std::make_shared<rebvio::CoreConfig>(config.core)),
+      sab_state_(config_.imu_state) {
   core_.session()->setImuNoise(config_.imu_state.gyro_std_dev, config_.imu_state.gyro_bias_std_dev);
   core_.session()->ctx();  // create the device context now: fail loudly here, not in a worker thread
   data_acquisition_thread_ = std::thread(&Rebvio::dataAcquisitionProcess, this);
@@ -107,10 +113,25 @@ void Rebvio::dataAcquisitionProcess() {
 void Rebvio::stateEstimationProcess() {
   REBVIO_INFO("Starting State Estimation Process..");
   rebvio_hip_ctx* ctx = core_.session()->ctx();
+  const types::Float FMAX = std::numeric_limits<types::Float>::max();
   types::Vector3f Pos = TooN::Zeros;
   types::Matrix3f R_global = TooN::Identity;
+  types::Float K = 1.0;
+  types::Float P_Kp = 5e-6;
   int num_gyro_init = 0;
   types::Vector3f gyro_init = TooN::Zeros;
+  types::Vector3f g_init = TooN::Zeros;
+
+  auto load3 = [](const float* p) {
+    types::Matrix3f m;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) m(i, j) = p[i * 3 + j];
+    return m;
+  };
+  auto store3 = [](const types::Matrix3f& m, float* p) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) p[i * 3 + j] = m(i, j);
+  };
 
   while (run_) {
     rebvio::EdgeMap::SharedPtr new_edge_map, old_edge_map;
@@ -127,14 +148,19 @@ void Rebvio::stateEstimationProcess() {
       continue;
     }
 
+    types::Matrix3f P_V = TooN::Identity * FMAX, P_W = TooN::Identity * FMAX;
+
     // IMU state initialisation (rebvio.cpp:145-160)
     const rebvio::types::IntegratedImu& imu = new_edge_map->imu().get(camera_.getRc2i(), camera_.getTc2i());
     if (!imu_state_.initialized && num_frames_ > 0) {
       if (config_.imu_state.init_bias > 0) {
         gyro_init += imu.gyro() * imu.dt_s();
+        g_init -= imu.cacc();
         if (++num_gyro_init > config_.imu_state.init_bias_frame_num) {
           imu_state_.Bg = gyro_init / types::Float(num_gyro_init);
           imu_state_.W_Bg = types::invert(imu_state_.RGBias * types::Float(1e2));
+          const types::Vector3f g0 = g_init / types::Float(num_gyro_init);
+          for (int i = 0; i < 3; ++i) sab_state_.X[1 + i] = g0[i];
           imu_state_.initialized = true;
         }
       } else {
@@ -143,50 +169,119 @@ void Rebvio::stateEstimationProcess() {
       }
       if (imu_state_.initialized) {
         float bg[3] = {imu_state_.Bg[0], imu_state_.Bg[1], imu_state_.Bg[2]}, wb[9];
-        for (int i = 0; i < 3; ++i)
-          for (int j = 0; j < 3; ++j) wb[i * 3 + j] = imu_state_.W_Bg(i, j);
+        store3(imu_state_.W_Bg, wb);
         rebvio_hip_set_gyro_state(ctx, bg, wb);
       }
     }
 
+    // first half on the device (rebvio.cpp:142-192)
     float Rp[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Rp[i * 3 + j] = imu.R()(i, j);
+    store3(imu.R(), Rp);
     const types::Float frame_dt = types::Float(new_edge_map->ts_us() - old_edge_map->ts_us()) / 1000000.0;
-    rebvio_hip_pair_out out;
-    backend::check("rebvio_hip_track_pair", rebvio_hip_track_pair(ctx, old_edge_map->handle(), new_edge_map->handle(), Rp, frame_dt, &out));
-    old_edge_map->invalidateMirror();
-    new_edge_map->invalidateMirror();
+    rebvio_hip_pair_mid mid;
+    backend::check("rebvio_hip_track_pair_begin",
+                   rebvio_hip_track_pair_begin(ctx, old_edge_map->handle(), new_edge_map->handle(), Rp, frame_dt, &mid));
     {
       float bg[3], wb[9];
       rebvio_hip_get_gyro_state(ctx, bg, wb);
       imu_state_.Bg = TooN::makeVector(bg[0], bg[1], bg[2]);
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) imu_state_.W_Bg(i, j) = wb[i * 3 + j];
+      imu_state_.W_Bg = load3(wb);
     }
-    imu_state_.Vg = TooN::makeVector(out.Vg[0], out.Vg[1], out.Vg[2]);
-    imu_state_.Vgva = TooN::makeVector(out.V[0], out.V[1], out.V[2]);
+    // the noise models the backend applied in gyroBiasCorrection (rebvio.cpp:186-187); RGBias feeds next frame's W_Bg init
+    imu_state_.RGBias = TooN::Identity * (double)(config_.imu_state.gyro_bias_std_dev * config_.imu_state.gyro_bias_std_dev * frame_dt * frame_dt);
+    imu_state_.RGyro = TooN::Identity * (double)(config_.imu_state.gyro_std_dev * config_.imu_state.gyro_std_dev * frame_dt * frame_dt);
+    imu_state_.Vg = TooN::makeVector(mid.Vg[0], mid.Vg[1], mid.Vg[2]);
+    imu_state_.P_Vg = load3(mid.P_Vg);
+    types::Vector6f Xgv, Xgva;
+    types::Matrix6f W_Xgv;
+    for (int i = 0; i < 6; ++i) {
+      Xgv[i] = mid.Xgv[i];
+      for (int j = 0; j < 6; ++j) W_Xgv(i, j) = mid.W_Xgv[i * 6 + j];
+    }
+    imu_state_.dVgv = Xgv.slice<0, 3>();
+    imu_state_.dWgv = Xgv.slice<3, 3>();
 
-    if (out.status == 1) {  // rebvio.cpp:236-241
+    // rebvio.cpp:195-203
+    types::Matrix3f R = load3(mid.R);
+    types::Matrix3f Rgva = R;
+    const types::Matrix3f R0 = TooN::SO3<types::Float>(imu_state_.dWgv).get_matrix();
+    R = (R0 * R.T()).T();
+    imu_state_.Vgv = R0 * imu_state_.Vg + imu_state_.dVgv;
+    {
+      float A6[36], inv[36];
+      for (int i = 0; i < 36; ++i) A6[i] = mid.W_Xgv[i];
+      rh::hm::cholesky6_inverse(A6, inv);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          P_V(i, j) = inv[i * 6 + j];
+          P_W(i, j) = inv[(3 + i) * 6 + 3 + j];
+        }
+    }
+
+    // rebvio.cpp:206-209
+    core_.estimateLs4Acceleration(-imu_state_.Vgv / frame_dt, imu_state_.Av, R, frame_dt);
+    core_.estimateMeanAcceleration(imu.cacc(), imu_state_.As, R);
+    Xgva = Xgv;
+    sab_state_.Rv = P_V / (frame_dt * frame_dt * frame_dt * frame_dt);
+    sab_state_.Qrot = P_W;
+    sab_state_.QKp = P_Kp;
+
+    types::Matrix3f R_second;
+    if (num_frames_ > 4u + (unsigned)config_.imu_state.init_bias_frame_num) {  // rebvio.cpp:210-224
+      K = core_.estimateBias(imu_state_.As, imu_state_.Av, 1.0, R, sab_state_.X, sab_state_.P, sab_state_.Qg, sab_state_.Qrot,
+                             sab_state_.Qbias, sab_state_.QKp, sab_state_.Rg, sab_state_.Rs, sab_state_.Rv, sab_state_.g_est,
+                             sab_state_.b_est, W_Xgv, Xgva, config_.imu_state.g_norm);
+      imu_state_.dVgva = Xgva.slice<0, 3>();
+      imu_state_.dWgva = Xgva.slice<3, 3>();
+      const types::Matrix3f R0gva = TooN::SO3<types::Float>(imu_state_.dWgva).get_matrix();
+      Rgva = (R0gva * Rgva.T()).T();
+      imu_state_.Vgva = R0gva * imu_state_.Vg + imu_state_.dVgva;
+      R_second = R0gva;
+    } else {  // rebvio.cpp:225-233
+      Rgva = R;
+      imu_state_.Vgva = imu_state_.Vgv;
+      R_second = R0;
+    }
+
+    // second half on the device (rebvio.cpp:222/232, 236-259)
+    float V[3] = {imu_state_.Vgva[0], imu_state_.Vgva[1], imu_state_.Vgva[2]}, pv[9], rg[9], r2[9];
+    store3(P_V, pv);
+    store3(Rgva, rg);
+    store3(R_second, r2);
+    int klm_num = 0, kf_matches = 0, reg_num = 0, status = 0;
+    backend::check("rebvio_hip_track_pair_finish", rebvio_hip_track_pair_finish(ctx, old_edge_map->handle(), new_edge_map->handle(), V,
+                                                                                pv, rg, r2, &klm_num, &kf_matches, &reg_num, &status));
+    old_edge_map->invalidateMirror();
+    new_edge_map->invalidateMirror();
+    if (status == 1) {  // rebvio.cpp:236-241
+      P_Kp = FMAX;
       std::cerr << "Minimization Error occured!\n";
       run_ = false;
-    } else if (out.status == 2) {  // rebvio.cpp:247-252
+    } else if (status == 2) {  // rebvio.cpp:247-252
+      P_Kp = FMAX;
       std::cerr << "Insufficient number of keylines matches!\n";
       run_ = false;
     }
 
-    // incremental pose (rebvio.cpp:263-271 without the gravity-aligned frame of the SAB filter)
+    // gravity-aligned pose integration (rebvio.cpp:263-271)
     if (num_frames_ > 4u + (unsigned)config_.imu_state.init_bias_frame_num) {
-      types::Matrix3f Rgva;
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Rgva(i, j) = out.R[i * 3 + j];
-      R_global = R_global * Rgva.T();
-      Pos += -(R_global * imu_state_.Vgva);
+      imu_state_.u_est = Rgva.T() * imu_state_.u_est;
+      imu_state_.u_est =
+          imu_state_.u_est - (imu_state_.u_est * sab_state_.g_est) / (sab_state_.g_est * sab_state_.g_est) * sab_state_.g_est;
+      imu_state_.u_est = imu_state_.u_est / std::sqrt(imu_state_.u_est * imu_state_.u_est);
+      const types::Matrix3f R1 = TooN::SO3<types::Float>(sab_state_.g_est, TooN::makeVector(0.0f, 1.0f, 0.0f)).get_matrix();
+      const types::Matrix3f R2 = TooN::SO3<types::Float>(R1 * imu_state_.u_est, TooN::makeVector(1.0f, 0.0f, 0.0f)).get_matrix();
+      R_global = R2 * R1;
+      Pos += -(R_global * imu_state_.Vgva) * K;
     }
     types::Odometry odometry;
     odometry.ts_us = new_edge_map->ts_us();
     odometry.orientation = TooN::SO3<types::Float>(R_global).ln();
     odometry.position = Pos;
+    odometry.scale = K;
+    odometry.gravity = sab_state_.g_est;
+    odometry.gyro_bias = imu_state_.Bg;
+    odometry.klm_num = klm_num;
     for (auto& cb : odometry_callbacks_) cb(odometry);
     ++num_frames_;
   }

@@ -1,0 +1,380 @@
+// Scale-attitude-bias estimator and Core::estimateBias on the host (reference sab_estimator.cpp:21-165,
+// core.cpp:350-414). Dense 7x7 / 11x11 fp32 algebra in TooN's evaluation order; SVD<7> (double in the reference,
+// sab_estimator.cpp:31) is a Jacobi pseudo-inverse in double with TooN's 1e9 condition cut.
+#include "rebvio/sab_estimator.hpp"
+
+#include <cmath>
+
+#include "../csrc/hostmath.hpp"
+#include "rebvio/core.hpp"
+
+namespace rebvio {
+
+namespace {
+template <int R, int C>
+struct Mx {
+  float a[R][C];
+  static Mx zeros() {
+    Mx m;
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < C; ++j) m.a[i][j] = 0;
+    return m;
+  }
+};
+template <int R, int K, int C>
+Mx<R, C> mul(const Mx<R, K>& x, const Mx<K, C>& y) {
+  Mx<R, C> r;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) {
+      float s = 0;
+      for (int k = 0; k < K; ++k) s += x.a[i][k] * y.a[k][j];
+      r.a[i][j] = s;
+    }
+  return r;
+}
+template <int R, int C>
+Mx<C, R> tr(const Mx<R, C>& x) {
+  Mx<C, R> r;
+  for (int i = 0; i < R; ++i)
+    for (int j = 0; j < C; ++j) r.a[j][i] = x.a[i][j];
+  return r;
+}
+template <int R, int C>
+void mulv(const Mx<R, C>& m, const float* v, float* out) {
+  float t[R];
+  for (int i = 0; i < R; ++i) {
+    float s = 0;
+    for (int k = 0; k < C; ++k) s += m.a[i][k] * v[k];
+    t[i] = s;
+  }
+  for (int i = 0; i < R; ++i) out[i] = t[i];
+}
+template <int N>
+float dot(const float* a, const float* b) {
+  float s = 0;
+  for (int i = 0; i < N; ++i) s += a[i] * b[i];
+  return s;
+}
+template <int N>
+float quad(const float* x, const Mx<N, N>& M, const float* y) {
+  float t[N];
+  for (int j = 0; j < N; ++j) {
+    float s = 0;
+    for (int k = 0; k < N; ++k) s += x[k] * M.a[k][j];
+    t[j] = s;
+  }
+  return dot<N>(t, y);
+}
+// TooN Cholesky<N,float>::get_inverse (LDL^T)
+template <int N>
+Mx<N, N> chol_inverse(const Mx<N, N>& A) {
+  float L[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) L[i][j] = A.a[i][j];
+  for (int col = 0; col < N; ++col) {
+    float inv_diag = 1;
+    for (int row = col; row < N; ++row) {
+      float val = L[row][col];
+      for (int c2 = 0; c2 < col; ++c2) val -= L[c2][col] * L[row][c2];
+      if (row == col) {
+        L[row][col] = val;
+        if (val == 0) break;
+        inv_diag = 1 / val;
+      } else {
+        L[col][row] = val;
+        L[row][col] = val * inv_diag;
+      }
+    }
+  }
+  Mx<N, N> inv;
+  for (int c = 0; c < N; ++c) {
+    float y[N], res[N];
+    for (int i = 0; i < N; ++i) {
+      float val = (i == c) ? 1.0f : 0.0f;
+      for (int j = 0; j < i; ++j) val -= L[i][j] * y[j];
+      y[i] = val;
+    }
+    for (int i = 0; i < N; ++i) y[i] /= L[i][i];
+    for (int i = N - 1; i >= 0; --i) {
+      float val = y[i];
+      for (int j = i + 1; j < N; ++j) val -= L[j][i] * res[j];
+      res[i] = val;
+    }
+    for (int i = 0; i < N; ++i) inv.a[i][c] = res[i];
+  }
+  return inv;
+}
+// pseudo-inverse solve of a symmetric system in double (Jacobi eigen-decomposition, 1e9 condition cut)
+template <int N>
+void sym_pinv_solve_d(const double* A_, const double* b_, double* x_) {
+  double A[N][N], V[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      A[i][j] = 0.5 * (A_[i * N + j] + A_[j * N + i]);
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 80; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = ((theta >= 0) ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < N; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = cs * akp - sn * akq;
+          A[k][q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = cs * apk - sn * aqk;
+          A[q][k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = cs * vkp - sn * vkq;
+          V[k][q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  double dmax = 0;
+  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(A[i][i]));
+  for (int i = 0; i < N; ++i) x_[i] = 0;
+  for (int k = 0; k < N; ++k) {
+    const double lam = A[k][k];
+    if (!(std::fabs(lam) * 1e9 > dmax)) continue;
+    double proj = 0;
+    for (int i = 0; i < N; ++i) proj += V[i][k] * b_[i];
+    proj /= lam;
+    for (int i = 0; i < N; ++i) x_[i] += V[i][k] * proj;
+  }
+}
+inline float saturate(float t, float limit) { return (t > limit) ? limit : ((t < -limit) ? -limit : t); }
+}  // namespace
+
+SABEstimator::State::State(rebvio::types::ImuStateConfig& cfg) {
+  Qg = TooN::Identity * (double)(cfg.g_uncertainty * cfg.g_uncertainty);
+  Rg = cfg.g_norm_uncertainty * cfg.g_norm_uncertainty;
+  Rs = TooN::Identity * (double)(cfg.acc_std_dev * cfg.acc_std_dev);
+  Qbias = TooN::Identity * (double)(cfg.vbias_std_dev * cfg.vbias_std_dev);
+  Qrot = TooN::Identity;
+  Rv = TooN::Identity;
+  QKp = 5e-6;
+  g_est = TooN::Zeros;
+  b_est = TooN::Zeros;
+  X = TooN::Zeros;
+  X[0] = M_PI_4;
+  X[2] = cfg.g_norm;
+  P = TooN::Zeros;
+  P(0, 0) = cfg.scale_stdd_dev_init * cfg.scale_stdd_dev_init;
+  P(1, 1) = P(2, 2) = P(3, 3) = 100.0;
+  P(4, 4) = P(5, 5) = P(6, 6) = cfg.vbias_std_dev * cfg.vbias_std_dev * 1e1;
+}
+
+SABEstimator::SABEstimator(SABEstimator::Config& config) : config_(config) {}
+SABEstimator::~SABEstimator() {}
+
+bool SABEstimator::problem(rebvio::types::Matrix7f& JtJ_, rebvio::types::Vector7f& JtF_, const rebvio::types::Vector7f& X) {
+  const Config& cfg = config_;
+  const float a = X[0];
+  const float g[3] = {X[1], X[2], X[3]}, b[3] = {X[4], X[5], X[6]};
+  float F[11];
+  for (int i = 0; i < 11; ++i) F[i] = 0;
+  const float ca = std::cos(a), sa = std::sin(a);
+  for (int i = 0; i < 3; ++i) F[i] = (cfg.a_s[i] + g[i]) * ca - cfg.a_v[i] * sa;
+  F[3] = dot<3>(g, g) - cfg.G * cfg.G;
+  F[4] = X[0] - cfg.x_p[0];
+  if (F[4] > M_PI) F[4] -= 2.0 * M_PI;
+  else if (F[4] < -M_PI) F[4] += 2.0 * M_PI;
+  const rh::hm::M3 Rb = rh::hm::so3_exp(b);
+  float Rg3[3];
+  rh::hm::mulv(Rb, g, Rg3);
+  for (int i = 0; i < 3; ++i) F[5 + i] = Rg3[i] - cfg.x_p[1 + i];
+  for (int i = 0; i < 3; ++i) F[8 + i] = b[i] - cfg.x_p[4 + i];
+  float dFda[11];
+  for (int i = 0; i < 11; ++i) dFda[i] = 0;
+  for (int i = 0; i < 3; ++i) dFda[i] = -(cfg.a_s[i] + g[i]) * sa - cfg.a_v[i] * ca;
+  dFda[4] = 1.0;
+  Mx<11, 6> dFdx1 = Mx<11, 6>::zeros();
+  const float Gx[3][3] = {{0.0f, Rg3[2], -Rg3[1]}, {-Rg3[2], 0.0f, Rg3[0]}, {Rg3[1], -Rg3[0], 0.0f}};
+  for (int i = 0; i < 3; ++i) dFdx1.a[i][i] = ca;
+  for (int j = 0; j < 3; ++j) dFdx1.a[3][j] = 2.0 * g[j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      dFdx1.a[5 + i][j] = Rb.a[i][j];
+      dFdx1.a[5 + i][3 + j] = Gx[i][j];
+    }
+  for (int i = 0; i < 3; ++i) dFdx1.a[8 + i][3 + i] = 1.0f;
+  Mx<11, 11> P = Mx<11, 11>::zeros(), W = Mx<11, 11>::zeros(), dPda = Mx<11, 11>::zeros();
+  Mx<3, 3> Pz;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Pz.a[i][j] = sa * sa * cfg.Rv(i, j) + ca * ca * cfg.Rs(i, j);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) P.a[i][j] = Pz.a[i][j];
+  P.a[3][3] = cfg.Rg;
+  Mx<7, 7> Pp;
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) {
+      Pp.a[i][j] = cfg.Pp(i, j);
+      P.a[4 + i][4 + j] = cfg.Pp(i, j);
+    }
+  const Mx<3, 3> Wz = chol_inverse<3>(Pz);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) W.a[i][j] = Wz.a[i][j];
+  W.a[3][3] = 1.0 / cfg.Rg;
+  const Mx<7, 7> Wp = chol_inverse<7>(Pp);
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) W.a[4 + i][4 + j] = Wp.a[i][j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) dPda.a[i][j] = 2.0 * sa * ca * (cfg.Rv(i, j) - cfg.Rs(i, j));
+  Mx<11, 11> dWda = mul(mul(W, dPda), W);
+  for (int i = 0; i < 11; ++i)
+    for (int j = 0; j < 11; ++j) dWda.a[i][j] = -dWda.a[i][j];
+  {
+    const Mx<11, 11> M = mul(mul(dWda, P), dWda);
+    JtJ_(0, 0) = 0.25 * quad<11>(F, M, F) + quad<11>(dFda, dWda, F) + quad<11>(dFda, W, dFda);
+  }
+  const Mx<6, 11> dT = tr(dFdx1);
+  {
+    float t1[11], t2[11], c1[6], c2[6];
+    mulv(dWda, F, t1);
+    mulv(W, dFda, t2);
+    mulv(dT, t1, c1);
+    mulv(dT, t2, c2);
+    for (int i = 0; i < 6; ++i) {
+      JtJ_(1 + i, 0) = 0.5 * c1[i] + c2[i];
+      JtJ_(0, 1 + i) = JtJ_(1 + i, 0);
+    }
+  }
+  {
+    const Mx<6, 6> B = mul(mul(dT, W), dFdx1);
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) JtJ_(1 + i, 1 + j) = B.a[i][j];
+  }
+  JtF_[0] = 0.5 * quad<11>(F, dWda, F) + quad<11>(dFda, W, F);
+  {
+    float t[11], c[6];
+    mulv(W, F, t);
+    mulv(dT, t, c);
+    for (int i = 0; i < 6; ++i) JtF_[1 + i] = c[i];
+  }
+  return true;
+}
+
+int SABEstimator::gaussNewton(rebvio::types::Vector7f& X, int iter_max, types::Float a_tol, types::Float r_tol) {
+  int i = 0;
+  for (; i < iter_max; ++i) {
+    types::Matrix7f JtJ;
+    types::Vector7f JtF;
+    problem(JtJ, JtF, X);
+    double A[49], b[7], h[7];
+    for (int r = 0; r < 7; ++r) {
+      b[r] = -(double)JtF[r];
+      for (int c = 0; c < 7; ++c) A[r * 7 + c] = (double)JtJ(r, c);
+    }
+    sym_pinv_solve_d<7>(A, b, h);
+    for (int r = 0; r < 7; ++r) X[r] = (float)((double)X[r] + h[r]);
+    X[0] = std::atan2(std::sin(X[0]), std::cos(X[0]));
+    for (int r = 4; r < 7; ++r) X[r] = saturate(X[r], 5e-1 / 25);
+    double nh = 0;
+    for (int r = 0; r < 7; ++r) nh += h[r] * h[r];
+    nh = std::sqrt(nh);
+    float nx = 0;
+    for (int r = 0; r < 7; ++r) nx += X[r] * X[r];
+    if (nh < a_tol || nh / (std::sqrt(nx) + 1e-20) < r_tol) break;
+  }
+  return i;
+}
+
+// Core::estimateBias (core.cpp:350-414)
+types::Float Core::estimateBias(const rebvio::types::Vector3f& sacc, const rebvio::types::Vector3f& facc, types::Float kP,
+                                const rebvio::types::Matrix3f Rot, rebvio::types::Vector7f& X, rebvio::types::Matrix7f& P,
+                                const rebvio::types::Matrix3f& Qg, const rebvio::types::Matrix3f& Qrot,
+                                const rebvio::types::Matrix3f& Qbias, types::Float QKp, types::Float Rg,
+                                const rebvio::types::Matrix3f& Rs, const rebvio::types::Matrix3f& Rf, rebvio::types::Vector3f& g_est,
+                                rebvio::types::Vector3f& b_est, const rebvio::types::Matrix6f& Wvw, rebvio::types::Vector6f& Xvw,
+                                types::Float g_gravit) {
+  Mx<7, 7> F = Mx<7, 7>::zeros();
+  F.a[0][0] = kP;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) F.a[1 + i][1 + j] = Rot(j, i);
+  for (int i = 0; i < 3; ++i) F.a[4 + i][4 + i] = 1.0f;
+  const float G[3] = {X[1], X[2], X[3]};
+  Mx<3, 3> GProd = {{{0.0f, G[2], -G[1]}, {-G[2], 0.0f, G[0]}, {G[1], -G[0], 0.0f}}};
+  Mx<3, 3> Qr, Qgm;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Qr.a[i][j] = Qrot(i, j);
+      Qgm.a[i][j] = Qg(i, j);
+    }
+  Mx<7, 7> Q = Mx<7, 7>::zeros();
+  const float tn = std::tan(X[0]);
+  Q.a[0][0] = QKp / (1.0 + tn * tn);
+  const Mx<3, 3> Qg2 = mul(mul(tr(GProd), Qr), GProd);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Q.a[1 + i][1 + j] = Qg2.a[i][j] + Qgm.a[i][j];
+      Q.a[4 + i][4 + j] = Qbias(i, j);
+    }
+  float Xa[7], Xp[7];
+  for (int i = 0; i < 7; ++i) Xa[i] = X[i];
+  mulv(F, Xa, Xp);
+  for (int i = 0; i < 7; ++i) X[i] = Xp[i];
+  Mx<7, 7> Pm;
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) Pm.a[i][j] = P(i, j);
+  Mx<7, 7> Ppm = mul(mul(F, Pm), tr(F));
+  types::Matrix7f Pp;
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) Pp(i, j) = Ppm.a[i][j] + Q.a[i][j];
+
+  rebvio::SABEstimator::Config params(facc, sacc, g_gravit, X, Rf, Rs, Rg, Pp);
+  rebvio::SABEstimator sab(params);
+  sab.gaussNewton(X, 20);
+  types::Matrix7f JtJ;
+  types::Vector7f JtF;
+  sab.problem(JtJ, JtF, X);
+  Mx<7, 7> J;
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) J.a[i][j] = JtJ(i, j);
+  const Mx<7, 7> Pi = chol_inverse<7>(J);
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) P(i, j) = Pi.a[i][j];
+  types::Float k = std::tan(X[0]);
+  if (k < 0 || std::isnan(k) || std::isinf(k)) k = 0;
+  for (int i = 0; i < 3; ++i) {
+    g_est[i] = X[1 + i];
+    b_est[i] = X[4 + i];
+  }
+  float A6[36], rhs[6], inv[36];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) A6[i * 6 + j] = 0.0f + Wvw(i, j);
+  float wc[3], wx[3];
+  for (int i = 0; i < 3; ++i) wc[i] = Xvw[3 + i] - b_est[i];
+  for (int i = 0; i < 3; ++i) {
+    float s = 0;
+    for (int j = 0; j < 3; ++j) {
+      s += JtJ(4 + i, 4 + j) * wc[j];
+      A6[(3 + i) * 6 + 3 + j] = JtJ(4 + i, 4 + j) + Wvw(3 + i, 3 + j);
+    }
+    wx[i] = s;
+  }
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+    for (int j = 0; j < 6; ++j) s += Wvw(i, j) * Xvw[j];
+    rhs[i] = s + ((i >= 3) ? wx[i - 3] : 0.0f);
+  }
+  rh::hm::cholesky6_inverse(A6, inv);
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+    for (int j = 0; j < 6; ++j) s += inv[i * 6 + j] * rhs[j];
+    Xvw[i] = s;
+  }
+  return k;
+}
+
+}  // namespace rebvio

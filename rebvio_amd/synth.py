@@ -175,6 +175,28 @@ def render_stream(width: int, height: int, n_frames: int, stream_id: int = 0, de
     return frames, cam
 
 
+def imu_samples(scene: Scene, n_frames: int, frame_dt_us: int = 50000, rate_hz: int = 200, R_c2i=None, noise_seed: int | None = None,
+                gyro_bias=(0.0, 0.0, 0.0)):
+    """Analytic IMU stream of the scene's motion (BASELINE config 5): constant world velocity (zero acceleration) and a
+    constant yaw rate about the camera's y axis, gravity along +y of the camera (image "down").
+    Returns (ts_us[int64], gyro[n,3], acc[n,3]) in the IMU frame; sample k of frame f has f*dt < ts <= (f+1)*dt... i.e.
+    timestamps in (0, (n_frames-1)*dt]."""
+    R_c2i = np.eye(3) if R_c2i is None else np.asarray(R_c2i, np.float64)
+    per = rate_hz * frame_dt_us // 1000000
+    step = frame_dt_us // per
+    ts = np.arange(1, (n_frames - 1) * per + 1, dtype=np.int64) * step
+    yaw_rate = math.radians(scene.yaw_deg) * (1e6 / frame_dt_us)  # rad/s about camera y
+    w_cam = np.array([0.0, yaw_rate, 0.0])
+    f_cam = np.array([0.0, -9.81, 0.0])  # specific force = a - g with a = 0, g = +9.81 along camera y (invariant under yaw)
+    gyro = np.tile(R_c2i @ w_cam + np.asarray(gyro_bias), (len(ts), 1))
+    acc = np.tile(R_c2i @ f_cam, (len(ts), 1))
+    if noise_seed is not None:
+        rng = np.random.Generator(np.random.PCG64(SEED * 31 + noise_seed))
+        gyro = gyro + rng.normal(0, 1.6968e-4, gyro.shape)
+        acc = acc + rng.normal(0, 2.0e-3, acc.shape)
+    return ts, gyro.astype(np.float32), acc.astype(np.float32)
+
+
 def pingpong_indices(n_base: int, n_total: int) -> np.ndarray:
     """0,1,..,n-1,n-2,..,1,0,1,.. : every consecutive pair is a valid small inter-frame motion."""
     period = list(range(n_base)) + list(range(n_base - 2, 0, -1))

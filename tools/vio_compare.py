@@ -1,0 +1,42 @@
+"""Debug aid: rebvio::Rebvio (device) vs the oracle's full-VIO restatement on the same synthetic camera+IMU stream."""
+import os, subprocess, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rebvio_amd import synth
+from oracle import oracle_py as O
+
+def main():
+    n, W, H = 30, 256, 192
+    frames, cam = synth.render_stream(W, H, n)
+    scene = synth.make_scene(0)
+    ts, gyro, acc = synth.imu_samples(scene, n, noise_seed=1)
+    d = tempfile.mkdtemp()
+    fp, ip = os.path.join(d, "f.u8"), os.path.join(d, "imu.bin")
+    frames.tofile(fp)
+    rec = np.zeros(len(ts), dtype=[("ts", "<i8"), ("gyro", "<f4", 3), ("acc", "<f4", 3)])
+    rec["ts"], rec["gyro"], rec["acc"] = ts, gyro, acc
+    rec.tofile(ip)
+    exe = os.path.join(ROOT, "rebvio_amd", "_build", "rebvio_stream_example")
+    r = subprocess.run([exe, fp, str(W), str(H), str(n), str(cam.fm), str(cam.cx), str(cam.cy), "2500", "3500", ip, "100"],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stderr[-500:])
+    got = np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines() if ln and ln[0].isdigit()])
+    O.build()
+    p = O.default_params(H, W, fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=2500, keylines_max=3500, global_min_matches_threshold=100)
+    orc = O.Oracle(p); orc.vio_reset()
+    prev, k, want = None, 0, []
+    for i in range(n):
+        m = orc.detect_u8(frames[i], i * 50000)
+        while k < len(ts) and ts[k] <= i * 50000:
+            orc.vio_add_imu(m, ts[k], gyro[k], acc[k]); k += 1
+        if prev is not None:
+            o = orc.vio_step(prev, m)
+            want.append([i * 50000] + list(o.orientation) + list(o.position) + [o.K] + list(o.g_est) + list(o.Bg) + [o.pair.klm_num])
+        prev = m
+    want = np.array(want)
+    np.set_printoptions(linewidth=250, precision=6, suppress=True)
+    for a, b in zip(got, want):
+        print("G", a[1:]); print("O", b[1:])
+
+main()
