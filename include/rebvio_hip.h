@@ -111,6 +111,16 @@ int rebvio_hip_detect(rebvio_hip_ctx* ctx, const float* img_host, size_t pitch_b
 /* Same, for a u8 frame already resident in device memory: fuses convertTo(CV_32F, 3.0) (rebvio.cpp:43)
  * into the first scan kernel. `frame_dev` is a device pointer to rows*cols bytes, dense. */
 int rebvio_hip_detect_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_map** out);
+/* Same, for a u8 frame in host memory (the MONO8 image ros_rebvio hands to imageCallback, ros_rebvio.cpp:96-104):
+ * uploads 1 byte/pixel instead of the fp32 frame. */
+int rebvio_hip_detect_u8(rebvio_hip_ctx* ctx, const uint8_t* img_host, size_t pitch_bytes, uint64_t ts_us,
+                         rebvio_hip_map** out);
+/* Lens model of the front end (camera.hpp:39-40,54-58: cv::undistort(in, out, K(fm,0,cx;0,fm,cy), D(k1,k2,p1,p2,k3))).
+ * K4 = fx, fy, cx, cy; D5 = k1, k2, p1, p2, k3. Once set, every *_u8 detect entry runs convertTo(CV_32F,3.0) +
+ * undistort on the device before the scale space (rebvio.cpp:43-47); all-zero D5 switches it off. Synchronises. */
+int rebvio_hip_set_undistort(rebvio_hip_ctx* ctx, const float K4[4], const float D5[5]);
+/* The front end alone: u8 host frame -> undistorted fp32 host frame (rows*cols floats). Needs a lens model. */
+int rebvio_hip_front_end_u8(rebvio_hip_ctx* ctx, const uint8_t* img_host, float* out_host);
 /* config_->threshold after the servo and auto_threshold_ (edge_detector.hpp:84,91). Synchronises. */
 int rebvio_hip_detector_state(rebvio_hip_ctx* ctx, float* threshold, float* auto_threshold, int* keylines_count);
 

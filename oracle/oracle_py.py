@@ -107,6 +107,7 @@ def lib(path: str | None = None):
         "orc_vio_reset": (None, [vp, fp, fp]),
         "orc_vio_add_imu": (None, [vp, vp, C.c_uint64, fp, fp]),
         "orc_vio_step": (C.c_int, [vp, vp, vp, C.POINTER(VioOut)]),
+        "orc_front_end_u8": (None, [vp, C.POINTER(C.c_uint8), fp, fp, fp]),
         "orc_ls4_reset": (None, [vp]),
         "orc_estimate_ls4_acceleration": (None, [vp, fp, fp, fp, C.c_float]),
         "orc_so3_exp": (None, [fp, fp]),
@@ -199,6 +200,15 @@ class Oracle:
         img, pi = _f(img)
         assert img.shape == (self.rows, self.cols)
         return Map(self.L, self.L.orc_detect(self.h, pi, ts_us))
+
+    def front_end_u8(self, frame_u8, fx, fy, cx, cy, dist) -> np.ndarray:
+        """convertTo(CV_32F, 3.0) + cv::undistort(K(fx,fy,cx,cy), D = k1,k2,p1,p2,k3)."""
+        frame_u8 = np.ascontiguousarray(frame_u8, np.uint8)
+        k, pk = _f(np.array([fx, fy, cx, cy], np.float32))
+        d, pd = _f(np.array(dist, np.float32))
+        out = np.empty(frame_u8.shape, np.float32)
+        self.L.orc_front_end_u8(self.h, frame_u8.ctypes.data_as(C.POINTER(C.c_uint8)), pk, pd, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
 
     def detect_u8(self, frame_u8, ts_us=0) -> Map:
         return self.detect(frame_u8.astype(np.float32) * np.float32(3.0), ts_us)

@@ -1974,6 +1974,66 @@ float estimate_bias(orc_ctx* c, const float sacc[3], const float facc[3], float 
 }
 }  // namespace
 
+// ---- front end: convertTo(CV_32F, 3.0) + cv::undistort (rebvio.cpp:43-47, camera.hpp:39-40,54-58) -----
+// OpenCV is a third-party dependency absent from /root/reference (found via find_package(OpenCV), version unpinned); this
+// restates its published algorithm: cv::undistort builds, per stripe of max(1, 4096/cols) rows, CV_16SC2 + CV_16UC1 maps
+// with initUndistortRectifyMap (double arithmetic, normalised x advanced by repeated addition of 1/fx, principal point
+// moved by the stripe offset, coordinates quantised to 1/32 px with cvRound = round-half-even) and calls
+// remap(INTER_LINEAR, BORDER_CONSTANT 0), whose float path weighs the four taps with the table tab_y[k1]*tab_x[k2].
+// Parity unpinned (no OpenCV here); exactness of the interpolation itself: every tap*weight product and their sum are
+// exactly representable for 8-bit*3 sources, so only the double-precision map can differ from a real OpenCV.
+extern "C" void orc_front_end_u8(orc_ctx* c, const uint8_t* img, const float K4[4], const float D5[5], float* out) {
+  const int R = c->p.rows, C = c->p.cols;
+  std::vector<float> src((size_t)R * C);
+  for (size_t i = 0; i < src.size(); ++i) src[i] = float(img[i]) * 3.0f;  // convertTo(CV_32F, 3.0)
+  const double fx = K4[0], fy = K4[1], u0 = K4[2], v0 = K4[3];
+  const double k1 = D5[0], k2 = D5[1], p1 = D5[2], p2 = D5[3], k3 = D5[4];
+  const int stripe0 = std::min(std::max(1, (1 << 12) / std::max(C, 1)), R);
+  std::vector<short> m1((size_t)stripe0 * C * 2);
+  std::vector<unsigned short> m2((size_t)stripe0 * C);
+  float tab[32][2];
+  for (int t = 0; t < 32; ++t) {
+    const float x = float(t) * (1.0f / 32.0f);
+    tab[t][0] = 1.0f - x;
+    tab[t][1] = x;
+  }
+  for (int y = 0; y < R; y += stripe0) {
+    const int sh = std::min(stripe0, R - y);
+    // inverse of Ar = [fx 0 u0; 0 fy v0-y; 0 0 1]
+    const double ir[9] = {1.0 / fx, 0.0, -u0 / fx, 0.0, 1.0 / fy, -(v0 - y) / fy, 0.0, 0.0, 1.0};
+    for (int i = 0; i < sh; ++i) {
+      double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+      for (int j = 0; j < C; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+        const double w = 1.0 / _w, x = _x * w, yy = _y * w;
+        const double x2 = x * x, y2 = yy * yy;
+        const double r2 = x2 + y2, _2xy = 2 * x * yy;
+        const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+        const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+        const double yd = yy * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+        const double u = fx * xd + u0, v = fy * yd + v0;
+        const int iu = (int)std::lrint(u * 32), iv = (int)std::lrint(v * 32);
+        m1[((size_t)i * C + j) * 2] = (short)(iu >> 5);
+        m1[((size_t)i * C + j) * 2 + 1] = (short)(iv >> 5);
+        m2[(size_t)i * C + j] = (unsigned short)((iv & 31) * 32 + (iu & 31));
+      }
+    }
+    for (int i = 0; i < sh; ++i)
+      for (int j = 0; j < C; ++j) {
+        const int sx = m1[((size_t)i * C + j) * 2], sy = m1[((size_t)i * C + j) * 2 + 1];
+        const int fxy = m2[(size_t)i * C + j];
+        const float* ty = tab[fxy >> 5];
+        const float* tx = tab[fxy & 31];
+        const float w4[4] = {ty[0] * tx[0], ty[0] * tx[1], ty[1] * tx[0], ty[1] * tx[1]};
+        float v4[4];
+        for (int k = 0; k < 4; ++k) {
+          const int xx = sx + (k & 1), yy = sy + (k >> 1);
+          v4[k] = (xx >= 0 && xx < C && yy >= 0 && yy < R) ? src[(size_t)yy * C + xx] : 0.0f;
+        }
+        out[(size_t)(y + i) * C + j] = v4[0] * w4[0] + v4[1] * w4[1] + v4[2] * w4[2] + v4[3] * w4[3];
+      }
+  }
+}
+
 extern "C" void orc_vio_reset(orc_ctx* c, const float R_c2i[9], const float t_c2i[3]) {
   orc_reset_state(c);
   c->R_c2i = m3_from(R_c2i);

@@ -148,6 +148,10 @@ void orc_vio_reset(orc_ctx* c, const float R_c2i[9], const float t_c2i[3]);
 void orc_vio_add_imu(orc_ctx* c, orc_map* m, uint64_t ts_us, const float gyro[3], const float acc[3]);
 int orc_vio_step(orc_ctx* c, orc_map* old_map, orc_map* new_map, orc_vio_out* out);
 
+/* Front end (rebvio.cpp:43-47): convertTo(CV_32F,3.0) + cv::undistort with K4 = fx,fy,cx,cy and
+ * D5 = k1,k2,p1,p2,k3 (camera.hpp:39-40). out = rows*cols floats. */
+void orc_front_end_u8(orc_ctx* c, const uint8_t* img, const float K4[4], const float D5[5], float* out);
+
 /* host glue pieces exposed for KATs */
 void orc_ls4_reset(orc_ctx* c);
 void orc_estimate_ls4_acceleration(orc_ctx* c, const float vel[3], float acc[3], const float R[9], float dt);

@@ -65,6 +65,9 @@ SIGNATURES = {
     "rebvio_hip_scale_space": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
     "rebvio_hip_detect": (C.c_int, [_vp, _fp, C.c_size_t, C.c_uint64, C.POINTER(_vp)]),
     "rebvio_hip_detect_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(_vp)]),
+    "rebvio_hip_detect_u8": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.POINTER(_vp)]),
+    "rebvio_hip_set_undistort": (C.c_int, [_vp, _fp, _fp]),
+    "rebvio_hip_front_end_u8": (C.c_int, [_vp, _vp, _fp]),
     "rebvio_hip_detector_state": (C.c_int, [_vp, _fp, _fp, _ip]),
     "rebvio_hip_map_size": (C.c_int, [_vp]),
     "rebvio_hip_map_threshold": (C.c_float, [_vp]),
@@ -226,6 +229,27 @@ class Context:
 
     def detect_u8(self, frame_u8, ts_us=0) -> Map:
         return self.detect(frame_u8.astype(np.float32) * np.float32(3.0), ts_us)
+
+    def detect_u8_host(self, frame_u8, ts_us=0) -> Map:
+        """u8 host frame through the device front end (x3, undistort when a lens model is set)."""
+        frame_u8 = np.ascontiguousarray(frame_u8, np.uint8)
+        assert frame_u8.shape == (self.rows, self.cols)
+        h = _vp()
+        _chk(lib().rebvio_hip_detect_u8(self.h, frame_u8.ctypes.data_as(_vp), 0, ts_us, C.byref(h)))
+        return Map(self, h)
+
+    def set_undistort(self, fx, fy, cx, cy, dist):
+        k, pk = _f(np.array([fx, fy, cx, cy], np.float32))
+        d, pd = _f(np.array(dist, np.float32))
+        assert d.size == 5
+        _chk(lib().rebvio_hip_set_undistort(self.h, pk, pd))
+
+    def front_end_u8(self, frame_u8) -> np.ndarray:
+        frame_u8 = np.ascontiguousarray(frame_u8, np.uint8)
+        assert frame_u8.shape == (self.rows, self.cols)
+        out = np.empty((self.rows, self.cols), np.float32)
+        _chk(lib().rebvio_hip_front_end_u8(self.h, frame_u8.ctypes.data_as(_vp), out.ctypes.data_as(_fp)))
+        return out
 
     def upload_frames(self, frames_u8: np.ndarray) -> int:
         """Stage u8 frames in HBM; returns the device address of frame 0."""

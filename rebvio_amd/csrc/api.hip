@@ -175,6 +175,8 @@ struct rebvio_hip_ctx {
   std::vector<rebvio_hip_map*> pool;
   float* img_dev = nullptr;
   uint8_t* img8_dev = nullptr;
+  int2* undist_map = nullptr;      // fixed-point source coordinates (null: no lens distortion, front end = x3 only)
+  float* undist_img[2]{};          // undistorted fp32 frame, double-buffered like dog2 / mag2
   rebvio_hip_keyline* aos_dev = nullptr;
   int* scratch_i = nullptr;  // 2 * rows*cols ints (df decode)
   float* diag0 = nullptr;
@@ -362,7 +364,14 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   db.rowcount = c->rowcount2[b];
   // scans of this frame (s_det); its DoG / gradient buffers were last read by the candidate kernel two frames ago
   if (c->ev_flag_used[b]) HIPCHK(hipStreamWaitEvent(c->s_det, c->ev_flag[b], 0));
-  launch_scale_space(c->s_det, c->K, j.img, j.is_u8, sb, c->widths, db.rowcount);
+  const void* img = j.img;
+  int is_u8 = j.is_u8;
+  if (is_u8 && c->undist_map) {  // x3 + undistort (rebvio.cpp:43-47); its output was last read by the scans two frames ago
+    launch_front_end_u8(c->s_det, c->K, (const uint8_t*)img, c->undist_map, c->undist_img[b]);
+    img = c->undist_img[b];
+    is_u8 = 0;
+  }
+  launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount);
   HIPCHK(hipEventRecord(c->ev_scan[b], c->s_det));
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
   HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
@@ -729,6 +738,9 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
     if (c->slot[i]) (void)hipHostFree(c->slot[i]);
     if (c->slot_ev[i]) (void)hipEventDestroy(c->slot_ev[i]);
   }
+  if (c->undist_map) (void)hipFree(c->undist_map);
+  for (int i = 0; i < 2; ++i)
+    if (c->undist_img[i]) (void)hipFree(c->undist_img[i]);
   if (c->lm_zero) (void)hipFree(c->lm_zero);
   if (c->dm_work) (void)hipFree(c->dm_work);
   if (c->dm_work_n) (void)hipFree(c->dm_work_n);
@@ -768,6 +780,48 @@ int rebvio_hip_detect(rebvio_hip_ctx* c, const float* img, size_t pitch_bytes, u
 int rebvio_hip_detect_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_map** out) {
   HIPCHK(hipSetDevice(c->device));
   return detect_common(c, frame_dev, 1, ts_us, out);
+}
+
+int rebvio_hip_detect_u8(rebvio_hip_ctx* c, const uint8_t* img, size_t pitch_bytes, uint64_t ts_us, rebvio_hip_map** out) {
+  HIPCHK(hipSetDevice(c->device));
+  const size_t rowb = (size_t)c->P.cols;
+  if (pitch_bytes == 0) pitch_bytes = rowb;
+  // the staging frame is read by this stream's own kernels only, so the copy is ordered behind the previous frame's
+  HIPCHK(hipMemcpy2DAsync(c->img8_dev, rowb, img, pitch_bytes, rowb, c->P.rows, hipMemcpyHostToDevice, c->s_det));
+  return detect_common(c, c->img8_dev, 1, ts_us, out);
+}
+
+int rebvio_hip_set_undistort(rebvio_hip_ctx* c, const float K4[4], const float D5[5]) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());  // no frame in flight may still read the old map
+  bool any = false;
+  for (int i = 0; i < 5; ++i) any = any || (D5[i] != 0.0f);
+  if (!any) {  // identity: the fixed-point map reproduces x3 exactly, skip the gather
+    if (c->undist_map) (void)hipFree(c->undist_map);
+    c->undist_map = nullptr;
+    return 0;
+  }
+  if (!(K4[0] > 0.0f) || !(K4[1] > 0.0f)) return fail_msg("set_undistort: focal lengths must be positive", -3);
+  const size_t Pn = (size_t)c->P.rows * c->P.cols;
+  std::vector<int> map(2 * Pn);
+  hm::undistort_fixed_map(c->P.rows, c->P.cols, K4[0], K4[1], K4[2], K4[3], D5[0], D5[1], D5[2], D5[3], D5[4], map.data());
+  if (!c->undist_map) HIPCHK(hipMalloc(&c->undist_map, Pn * sizeof(int2)));
+  for (int i = 0; i < 2; ++i)
+    if (!c->undist_img[i]) HIPCHK(hipMalloc(&c->undist_img[i], Pn * sizeof(float)));
+  HIPCHK(hipMemcpy(c->undist_map, map.data(), Pn * sizeof(int2), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int rebvio_hip_front_end_u8(rebvio_hip_ctx* c, const uint8_t* img, float* out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->undist_map) return fail_msg("front_end_u8: no distortion model set (rebvio_hip_set_undistort)", -3);
+  const size_t Pn = (size_t)c->P.rows * c->P.cols;
+  HIPCHK(hipMemcpyAsync(c->img8_dev, img, Pn, hipMemcpyHostToDevice, c->s_det));
+  launch_front_end_u8(c->s_det, c->K, c->img8_dev, c->undist_map, c->undist_img[0]);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, c->undist_img[0], Pn * sizeof(float), hipMemcpyDeviceToHost, c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_det));
+  return 0;
 }
 
 int rebvio_hip_detector_state(rebvio_hip_ctx* c, float* threshold, float* auto_threshold, int* count) {

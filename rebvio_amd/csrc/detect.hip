@@ -662,6 +662,33 @@ static int lds_pitch(int cols) {
   return cols + pad;
 }
 
+// ---- front end: convertTo(CV_32F, 3.0) + cv::undistort as one gather kernel (rebvio.cpp:43-47) -------
+// map = fixed-point source coordinates (1/32 px, hostmath.hpp undistort_fixed_map). Weights (1-a)(1-b) .. with a, b
+// multiples of 1/32 and 8-bit*3 sources make every product and the 4-term sum exact in fp32, so the result does not
+// depend on evaluation order; taps outside the image read the constant border 0 (BORDER_CONSTANT).
+__global__ __launch_bounds__(256) void k_front_end_u8(const uint8_t* __restrict__ src, const int2* __restrict__ map,
+                                                        float* __restrict__ dst, int rows, int cols) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int2 m = map[i];
+  const int sx = m.x >> 5, sy = m.y >> 5;
+  const float ax = (float)(m.x & 31) * 0.03125f, ay = (float)(m.y & 31) * 0.03125f;
+  const bool x0 = (unsigned)sx < (unsigned)cols, x1 = (unsigned)(sx + 1) < (unsigned)cols;
+  const bool y0 = (unsigned)sy < (unsigned)rows, y1 = (unsigned)(sy + 1) < (unsigned)rows;
+  const uint8_t* r0 = src + (size_t)(y0 ? sy : 0) * cols;
+  const uint8_t* r1 = src + (size_t)(y1 ? sy + 1 : 0) * cols;
+  const float s00 = (x0 && y0) ? (float)r0[sx] * 3.0f : 0.0f;
+  const float s01 = (x1 && y0) ? (float)r0[sx + 1] * 3.0f : 0.0f;
+  const float s10 = (x0 && y1) ? (float)r1[sx] * 3.0f : 0.0f;
+  const float s11 = (x1 && y1) ? (float)r1[sx + 1] * 3.0f : 0.0f;
+  const float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax, w10 = ay * (1.0f - ax), w11 = ay * ax;
+  dst[i] = s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11;
+}
+
+void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, const int2* map, float* dst) {
+  RH_LAUNCH(k_front_end_u8, dim3(div_up(p.rows * p.cols, 256)), dim3(256), 0, s, src, map, dst, p.rows, p.cols);
+}
+
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
                         const int widths[2][3], int* rowcount_to_zero) {
   const int R = p.rows, C = p.cols;

@@ -322,6 +322,36 @@ inline void gyro_bias_correction(float X[6], float Wx[36], M3& Wb, const M3& Rg,
 }
 
 // Kovesi box widths of FastGaussian::FastGaussian (scale_space.cpp:19-35)
+// Fixed-point source coordinates of cv::undistort(src, dst, K, D) with K = (fx,0,cx; 0,fy,cy), D = (k1,k2,p1,p2,k3), as
+// the reference calls it (camera.hpp:39-40,54-58): OpenCV builds CV_16SC2 maps in double, stripe by stripe
+// (stripe = max(1, 4096/cols) rows, principal point shifted by the stripe's first row), u and v quantised to 1/32 pixel
+// with round-half-even; remap then interpolates bilinearly with constant-zero border. out[2*i] = iu, out[2*i+1] = iv.
+inline void undistort_fixed_map(int rows, int cols, double fx, double fy, double cx, double cy, double k1, double k2, double p1,
+                                double p2, double k3, int* out) {
+  const int stripe = std::min(std::max(1, (1 << 12) / std::max(cols, 1)), rows);
+  const double ir0 = 1.0 / fx, ir4 = 1.0 / fy, ir2 = -cx / fx;
+  for (int y0 = 0; y0 < rows; y0 += stripe) {
+    const int h = std::min(stripe, rows - y0);
+    const double ir5 = -(cy - y0) / fy;
+    for (int i = 0; i < h; ++i) {
+      double x_ = ir2;
+      const double y = i * ir4 + ir5;
+      int* o = out + (size_t)(y0 + i) * cols * 2;
+      for (int j = 0; j < cols; ++j, x_ += ir0) {
+        const double x = x_;
+        const double x2 = x * x, y2 = y * y;
+        const double r2 = x2 + y2, xy2 = 2 * x * y;
+        const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+        const double xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2);
+        const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2;
+        const double u = fx * xd + cx, v = fy * yd + cy;
+        o[2 * j] = (int)std::nearbyint(u * 32.0);
+        o[2 * j + 1] = (int)std::nearbyint(v * 32.0);
+      }
+    }
+  }
+}
+
 inline void kovesi_widths(float sigma, int n, int* widths, float* sigma_true) {
   const float w_ideal = std::sqrt(12.0 * sigma * sigma / float(n + 1));
   int w_l = int(w_ideal);

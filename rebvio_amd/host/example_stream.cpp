@@ -29,6 +29,18 @@ int main(int argc, char** argv) {
   const float fm = argc > 5 ? std::atof(argv[5]) : 458.0f * W / 640.0f;
   const float cx = argc > 6 ? std::atof(argv[6]) : W / 2.0f, cy = argc > 7 ? std::atof(argv[7]) : H / 2.0f;
   config.camera = rebvio::Camera(H, W, fm, fm, cx, cy);
+  if (const char* d = std::getenv("REBVIO_EXAMPLE_DISTORTION")) {  // "k1,k2,p1,p2,k3" of the rad-tan lens model
+    float k[5] = {0, 0, 0, 0, 0};
+    if (std::sscanf(d, "%f,%f,%f,%f,%f", &k[0], &k[1], &k[2], &k[3], &k[4]) < 1) {
+      std::fprintf(stderr, "bad REBVIO_EXAMPLE_DISTORTION\n");
+      return 2;
+    }
+    config.camera.k1_ = k[0];
+    config.camera.k2_ = k[1];
+    config.camera.p1_ = k[2];
+    config.camera.p2_ = k[3];
+    config.camera.k3_ = k[4];
+  }
   if (argc > 8) config.edge_detector.keylines_ref = std::atoi(argv[8]);
   if (argc > 9) config.edge_detector.keylines_max = std::atoi(argv[9]);
   if (W * H < 640 * 480) config.core.global_min_matches_threshold = 50;

@@ -49,9 +49,12 @@ Rebvio::~Rebvio() {
 
 void Rebvio::imageCallback(rebvio::types::Image&& image) {
   std::lock_guard<std::mutex> guard(image_buffer_mutex_);
-  cv::Mat img;
-  image.data.convertTo(img, CV_FLOAT_PRECISION, 3.0);  // 0..765, matches max_image_value_ (edge_detector.cpp:21)
-  image.data = camera_.undistort(img);
+  if (image.data.type() != CV_8UC1) {
+    // not a MONO8 frame: convert and undistort here like the reference does (rebvio.cpp:43-47)
+    cv::Mat img;
+    image.data.convertTo(img, CV_FLOAT_PRECISION, 3.0);  // 0..765, matches max_image_value_ (edge_detector.cpp:21)
+    image.data = camera_.undistort(img);
+  }  // else: the u8 frame goes to the device as it is; x3 + undistort run there (1 byte/pixel over PCIe instead of 4)
   image_buffer_.push(image);
   ++num_images_;
 }
@@ -93,7 +96,18 @@ void Rebvio::dataAcquisitionProcess() {
       continue;
     }
     rebvio::EdgeMap::SharedPtr edge_map = edge_detector_.detect(img);
-    for (auto& cb : edge_image_callbacks_) cb(img.data, edge_map);
+    if (!edge_image_callbacks_.empty()) {
+      // callbacks see the undistorted frame, as in the reference; for a raw u8 frame of a distorting lens it is fetched
+      // from the device front end (only when somebody listens)
+      if (img.data.type() == CV_8UC1 && core_.session()->hasDistortion()) {
+        cv::Mat und(img.data.rows, img.data.cols, CV_32FC1);
+        cv::Mat dense = (img.data.step == (size_t)img.data.cols) ? img.data : img.data.clone();
+        backend::check("rebvio_hip_front_end_u8",
+                       rebvio_hip_front_end_u8(core_.session()->ctx(), dense.ptr<unsigned char>(0), und.ptr<float>(0)));
+        img.data = und;
+      }
+      for (auto& cb : edge_image_callbacks_) cb(img.data, edge_map);
+    }
     {
       // integrate the IMU samples up to this frame BEFORE the map becomes visible to the tracker
       std::lock_guard<std::mutex> guard(imu_buffer_mutex_);

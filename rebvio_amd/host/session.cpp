@@ -1,5 +1,6 @@
 #include "session.hpp"
 
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -40,6 +41,10 @@ std::shared_ptr<Session> Session::forCamera(const Camera& cam) {
   s->p_.cx = cam.cx_;
   s->p_.cy = cam.cy_;
   s->p_.device_id = t_device;
+  const float K4[4] = {cam.fm_, cam.fm_, cam.cx_, cam.cy_};  // K_ uses the mean focal length on both axes (camera.hpp:39)
+  const float D5[5] = {cam.k1_, cam.k2_, cam.p1_, cam.p2_, cam.k3_};
+  std::memcpy(s->K4_, K4, sizeof(K4));
+  std::memcpy(s->D5_, D5, sizeof(D5));
   g_sessions[k] = s;
   return s;
 }
@@ -81,7 +86,10 @@ void Session::setImuNoise(float gyro_std_dev, float gyro_bias_std_dev) {
 
 rebvio_hip_ctx* Session::ctx() {
   std::lock_guard<std::mutex> g(mu_);
-  if (!ctx_) check("rebvio_hip_create", rebvio_hip_create(&p_, &ctx_));
+  if (!ctx_) {
+    check("rebvio_hip_create", rebvio_hip_create(&p_, &ctx_));
+    check("rebvio_hip_set_undistort", rebvio_hip_set_undistort(ctx_, K4_, D5_));
+  }
   return ctx_;
 }
 

@@ -26,11 +26,13 @@ class Session {
   void setImuNoise(float gyro_std_dev, float gyro_bias_std_dev);
   rebvio_hip_ctx* ctx();  // throws std::runtime_error when no GPU / library error: there is no CPU fallback
   const rebvio_hip_params& params() const { return p_; }
+  bool hasDistortion() const { return D5_[0] != 0 || D5_[1] != 0 || D5_[2] != 0 || D5_[3] != 0 || D5_[4] != 0; }
   ~Session();
 
  private:
   Session() = default;
   rebvio_hip_params p_{};
+  float K4_[4]{}, D5_[5]{};  // lens model of the device front end (camera.hpp:39-40)
   rebvio_hip_ctx* ctx_ = nullptr;
   std::mutex mu_;
 };

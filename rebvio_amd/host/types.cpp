@@ -1,5 +1,6 @@
 // Camera, IntegratedImu and the small dense helpers of the host API.
 #include <cmath>
+#include <vector>
 #include <cstring>
 
 #include "../csrc/hostmath.hpp"
@@ -36,26 +37,24 @@ Camera::Camera(unsigned int rows, unsigned int cols, types::Float fx, types::Flo
 }
 
 cv::Mat Camera::undistort(cv::Mat& in) {
+  // cv::undistort(in, out, K(fm,0,cx;0,fm,cy), D) on an fp32 frame: fixed-point maps (1/32 px) + bilinear remap with a
+  // constant-zero border (camera.hpp:54-58). Host version for callers of the public API; rebvio::Rebvio itself sends
+  // MONO8 frames through the device front end (rebvio_hip_set_undistort), which implements the same map.
   if (k1_ == 0 && k2_ == 0 && k3_ == 0 && p1_ == 0 && p2_ == 0) return in;
+  std::vector<int> map((size_t)2 * in.rows * in.cols);
+  rh::hm::undistort_fixed_map(in.rows, in.cols, fm_, fm_, cx_, cy_, k1_, k2_, p1_, p2_, k3_, map.data());
   cv::Mat out(in.rows, in.cols, CV_32FC1);
   for (int v = 0; v < in.rows; ++v) {
     float* o = out.ptr<float>(v);
     for (int u = 0; u < in.cols; ++u) {
-      const double x = (u - cx_) / fm_, y = (v - cy_) / fm_;
-      const double r2 = x * x + y * y;
-      const double kr = 1 + ((k3_ * r2 + k2_) * r2 + k1_) * r2;
-      const double xd = x * kr + 2 * p1_ * x * y + p2_ * (r2 + 2 * x * x);
-      const double yd = y * kr + p1_ * (r2 + 2 * y * y) + 2 * p2_ * x * y;
-      const double us = xd * fm_ + cx_, vs = yd * fm_ + cy_;
-      const int x0 = (int)std::floor(us), y0 = (int)std::floor(vs);
-      float val = 0.f;
-      if (x0 >= 0 && y0 >= 0 && x0 + 1 < in.cols && y0 + 1 < in.rows) {
-        const float ax = (float)(us - x0), ay = (float)(vs - y0);
-        const float* r0 = in.ptr<float>(y0);
-        const float* r1 = in.ptr<float>(y0 + 1);
-        val = (1 - ay) * ((1 - ax) * r0[x0] + ax * r0[x0 + 1]) + ay * ((1 - ax) * r1[x0] + ax * r1[x0 + 1]);
-      }
-      o[u] = val;
+      const int iu = map[((size_t)v * in.cols + u) * 2], iv = map[((size_t)v * in.cols + u) * 2 + 1];
+      const int sx = iu >> 5, sy = iv >> 5;
+      const float ax = (float)(iu & 31) * 0.03125f, ay = (float)(iv & 31) * 0.03125f;
+      auto tap = [&](int y, int x) -> float {
+        return (x >= 0 && x < in.cols && y >= 0 && y < in.rows) ? in.ptr<float>(y)[x] : 0.0f;
+      };
+      o[u] = tap(sy, sx) * ((1.0f - ay) * (1.0f - ax)) + tap(sy, sx + 1) * ((1.0f - ay) * ax) + tap(sy + 1, sx) * (ay * (1.0f - ax)) +
+             tap(sy + 1, sx + 1) * (ay * ax);
     }
   }
   return out;

@@ -28,6 +28,24 @@ class Camera:
     fm: float
     cx: float
     cy: float
+    dist: tuple = (0.0, 0.0, 0.0, 0.0, 0.0)   # rad-tan k1, k2, p1, p2, k3 (camera.hpp:31-35); zero = pinhole
+
+    def undistorted_rays(self):
+        """Normalised pinhole coordinates (x, y) seen by every pixel of the (possibly distorting) lens: inverts
+        xd = x*kr + 2 p1 x y + p2 (r2 + 2 x^2), yd = y*kr + p1 (r2 + 2 y^2) + 2 p2 x y by fixed-point iteration."""
+        xd, yd = np.meshgrid((np.arange(self.width, dtype=np.float64) - self.cx) / self.fm,
+                             (np.arange(self.height, dtype=np.float64) - self.cy) / self.fm)
+        k1, k2, p1, p2, k3 = self.dist
+        if not any(self.dist):
+            return xd, yd
+        x, y = xd.copy(), yd.copy()
+        for _ in range(20):
+            r2 = x * x + y * y
+            kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x, y = (xd - dx) / kr, (yd - dy) / kr
+        return x, y
 
     @staticmethod
     def for_size(width: int, height: int) -> "Camera":
@@ -134,9 +152,7 @@ def pose(scene: Scene, t: float):
 def render_frame(scene: Scene, cam: Camera, t: float, noise_seed: int | None = None, noise_sigma: float = 2.0) -> np.ndarray:
     """Render frame t as u8 [height, width]."""
     R, p = pose(scene, t)
-    xs = (np.arange(cam.width, dtype=np.float64) - cam.cx) / cam.fm
-    ys = (np.arange(cam.height, dtype=np.float64) - cam.cy) / cam.fm
-    X, Y = np.meshgrid(xs, ys)
+    X, Y = cam.undistorted_rays()
     dx = R[0, 0] * X + R[0, 1] * Y + R[0, 2]
     dy = R[1, 0] * X + R[1, 1] * Y + R[1, 2]
     dz = R[2, 0] * X + R[2, 1] * Y + R[2, 2]
@@ -164,9 +180,13 @@ def render_frame(scene: Scene, cam: Camera, t: float, noise_seed: int | None = N
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def render_stream(width: int, height: int, n_frames: int, stream_id: int = 0, density: float = 1.0, noise: bool = True):
-    """Frames 0..n_frames-1 of stream `stream_id` -> (u8 [n, H, W], Camera)."""
+def render_stream(width: int, height: int, n_frames: int, stream_id: int = 0, density: float = 1.0, noise: bool = True,
+                  dist=None):
+    """Frames 0..n_frames-1 of stream `stream_id` -> (u8 [n, H, W], Camera). `dist` = rad-tan lens (k1,k2,p1,p2,k3): the
+    frames are then what that lens sees, and undistorting them gives back the pinhole view."""
     cam = Camera.for_size(width, height)
+    if dist is not None:
+        cam.dist = tuple(float(v) for v in dist)
     scene = make_scene(stream_id, density)
     # keep metric motion per pixel constant across resolutions
     frames = np.empty((n_frames, height, width), np.uint8)

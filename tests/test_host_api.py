@@ -78,24 +78,32 @@ def _write_imu(path, ts, gyro, acc):
     rec.tofile(path)
 
 
+EUROC_D = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]  # camera.hpp:31-35
+
+
 @pytest.mark.gpu
-def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod):
+@pytest.mark.parametrize("dist", [None, EUROC_D], ids=["pinhole", "radtan"])
+def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod, dist):
     """BASELINE config 5 (camera + IMU, SAB scale/attitude/bias filter): rebvio::Rebvio on the device against the oracle's
     restatement of rebvio.cpp:92-293 on the same frames and IMU samples. The per-keyline work is bit-exact, the reductions
     feeding the 3x3 / 6x6 / 7x7 solves are not (REL_SUM in test_parity_gpu.py), so the fused state is compared in tolerance:
     1e-4 rad / 1e-4 m on pose after 29 pairs, 1e-4 on scale, 2e-3 m/s^2 on gravity, 2e-6 rad/frame on gyro bias (observed
-    on MI355X: <= 2e-6 everywhere, match counts identical)."""
+    on MI355X: <= 2e-6 everywhere, match counts identical). The "radtan" case adds the EuRoC lens model: the MONO8 frames
+    then pass through the device front end (x3 + undistort) on one side and the oracle's on the other."""
     from rebvio_amd import synth
     n, W, H = 30, 256, 192
-    frames, cam = synth.render_stream(W, H, n)
+    frames, cam = synth.render_stream(W, H, n, dist=dist)
     scene = synth.make_scene(0)
     ts, gyro, acc = synth.imu_samples(scene, n, noise_seed=1)
     fp, ip = tmp_path / "frames.u8", tmp_path / "imu.bin"
     frames.tofile(fp)
     _write_imu(ip, ts, gyro, acc)
     exe = os.path.join(host_lib, "rebvio_stream_example")
+    env = dict(os.environ)
+    if dist is not None:
+        env["REBVIO_EXAMPLE_DISTORTION"] = ",".join(repr(float(np.float32(v))) for v in dist)
     r = subprocess.run([exe, str(fp), str(W), str(H), str(n), str(cam.fm), str(cam.cx), str(cam.cy), "2500", "3500", str(ip), "100"],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines() if ln and ln[0].isdigit()])
     assert got.shape == (n - 1, 15)
@@ -106,7 +114,10 @@ def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod):
     orc.vio_reset()
     prev, k, want = None, 0, []
     for i in range(n):
-        m = orc.detect_u8(frames[i], i * 50000)
+        if dist is None:
+            m = orc.detect_u8(frames[i], i * 50000)
+        else:
+            m = orc.detect(orc.front_end_u8(frames[i], cam.fm, cam.fm, cam.cx, cam.cy, dist), i * 50000)
         while k < len(ts) and ts[k] <= i * 50000:
             orc.vio_add_imu(m, ts[k], gyro[k], acc[k])
             k += 1

@@ -204,3 +204,51 @@ def test_tracking_recovers_translation_direction(orc_mod, small_stream):
     v = np.array(vs[3:])
     assert (v[:, 0] < 0).all()  # scene moves towards -x for a camera moving +x
     assert np.std(v[:, 0]) < 0.5 * np.abs(np.mean(v[:, 0]))
+
+
+# ---- front end: convertTo(CV_32F, 3.0) + cv::undistort -------------------------------------------------
+EUROC_D = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]  # camera.hpp:31-35
+
+
+def _numpy_undistort(img, fm, cx, cy, D):
+    """Independent float64 statement of the same published algorithm (map in double, 1/32 px quantisation, bilinear with
+    zero border); every product is exact, so float64 == the fp32 result."""
+    H, W = img.shape
+    j, i = np.meshgrid(np.arange(W), np.arange(H))
+    k1, k2, p1, p2, k3 = [float(np.float32(v)) for v in D]
+    fm, cx, cy = float(np.float32(fm)), float(np.float32(cx)), float(np.float32(cy))
+    x, y = (j - cx) / fm, (i - cy) / fm
+    r2 = x * x + y * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + p1 * 2 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + p2 * 2 * x * y
+    iu, iv = np.rint((fm * xd + cx) * 32).astype(int), np.rint((fm * yd + cy) * 32).astype(int)
+    sx, sy, ax, ay = iu >> 5, iv >> 5, (iu & 31) / 32.0, (iv & 31) / 32.0
+    src = img.astype(np.float64) * 3
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        return np.where(ok, src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], 0.0)
+
+    return ((1 - ay) * (1 - ax) * tap(sy, sx) + (1 - ay) * ax * tap(sy, sx + 1) + ay * (1 - ax) * tap(sy + 1, sx)
+            + ay * ax * tap(sy + 1, sx + 1))
+
+
+def test_front_end_identity_and_radial_model(orc_mod, small_stream):
+    frames, cam = small_stream
+    orc = orc_mod.Oracle(params_for(orc_mod, cam))
+    img = np.maximum(frames[0], 1)   # no zero pixels, so a zero in the output can only be the border constant
+    same = orc.front_end_u8(img, cam.fm, cam.fm, cam.cx, cam.cy, [0, 0, 0, 0, 0])
+    assert np.array_equal(same, img.astype(np.float32) * np.float32(3.0))       # no distortion: x3 only, borders included
+    out = orc.front_end_u8(img, cam.fm, cam.fm, cam.cx, cam.cy, EUROC_D)
+    ref = _numpy_undistort(img, cam.fm, cam.cx, cam.cy, EUROC_D)
+    assert np.abs(ref - out).max() <= 0.75                                      # a half-ulp map tie moves one tap by 1/32 px
+    assert (ref != out).mean() < 1e-3
+    # barrel distortion (k1 < 0): the undistorted view samples inside the distorted frame -> no border pixels, and the
+    # principal point is a fixed point of the map
+    assert out.min() > 0
+    ci, cj = int(round(cam.cy)), int(round(cam.cx))
+    assert abs(out[ci, cj] - 3.0 * img[ci, cj]) <= 3.0 * np.abs(np.diff(img[ci, cj - 1:cj + 2].astype(np.float32))).max()
+    # pincushion (k1 > 0) reaches outside the frame: constant-zero border shows up in the corners
+    pin = orc.front_end_u8(img, cam.fm, cam.fm, cam.cx, cam.cy, [0.6, 0, 0, 0, 0])
+    assert pin[0, 0] == 0.0 and pin[-1, -1] == 0.0 and pin[ci, cj] > 0

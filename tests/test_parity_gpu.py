@@ -340,3 +340,40 @@ def test_full_size_properties(B):
         px = np.floor(kg["pos"] + 0.5)
         assert (np.abs(kg["pos"][:, 0] - xs) <= 0.5).all() and (np.abs(kg["pos"][:, 1] - ys) <= 0.5).all()
         assert px.shape[0] == len(kg)
+
+
+# ---- front end: u8 -> x3 -> undistort on the device ----------------------------------------------------
+EUROC_D = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]  # camera.hpp:31-35
+
+
+def test_front_end_undistort_bit_exact(orc_mod, B, c2_stream):
+    frames, cam = c2_stream
+    orc = orc_mod.Oracle(params_for(orc_mod, cam, **KW_C2))
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    for D in (EUROC_D, [0.6, -0.1, 1e-3, -2e-3, 0.05]):   # barrel (inside the frame) and pincushion (reads the zero border)
+        ctx.set_undistort(cam.fm, cam.fm, cam.cx, cam.cy, D)
+        for i in (0, 3):
+            want = orc.front_end_u8(frames[i], cam.fm, cam.fm, cam.cx, cam.cy, D)
+            got = ctx.front_end_u8(frames[i])
+            assert _bits_equal(want, got), f"D={D} frame {i}: {np.abs(want - got).max()}"
+
+
+def test_detect_through_device_front_end(orc_mod, B, c2_stream):
+    """u8 host frame -> device (x3 + undistort + detect) == oracle front end + oracle detect, keyline for keyline; and
+    with the lens model switched off the u8 entry equals the fp32 entry."""
+    frames, cam = c2_stream
+    orc = orc_mod.Oracle(params_for(orc_mod, cam, **KW_C2))
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    ctx.set_undistort(cam.fm, cam.fm, cam.cx, cam.cy, EUROC_D)
+    for i in range(4):
+        om = orc.detect(orc.front_end_u8(frames[i], cam.fm, cam.fm, cam.cx, cam.cy, EUROC_D), i * 50000)
+        gm = ctx.detect_u8_host(frames[i], i * 50000)
+        assert_keylines_equal(om.keylines(), gm.keylines(), what=f"undistorted frame {i}")
+        assert om.threshold == gm.threshold
+    ctx2 = B.Context(params_for(B, cam, **KW_C2))
+    ctx3 = B.Context(params_for(B, cam, **KW_C2))
+    ctx3.set_undistort(cam.fm, cam.fm, cam.cx, cam.cy, [0, 0, 0, 0, 0])
+    for i in range(3):
+        a = ctx2.detect_u8(frames[i], i * 50000)
+        b = ctx3.detect_u8_host(frames[i], i * 50000)
+        assert_keylines_equal(a.keylines(), b.keylines(), what=f"u8 entry frame {i}")

@@ -8,7 +8,8 @@ from oracle import oracle_py as O
 
 def main():
     n, W, H = 30, 256, 192
-    frames, cam = synth.render_stream(W, H, n)
+    dist = [float(np.float32(v)) for v in os.environ["VIO_DIST"].split(",")] if os.environ.get("VIO_DIST") else None
+    frames, cam = synth.render_stream(W, H, n, dist=dist)
     scene = synth.make_scene(0)
     ts, gyro, acc = synth.imu_samples(scene, n, noise_seed=1)
     d = tempfile.mkdtemp()
@@ -18,8 +19,11 @@ def main():
     rec["ts"], rec["gyro"], rec["acc"] = ts, gyro, acc
     rec.tofile(ip)
     exe = os.path.join(ROOT, "rebvio_amd", "_build", "rebvio_stream_example")
+    env = dict(os.environ)
+    if dist:
+        env["REBVIO_EXAMPLE_DISTORTION"] = ",".join(repr(v) for v in dist)
     r = subprocess.run([exe, fp, str(W), str(H), str(n), str(cam.fm), str(cam.cx), str(cam.cy), "2500", "3500", ip, "100"],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300, env=env)
     print(r.stderr[-500:])
     got = np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines() if ln and ln[0].isdigit()])
     O.build()
@@ -27,7 +31,10 @@ def main():
     orc = O.Oracle(p); orc.vio_reset()
     prev, k, want = None, 0, []
     for i in range(n):
-        m = orc.detect_u8(frames[i], i * 50000)
+        if dist:
+            m = orc.detect(orc.front_end_u8(frames[i], cam.fm, cam.fm, cam.cx, cam.cy, dist), i * 50000)
+        else:
+            m = orc.detect_u8(frames[i], i * 50000)
         while k < len(ts) and ts[k] <= i * 50000:
             orc.vio_add_imu(m, ts[k], gyro[k], acc[k]); k += 1
         if prev is not None:
