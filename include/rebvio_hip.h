@@ -131,6 +131,11 @@ uint64_t rebvio_hip_map_ts(rebvio_hip_map* m);
 /* Lazy host mirror of keylines() / mask() (edge_map.hpp:50,75): AoS keylines (may be NULL) and the
  * dense image-index -> keyline-index table (may be NULL; -1 = none). */
 int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int* mask);
+/* Edge image for registerEdgeImageCallback consumers, rendered on the device the way ros_rebvio.cpp:32-50 draws it on
+ * the host: the grey frame (rows*cols bytes, NULL = black) replicated to RGB, each keyline's pixel
+ * (round(pos[1]), round(pos[0])) set to (255,0,0). rgb_out = rows*cols*3 bytes. Synchronises. */
+int rebvio_hip_render_edge_image(rebvio_hip_map* map, const uint8_t* gray_host, uint8_t* rgb_out_host);
+
 /* Test hook: overwrite the device keylines (count must equal the map size). */
 int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines, int n);
 void rebvio_hip_map_release(rebvio_hip_map* m);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rebvio_hip_map_threshold": (C.c_float, [_vp]),
     "rebvio_hip_map_ts": (C.c_uint64, [_vp]),
     "rebvio_hip_map_download": (C.c_int, [_vp, _vp, _ip]),
+    "rebvio_hip_render_edge_image": (C.c_int, [_vp, _vp, _vp]),
     "rebvio_hip_map_upload": (C.c_int, [_vp, _vp, C.c_int]),
     "rebvio_hip_map_release": (None, [_vp]),
     "rebvio_hip_build_distance_field": (C.c_int, [_vp, _vp]),
@@ -174,6 +175,17 @@ class Map:
     @property
     def threshold(self):
         return lib().rebvio_hip_map_threshold(self.h)
+
+    def render_edge_image(self, gray_u8=None) -> np.ndarray:
+        rows, cols = self.ctx.rows, self.ctx.cols
+        out = np.empty((rows, cols, 3), np.uint8)
+        g = None
+        if gray_u8 is not None:
+            gray_u8 = np.ascontiguousarray(gray_u8, np.uint8)
+            assert gray_u8.shape == (rows, cols)
+            g = gray_u8.ctypes.data_as(_vp)
+        _chk(lib().rebvio_hip_render_edge_image(self.h, g, out.ctypes.data_as(_vp)))
+        return out
 
     def keylines(self) -> np.ndarray:
         out = np.zeros(self.size(), KEYLINE_DTYPE)

@@ -878,6 +878,23 @@ int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int
   return 0;
 }
 
+int rebvio_hip_render_edge_image(rebvio_hip_map* m, const uint8_t* gray, uint8_t* rgb_out) {
+  rebvio_hip_ctx* c = m->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->s_det));  // the staging frame and the scratch are shared with the detect path
+  HIPCHK(hipStreamSynchronize(c->s_key));
+  HIPCHK(hipStreamSynchronize(c->s_df));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  const size_t Pn = (size_t)c->P.rows * c->P.cols;
+  uint8_t* rgb = reinterpret_cast<uint8_t*>(c->scratch_i);  // 8 bytes/pixel available, 3 used
+  if (gray) HIPCHK(hipMemcpyAsync(c->img8_dev, gray, Pn, hipMemcpyHostToDevice, c->s_cpy));
+  launch_render_edge_image(c->s_cpy, c->K, m->d, gray ? c->img8_dev : nullptr, rgb);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(rgb_out, rgb, 3 * Pn, hipMemcpyDeviceToHost, c->s_cpy));
+  HIPCHK(hipStreamSynchronize(c->s_cpy));
+  return 0;
+}
+
 int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines, int n) {
   rebvio_hip_ctx* c = m->ctx;
   HIPCHK(hipSetDevice(c->device));

@@ -160,6 +160,7 @@ void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, con
 void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate, int* work_n_reset);
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp,
                       int min_matches_gate);
+void launch_render_edge_image(hipStream_t s, const KParams& p, const MapDev& m, const uint8_t* gray_or_null, uint8_t* rgb);
 void launch_map_pack(hipStream_t s, const KParams& p, const MapDev& m, rebvio_hip_keyline* aos_dev);
 void launch_map_unpack(hipStream_t s, const KParams& p, const MapDev& m, const rebvio_hip_keyline* aos_dev, int n);
 

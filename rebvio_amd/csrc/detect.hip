@@ -655,6 +655,28 @@ __global__ __launch_bounds__(256) void k_map_unpack(MapDev m, const rebvio_hip_k
   m.matches[idx] = k.matches;
 }
 
+// ---- edge image of the callback consumers (what ros_rebvio.cpp:32-50 draws on the host): the grey frame
+// replicated to RGB, every keyline's pixel (round(pos.y), round(pos.x)) set to (255, 0, 0) ----------------------------
+__global__ __launch_bounds__(256) void k_render_gray(const uint8_t* __restrict__ gray, uint8_t* __restrict__ rgb, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t g = gray ? gray[i] : (uint8_t)0;
+  rgb[3 * i] = g;
+  rgb[3 * i + 1] = g;
+  rgb[3 * i + 2] = g;
+}
+__global__ __launch_bounds__(256) void k_render_keylines(KParams p, MapDev m, uint8_t* __restrict__ rgb) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= m.st->n) return;
+  const float2 q = m.pos[idx];
+  const int row = cvtt_f32(roundf(q.y)), col = cvtt_f32(roundf(q.x));
+  if ((unsigned)row >= (unsigned)p.rows || (unsigned)col >= (unsigned)p.cols) return;
+  uint8_t* o = rgb + 3 * ((size_t)row * p.cols + col);
+  o[0] = 255;
+  o[1] = 0;
+  o[2] = 0;
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------
 static int lds_pitch(int cols) {
   int pad = 4;
@@ -746,6 +768,11 @@ void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const Det
 
 void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out) {
   RH_LAUNCH(k_df_decode, dim3(div_up(p.rows * p.cols, 256)), dim3(256), 0, s, p, m, id_out, dist_out);
+}
+
+void launch_render_edge_image(hipStream_t s, const KParams& p, const MapDev& m, const uint8_t* gray_or_null, uint8_t* rgb) {
+  RH_LAUNCH(k_render_gray, dim3(div_up(p.rows * p.cols, 256)), dim3(256), 0, s, gray_or_null, rgb, p.rows * p.cols);
+  RH_LAUNCH(k_render_keylines, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, rgb);
 }
 
 void launch_map_pack(hipStream_t s, const KParams& p, const MapDev& m, rebvio_hip_keyline* aos_dev) {

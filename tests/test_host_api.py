@@ -40,6 +40,37 @@ def test_sab_estimator_analytic_cases(host_lib, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_stream_io_png_asl_replay_and_odometry_format(host_lib, tmp_path):
+    """SURVEY.md N4 on the CPU: PNG decoding (all five scanline filters, split IDAT), EuRoC folder parsing with unordered
+    csv rows, replay ordering, and the odometry text format pinned by the reference's own regression file."""
+    from pngutil import write_asl, write_png
+    rng = np.random.default_rng(5)
+    n, W, H = 6, 64, 40
+    frames = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    frames[1] = np.arange(W, dtype=np.uint8)[None, :] * 3          # smooth rows: exercises Sub / Average / Paeth predictions
+    ts = 1000000 + np.arange(n) * 50000
+    its = np.concatenate([ts[i] + (np.arange(10) + 1) * 5000 for i in range(n - 1)])
+    gyro = np.tile(np.array([0.0, 0.25, 0.0], np.float32), (len(its), 1))
+    acc = np.tile(np.array([0.0, 0.0, -9.5], np.float32), (len(its), 1))
+    write_asl(str(tmp_path / "mav0"), frames, ts, its, gyro, acc, shuffle_seed=3)
+    frames.tofile(tmp_path / "frames.u8")
+    exe = str(tmp_path / "stream_io")
+    subprocess.run(["g++", "-std=c++17", "-O1"] + INC + [os.path.join(ROOT, "tests", "cpp", "test_stream_io.cpp"), "-o", exe,
+                    "-L", host_lib, "-lrebvio", "-lrebvio_hip", f"-Wl,-rpath,{host_lib}", "-pthread"], check=True)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    write_png(str(tmp_path / "rgb.png"), rgb, filters=(4, 1))
+    ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14
+     ).astype(np.uint8).tofile(tmp_path / "rgb.want")
+    g16 = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+    write_png(str(tmp_path / "g16.png"), g16, filters=(3, 2), depth=16)
+    (g16 >> 8).astype(np.uint8).tofile(tmp_path / "g16.want")
+    r = subprocess.run([exe, str(tmp_path / "mav0"), str(tmp_path / "frames.u8"), str(W), str(H), str(n),
+                        os.path.join(ROOT, "tests", "golden", "MH_03_medium_test_15s-30s_odometry.txt"),
+                        str(tmp_path / "rgb.png"), str(tmp_path / "rgb.want"), str(tmp_path / "g16.png"), str(tmp_path / "g16.want")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_host_library_exports_reference_classes(host_lib):
     out = subprocess.run(["nm", "-DC", os.path.join(host_lib, "librebvio.so")], capture_output=True, text=True, check=True).stdout
     for sym in ("rebvio::Rebvio::Rebvio(rebvio::RebvioConfig&)", "rebvio::Rebvio::imageCallback(rebvio::types::Image&&)",
@@ -135,3 +166,35 @@ def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod, dist):
     np.testing.assert_allclose(got[:, 8:11], want[:, 8:11], atol=2e-3)  # gravity
     np.testing.assert_allclose(got[:, 11:14], want[:, 11:14], atol=2e-6)  # gyro bias
     assert np.abs(got[:, 14] - want[:, 14]).max() <= 2                  # directedMatch counts
+
+
+@pytest.mark.gpu
+def test_replay_asl_folder_equals_raw_stream(host_lib, tmp_path):
+    """rebvio_replay over an EuRoC-layout folder (PNG frames, csv IMU) and over the same data as raw files writes the same
+    odometry file, in the reference's regression format, and agrees with the ros_rebvio-style example."""
+    from pngutil import write_asl
+    from rebvio_amd import synth
+    n, W, H = 22, 256, 192
+    frames, cam = synth.render_stream(W, H, n)
+    ts, gyro, acc = synth.imu_samples(synth.make_scene(0), n, noise_seed=1)
+    write_asl(str(tmp_path / "mav0"), frames, np.arange(n) * 50000, ts, gyro, acc, shuffle_seed=1, filters=(0, 4))
+    frames.tofile(tmp_path / "frames.u8")
+    _write_imu(tmp_path / "imu.bin", ts, gyro, acc)
+    common = ["--camera", str(cam.fm), str(cam.cx), str(cam.cy), "--keylines", "2500", "3500", "--min-matches", "100"]
+    exe = os.path.join(host_lib, "rebvio_replay")
+    a = subprocess.run([exe, "--asl", str(tmp_path / "mav0"), "--out", str(tmp_path / "a.txt")] + common, capture_output=True, text=True,
+                       timeout=300)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([exe, "--raw", str(tmp_path / "frames.u8"), "--size", str(W), str(H), "--imu", str(tmp_path / "imu.bin"),
+                        "--out", str(tmp_path / "b.txt")] + common, capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-2000:]
+    ta, tb = (tmp_path / "a.txt").read_text(), (tmp_path / "b.txt").read_text()
+    assert ta == tb and len(ta.splitlines()) == n - 1
+    vals = np.array([[float(x) for x in ln.split()] for ln in ta.splitlines()])
+    assert (vals[:15, 1:] == 0).all() and np.abs(vals[-1, 4:]).max() > 0
+    ex = subprocess.run([os.path.join(host_lib, "rebvio_stream_example"), str(tmp_path / "frames.u8"), str(W), str(H), str(n), str(cam.fm),
+                         str(cam.cx), str(cam.cy), "2500", "3500", str(tmp_path / "imu.bin"), "100"], capture_output=True, text=True,
+                        timeout=300)
+    assert ex.returncode == 0
+    ev = np.array([[float(x) for x in ln.split()[:7]] for ln in ex.stdout.strip().splitlines() if ln and ln[0].isdigit()])
+    np.testing.assert_allclose(ev, vals, atol=1e-6)

@@ -377,3 +377,19 @@ def test_detect_through_device_front_end(orc_mod, B, c2_stream):
         a = ctx2.detect_u8(frames[i], i * 50000)
         b = ctx3.detect_u8_host(frames[i], i * 50000)
         assert_keylines_equal(a.keylines(), b.keylines(), what=f"u8 entry frame {i}")
+
+
+def test_edge_image_rendering(B, c2_stream):
+    """Device-side edge image == what ros_rebvio.cpp:32-50 draws: grey -> RGB, keyline pixels red."""
+    frames, cam = c2_stream
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    m = ctx.detect_u8(frames[0], 0)
+    kl = m.keylines()
+    want = np.repeat(frames[0][:, :, None], 3, axis=2)
+    rows = np.floor(kl["pos"][:, 1] + 0.5).astype(int)   # std::round for the non-negative pixel coordinates
+    cols = np.floor(kl["pos"][:, 0] + 0.5).astype(int)
+    want[rows, cols] = (255, 0, 0)
+    got = m.render_edge_image(frames[0])
+    assert np.array_equal(got, want)
+    black = m.render_edge_image(None)
+    assert black.sum() == 255 * len(np.unique(rows * cam.width + cols))
