@@ -190,6 +190,11 @@ struct rebvio_hip_ctx {
   int* dm_work_n = nullptr; // its length (zero between pairs)
   float* fscratch = nullptr;
   int maxblocks = 0;
+  // persistent LM kernel: barrier arrival counter, its host-side shadow, sticky time-out flag
+  unsigned* lm_bar = nullptr;
+  unsigned lm_bar_base = 0;
+  int* lm_bar_err = nullptr;  // pinned, zero-copy
+  bool lm_persistent = true;
   rebvio_hip_map* df_map = nullptr;
   // pinned host staging
   LmState* h_lm = nullptr;   // [2]
@@ -256,8 +261,8 @@ inline void wait_enqueued(rebvio_hip_map* m) {
 size_t part_call_stride(const rebvio_hip_ctx* c) { return (size_t)c->maxblocks * kPartStride; }
 
 int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
-  // keyline arrays are padded to the launch grid (multiple of 256) so kernels may load before checking n
-  const size_t M = (size_t)div_up(c->P.keylines_max, 256) * 256, Pn = (size_t)c->P.rows * c->P.cols;
+  // keyline arrays are padded to the launch grids (256- and 1024-thread workgroups) so kernels may load before checking n
+  const size_t M = (size_t)div_up(c->P.keylines_max, 1024) * 1024, Pn = (size_t)c->P.rows * c->P.cols;
   MapDev& d = m->d;
   HIPCHK(hipMalloc(&d.pos, M * sizeof(float2)));
   HIPCHK(hipMalloc(&d.pos_img, M * sizeof(float2)));
@@ -513,6 +518,33 @@ void enqueue_lm_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm,
   prof_group_end(c->s_trk);
 }
 
+// minimizeVel + forwardMatch + extRotVel of one pair on the track stream (rebvio.cpp:167-177); results land in `slot`.
+// Default: the persistent kernel (one launch); REBVIO_HIP_LM=percall selects the per-evaluation kernels, which compute
+// identical bits (same per-keyline code, same record order).
+int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3], PairSlot* slot) {
+  const int calls = (int)c->P.iterations + 1;
+  if (!c->lm_persistent) {
+    enqueue_lm_chain(c, om, nm, vel0);
+    launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
+                       c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, vel0, slot, c->hist);
+    return 0;
+  }
+  if (*c->lm_bar_err) return fail_msg("persistent LM kernel: grid barrier timed out", -9);
+  LmState* first = c->lm_zero;
+  if (vel0[0] != 0.f || vel0[1] != 0.f || vel0[2] != 0.f) {
+    LmState init;
+    std::memset(&init, 0, sizeof(init));
+    for (int i = 0; i < 3; ++i) init.vel[i] = vel0[i];
+    c->h_lm[1] = init;
+    (void)hipMemcpyAsync(c->lm, &c->h_lm[1], sizeof(LmState), hipMemcpyHostToDevice, c->s_trk);
+    first = c->lm;
+  }
+  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, 1, first, c->lm + calls + 1, c->part, c->lm_bar, c->lm_bar_base, c->lm_bar_err,
+                  c->hist, slot->xrv, slot, c->hist);
+  c->lm_bar_base += (unsigned)calls * (unsigned)lm_chain_grid(c->K.kmax);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -654,7 +686,12 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->aos_dev, (size_t)p->keylines_max * sizeof(rebvio_hip_keyline)));
   HIPCHK(hipMalloc(&c->scratch_i, 2 * Pn * sizeof(int)));
 
-  c->maxblocks = div_up(p->keylines_max, 256);
+  c->maxblocks = lm_chain_grid(p->keylines_max) * 4;  // record groups of 256 keylines, padded to whole 1024-thread workgroups
+  HIPCHK(hipMalloc(&c->lm_bar, sizeof(unsigned)));
+  HIPCHK(hipMemset(c->lm_bar, 0, sizeof(unsigned)));
+  HIPCHK(hipHostMalloc(&c->lm_bar_err, sizeof(int), hipHostMallocDefault));
+  *c->lm_bar_err = 0;
+  if (const char* e = std::getenv("REBVIO_HIP_LM")) c->lm_persistent = std::strcmp(e, "percall") != 0;
   HIPCHK(hipMalloc(&c->lm, 16 * sizeof(LmState)));
   HIPCHK(hipMemset(c->lm, 0, 16 * sizeof(LmState)));
   HIPCHK(hipMalloc(&c->part, (size_t)(kMaxLmCalls + 1) * part_call_stride(c) * sizeof(float)));
@@ -741,6 +778,8 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->undist_map) (void)hipFree(c->undist_map);
   for (int i = 0; i < 2; ++i)
     if (c->undist_img[i]) (void)hipFree(c->undist_img[i]);
+  if (c->lm_bar) (void)hipFree(c->lm_bar);
+  if (c->lm_bar_err) (void)hipHostFree(c->lm_bar_err);
   if (c->lm_zero) (void)hipFree(c->lm_zero);
   if (c->dm_work) (void)hipFree(c->dm_work);
   if (c->dm_work_n) (void)hipFree(c->dm_work_n);
@@ -1202,12 +1241,10 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   hm::store3(hm::transpose(R), RT);
   launch_rotate(s, c->K, om->d, RT, c->hist, 0);  // rebvio.cpp:165 (+ histogram for estimateQuantile; hist is zero here)
   const float v0[3] = {0, 0, 0};                  // imu_state_.Vg = Zeros (rebvio.cpp:167)
-  enqueue_lm_chain(c, om, nm, v0);                // minimizeVel (rebvio.cpp:169)
-  const int calls = (int)c->P.iterations + 1;
-  // forwardMatch + extRotVel (rebvio.cpp:172-177), LM's last accept/reject in the prologue; results land in slot 0
+  // minimizeVel, forwardMatch + extRotVel (rebvio.cpp:169-177); results land in slot 0
   PairSlot* slot = c->slot[0];
-  launch_ext_rot_vel(s, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
-                     c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, v0, slot, c->hist);
+  rc = enqueue_pair_lm(c, om, nm, v0, slot);
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
   nm->n_host = slot->new_st.n;
@@ -1244,11 +1281,9 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   hm::store3(hm::transpose(R), RT);
   launch_rotate(s, c->K, om->d, RT, c->hist, 0);
   const float v0[3] = {0, 0, 0};
-  enqueue_lm_chain(c, om, nm, v0);
-  const int calls = (int)c->P.iterations + 1;
   PairSlot* slot = c->slot[0];
-  launch_ext_rot_vel(s, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
-                     c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, v0, slot, c->hist);
+  rc = enqueue_pair_lm(c, om, nm, v0, slot);
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
   nm->n_host = slot->new_st.n;
@@ -1314,11 +1349,9 @@ int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   hm::store3(hm::transpose(pp.R), RT);
   if (!pp.om->pre_rotated) launch_rotate(s, c->K, pp.om->d, RT, c->hist, 0);  // else done by the previous B-chain
   const float v0[3] = {0, 0, 0};
-  enqueue_lm_chain(c, pp.om, pp.nm, v0);
-  const int calls = (int)c->P.iterations + 1;
   PairSlot* slot = c->slot[pp.slot];
-  launch_ext_rot_vel(s, c->K, pp.om->d, pp.nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
-                     c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, v0, slot, c->hist);
+  int rc = enqueue_pair_lm(c, pp.om, pp.nm, v0, slot);
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->slot_ev[pp.slot], s));
   if (c->dbg) (void)hipEventRecord(c->dbg_ev[2], s);

@@ -149,6 +149,13 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
                         float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero);
 void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm);
+// Persistent minimizeVel (+ forwardMatch + extRotVel when do_ext): one launch, grid barriers between the evaluations.
+// `bar` counts barrier arrivals monotonically; the caller passes bar_base = arrivals before this launch and advances
+// it by calls * lm_chain_grid(kmax).
+inline int lm_chain_grid(int kmax) { return (kmax + 1023) / 1024; }
+void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
+                     LmState* st_out, float* part, unsigned* bar, unsigned bar_base, int* bar_err, const int* hist, float* xrv_part,
+                     PairSlot* slot, int* hist_to_zero);
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,

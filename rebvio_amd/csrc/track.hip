@@ -28,6 +28,23 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Wave total through the DPP data path (no LDS crossbar traffic, unlike __shfl_xor = ds_bpermute): Hillis-Steele steps
+// inside each row of 16 lanes (row_shr 1,2,4,8, zero fill), then row_bcast15 into rows 1 and 3, row_bcast31 into rows
+// 2 and 3. The total is valid in LANE 63 only; the tree is fixed, so results are reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_total63_f(float v) {
+  v = dpp_add_f<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add_f<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add_f<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add_f<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add_f<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add_f<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -284,6 +301,89 @@ __device__ void reduce_staged_records(const float* rec, int nblocks, float* red 
   }
 }
 
+// Per-keyline body of Core::tryVel / calculatefJ / testfk (core.cpp:39-148), shared by the per-call kernel and the
+// persistent LM kernel.
+struct TvIn {
+  float gn;
+  float2 rs, pi, g2;
+  unsigned nmatches;
+};
+struct TvOut {
+  float f, jx, jy, jz, fi, res_out;
+  int mfwd;
+  bool contrib, matched, need_carry, wrote_res;
+};
+__device__ __forceinline__ TvOut try_vel_eval(const KParams& p, const MapDev& nm, const TvIn& k, float res_in, float cin, float vx,
+                                              float vy, float vz, float srm, float thr, unsigned min_matches) {
+  const float gn = k.gn;
+  const float2 rs = k.rs, pi = k.pi, g2 = k.g2;
+  float f = 0.f, jx = 0.f, jy = 0.f, jz = 0.f, fi = 0.f, res_out = 0.f;
+  bool contrib = false, matched = false, need_carry = false, wrote_res = false;
+  int mfwd = -1;
+  const bool skip = (thr > 0.0f && gn < thr) || (rs.y > srm) || (k.nmatches < min_matches);
+  if (!skip) {
+    float res = res_in;
+    if (res == kResidualCarry) res = cin;
+    res_out = res;
+    float weight = 1.0f;
+    if (res > p.reweight_distance) weight = p.reweight_distance / res;
+    const float z_p = (float)(1.0 / (double)rs.x + (double)vz);
+    bool penalty1 = false;
+    float rho_p = 0.f, p_x = 0.f, p_y = 0.f, p_xc = 0.f, p_yc = 0.f;
+    int x = 0, y = 0;
+    if (z_p <= 0.0f) {
+      penalty1 = true;
+    } else {
+      rho_p = (float)(1.0 / (double)z_p);
+      p_x = rho_p * (vx * p.fm - vz * pi.x) + pi.x;
+      p_y = rho_p * (vy * p.fm - vz * pi.y) + pi.y;
+      p_xc = p_x + p.cx;
+      p_yc = p_y + p.cy;
+      x = cvtt_f64((double)p_xc + 0.5);
+      y = cvtt_f64((double)p_yc + 0.5);
+      if (x < 1 || y < 1 || (unsigned)x >= (unsigned)p.cols - 1u || (unsigned)y >= (unsigned)p.rows - 1u) penalty1 = true;
+    }
+    contrib = true;
+    if (penalty1) {
+      f = (float)(((1.0 / (double)rs.y) * (double)p.search_range) * (double)weight);
+    } else {
+      float df_dx = 0.f, df_dy = 0.f;
+      const unsigned key = nm.df[(size_t)y * p.cols + x];
+      if (key != kDfEmpty) {
+        const int id = (int)((kDfSeqMask - (key & kDfSeqMask)) / (unsigned)p.df_nr);
+        const float2 g1 = nm.grad[id];
+        const float2 pn = nm.pos[id];   // issued with g1: one gather round trip
+        const float gnn = nm.gnorm[id];
+        const float norm_squared = gn * gn;
+        const float dot_product = g1.x * g2.x + g1.y * g2.y;
+        if (!(fabsf(dot_product - norm_squared) > p.match_treshold * norm_squared)) {
+          const float dx = p_xc - pn.x;
+          const float dy = p_yc - pn.y;
+          const float gnx = g1.x / gnn;
+          const float gny = g1.y / gnn;
+          fi = (dx * gnx + dy * gny);
+          df_dx = gnx / rs.y;
+          df_dy = gny / rs.y;
+          mfwd = id;
+          f = fi / rs.y;
+          matched = true;
+        }
+      }
+      if (!matched) {
+        f = p.search_range / rs.y;
+        need_carry = true;
+      }
+      f *= weight;
+      jx = rho_p * p.fm * df_dx * weight;
+      jy = rho_p * p.fm * df_dy * weight;
+      jz = -rho_p * (p_x * df_dx + p_y * df_dy) * weight;
+      if (matched) res_out = fabsf(fi);
+    }
+    wrote_res = !need_carry;
+  }
+  return TvOut{f, jx, jy, jz, fi, res_out, mfwd, contrib, matched, need_carry, wrote_res};
+}
+
 // ---- Core::tryVel + calculatefJ + testfk (core.cpp:39-148) ---------------------------------------------------
 // mode_lm = 0: evaluate at st_in->Vnew with st_in->sigma_rho_min (stand-alone tryVel).
 // mode_lm = 1: call `call` of minimizeVel; prologue derives the LM state from the previous call's records.
@@ -343,77 +443,20 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
   const unsigned min_matches = min(p.min_match_threshold, frame_count);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 
-  float f = 0.f, jx = 0.f, jy = 0.f, jz = 0.f, fi = 0.f;
-  bool contrib = false, matched = false, need_carry = false;
+  TvOut e{};
+  e.mfwd = -1;
   if (idx < n) {
-    int mfwd = -1;
-    const bool skip = (thr > 0.0f && gn < thr) || (rs.y > srm) || (nmatches < min_matches);
-    if (!skip) {
-      float res = res_in;
-      if (res == kResidualCarry) res = cin;
-      float res_out = res;
-      float weight = 1.0f;
-      if (res > p.reweight_distance) weight = p.reweight_distance / res;
-      const float z_p = (float)(1.0 / (double)rs.x + (double)vz);
-      bool penalty1 = false;
-      float rho_p = 0.f, p_x = 0.f, p_y = 0.f, p_xc = 0.f, p_yc = 0.f;
-      int x = 0, y = 0;
-      if (z_p <= 0.0f) {
-        penalty1 = true;
-      } else {
-        rho_p = (float)(1.0 / (double)z_p);
-        p_x = rho_p * (vx * p.fm - vz * pi.x) + pi.x;
-        p_y = rho_p * (vy * p.fm - vz * pi.y) + pi.y;
-        p_xc = p_x + p.cx;
-        p_yc = p_y + p.cy;
-        x = cvtt_f64((double)p_xc + 0.5);
-        y = cvtt_f64((double)p_yc + 0.5);
-        if (x < 1 || y < 1 || (unsigned)x >= (unsigned)p.cols - 1u || (unsigned)y >= (unsigned)p.rows - 1u) penalty1 = true;
-      }
-      contrib = true;
-      if (penalty1) {
-        f = (float)(((1.0 / (double)rs.y) * (double)p.search_range) * (double)weight);
-      } else {
-        float df_dx = 0.f, df_dy = 0.f;
-        const unsigned key = nm.df[(size_t)y * p.cols + x];
-        if (key != kDfEmpty) {
-          const int id = (int)((kDfSeqMask - (key & kDfSeqMask)) / (unsigned)p.df_nr);
-          const float2 g1 = nm.grad[id];
-          const float2 pn = nm.pos[id];   // issued with g1: one gather round trip
-          const float gnn = nm.gnorm[id];
-          const float norm_squared = gn * gn;
-          const float dot_product = g1.x * g2.x + g1.y * g2.y;
-          if (!(fabsf(dot_product - norm_squared) > p.match_treshold * norm_squared)) {
-            const float dx = p_xc - pn.x;
-            const float dy = p_yc - pn.y;
-            const float gnx = g1.x / gnn;
-            const float gny = g1.y / gnn;
-            fi = (dx * gnx + dy * gny);
-            df_dx = gnx / rs.y;
-            df_dy = gny / rs.y;
-            mfwd = id;
-            f = fi / rs.y;
-            matched = true;
-          }
-        }
-        if (!matched) {
-          f = p.search_range / rs.y;
-          need_carry = true;
-        }
-        f *= weight;
-        jx = rho_p * p.fm * df_dx * weight;
-        jy = rho_p * p.fm * df_dy * weight;
-        jz = -rho_p * (p_x * df_dx + p_y * df_dy) * weight;
-        if (matched) res_out = fabsf(fi);
-      }
-      if (!need_carry) om.residual[idx] = res_out;
-      if (matched && last) {
-        const unsigned long long key = ((unsigned long long)order_key(rs.x) << 32) | (unsigned)idx;
-        atomicMax(&nm.fwd_key[mfwd], key);
-      }
+    const TvIn in{gn, rs, pi, g2, nmatches};
+    e = try_vel_eval(p, nm, in, res_in, cin, vx, vy, vz, srm, thr, min_matches);
+    if (e.wrote_res) om.residual[idx] = e.res_out;
+    if (e.matched && last) {
+      const unsigned long long key = ((unsigned long long)order_key(rs.x) << 32) | (unsigned)idx;
+      atomicMax(&nm.fwd_key[e.mfwd], key);
     }
-    om.match_fwd[idx] = mfwd;
+    om.match_fwd[idx] = e.mfwd;
   }
+  const float f = e.f, jx = e.jx, jy = e.jy, jz = e.jz, fi = e.fi;
+  const bool contrib = e.contrib, matched = e.matched, need_carry = e.need_carry;
 
   // carry-forward of the last written fi (index order) for calculatefJ's early-return paths
   const unsigned long long mm = __ballot(matched);
@@ -430,8 +473,8 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
   const float sc = contrib ? f * f : 0.f;
   float v[10] = {sc, jx * jx, jy * jy, jz * jz, jx * jy, jx * jz, jy * jz, jx * f, jy * f, jz * f};
 #pragma unroll
-  for (int k = 0; k < 10; ++k) v[k] = wave_sum_f(v[k]);
-  if (lane == 0) {
+  for (int k = 0; k < 10; ++k) v[k] = wave_total63_f(v[k]);
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) wsum[wid][k] = v[k];
   }
@@ -496,6 +539,61 @@ __global__ __launch_bounds__(256) void k_forward_keys(MapDev om, MapDev nm) {
   atomicMax(&nm.fwd_key[j], key);
 }
 
+// Per-keyline body of forwardMatch's gather (edge_map.cpp:78-96) and of extRotVel's row (core.cpp:198-245), shared by
+// the per-call kernel and the persistent LM kernel.
+struct XrvIn {
+  unsigned long long key;
+  int mid;
+  float2 rs, mpi, g;
+  float gn;
+  float2 q;
+};
+__device__ __forceinline__ void xrv_eval(const KParams& p, const MapDev& om, MapDev& nm, int idx, int do_forward, XrvIn k, float vx,
+                                         float vy, float vz, float row[6], float* Y_out, int* cnt_out) {
+  float2 rs = k.rs, mpi = k.mpi;
+  int mid = k.mid;
+  if (do_forward) {
+    if (k.key != 0ull) {
+      const int o = (int)(unsigned)(k.key & 0xFFFFFFFFull);
+      rs = om.rs[o];
+      mpi = om.pos_img[o];
+      mid = o;
+      nm.rs[idx] = rs;
+      nm.matches[idx] = om.matches[o] + 1u;
+      nm.match_id[idx] = o;
+      nm.mpos_img[idx] = mpi;
+      nm.mgrad[idx] = om.grad[o];
+      nm.mgnorm[idx] = om.gnorm[o];
+      nm.match_kf[idx] = om.match_kf[o];
+    }
+  }
+  if (mid >= 0) {
+    const float u_x = k.g.x / k.gn;
+    const float u_y = k.g.y / k.gn;
+    const float rho_t = (float)(1.0 / (1.0 / (double)rs.x + (double)vz));
+    const float qt_x = mpi.x + rho_t * (vx * p.fm - vz * mpi.x);
+    const float qt_y = mpi.y + rho_t * (vy * p.fm - vz * mpi.y);
+    const float q_x = k.q.x, q_y = k.q.y;
+    row[0] = u_x * rho_t * p.fm;
+    row[1] = u_y * rho_t * p.fm;
+    row[2] = u_x * (-rho_t * q_x) + u_y * (-rho_t * q_y);
+    row[3] = -u_x * q_x * q_y / p.fm - u_y * (p.fm + q_y * q_y / p.fm);
+    row[4] = u_y * q_x * q_y / p.fm + u_x * (p.fm + q_x * q_x / p.fm);
+    row[5] = -u_x * q_y + u_y * q_x;
+    float Y = u_x * (q_x - qt_x) + u_y * (q_y - qt_y);
+    const float dqvel = u_x * (vx * p.fm - vz * mpi.x) + u_y * (vy * p.fm - vz * mpi.y);
+    const float s_y = sqrtf(rs.y * rs.y * dqvel * dqvel + p.pixel_uncertainty * p.pixel_uncertainty);
+    float weight = 1.0f;
+    if (fabsf(Y) > p.reweight_distance) weight = fabsf(Y) / p.reweight_distance;
+    const float dv = s_y * weight;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) row[i] /= dv;
+    Y /= dv;
+    *Y_out = Y;
+    *cnt_out = 1;
+  }
+}
+
 // ---- EdgeMap::forwardMatch gather (edge_map.cpp:78-96) + Core::extRotVel sums (core.cpp:198-245) -------------
 // Sequential rule "overwrite unless the target already holds a larger rho" == the writer with the largest
 // rho wins, ties -> largest index: exactly the atomicMax key. One thread per keyline of the NEW map.
@@ -551,45 +649,8 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
   float Y = 0.f;
   int cnt = 0;
   if (idx < n) {
-    if (do_forward) {
-      if (key != 0ull) {
-        const int o = (int)(unsigned)(key & 0xFFFFFFFFull);
-        rs = om.rs[o];
-        mpi = om.pos_img[o];
-        mid = o;
-        nm.rs[idx] = rs;
-        nm.matches[idx] = om.matches[o] + 1u;
-        nm.match_id[idx] = o;
-        nm.mpos_img[idx] = mpi;
-        nm.mgrad[idx] = om.grad[o];
-        nm.mgnorm[idx] = om.gnorm[o];
-        nm.match_kf[idx] = om.match_kf[o];
-      }
-    }
-    if (mid >= 0) {
-      const float u_x = g.x / gn;
-      const float u_y = g.y / gn;
-      const float rho_t = (float)(1.0 / (1.0 / (double)rs.x + (double)vz));
-      const float qt_x = mpi.x + rho_t * (vx * p.fm - vz * mpi.x);
-      const float qt_y = mpi.y + rho_t * (vy * p.fm - vz * mpi.y);
-      const float q_x = q.x, q_y = q.y;
-      row[0] = u_x * rho_t * p.fm;
-      row[1] = u_y * rho_t * p.fm;
-      row[2] = u_x * (-rho_t * q_x) + u_y * (-rho_t * q_y);
-      row[3] = -u_x * q_x * q_y / p.fm - u_y * (p.fm + q_y * q_y / p.fm);
-      row[4] = u_y * q_x * q_y / p.fm + u_x * (p.fm + q_x * q_x / p.fm);
-      row[5] = -u_x * q_y + u_y * q_x;
-      Y = u_x * (q_x - qt_x) + u_y * (q_y - qt_y);
-      const float dqvel = u_x * (vx * p.fm - vz * mpi.x) + u_y * (vy * p.fm - vz * mpi.y);
-      const float s_y = sqrtf(rs.y * rs.y * dqvel * dqvel + p.pixel_uncertainty * p.pixel_uncertainty);
-      float weight = 1.0f;
-      if (fabsf(Y) > p.reweight_distance) weight = fabsf(Y) / p.reweight_distance;
-      const float dv = s_y * weight;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) row[i] /= dv;
-      Y /= dv;
-      cnt = 1;
-    }
+    XrvIn k{key, mid, rs, mpi, g, gn, q};
+    xrv_eval(p, om, nm, idx, do_forward, k, vx, vy, vz, row, &Y, &cnt);
   }
   float v[28];
   {
@@ -603,8 +664,8 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
     v[27] = (float)cnt;
   }
 #pragma unroll
-  for (int k = 0; k < 28; ++k) v[k] = wave_sum_f(v[k]);
-  if (lane == 0) {
+  for (int k = 0; k < 28; ++k) v[k] = wave_total63_f(v[k]);
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
   }
@@ -613,6 +674,238 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
     float acc = 0.f;
     for (int w = 0; w < 4; ++w) acc += wsum[w][threadIdx.x];
     xrv_part[blockIdx.x * kXrvStride + threadIdx.x] = acc;
+  }
+}
+
+// ---- persistent minimizeVel + forwardMatch + extRotVel (core.cpp:150-245, edge_map.cpp:78-96) --------------------
+// One launch instead of iterations+2: every workgroup keeps its keylines in registers across the LM evaluations and the
+// workgroups meet at a grid barrier after each evaluation (7 kernel boundaries of ~3 us + their prologue reloads become
+// 6 barriers of ~1.6 us among <= 16 workgroups at 640x480). Records stay per 256 keylines ("record groups"), summed in
+// the same fixed order as the per-call kernels, so both paths produce identical bits.
+// Cross-workgroup data (block records, forwardMatch keys) is written and read with agent-scope atomics, the barrier
+// itself is one agent-scope counter: target = base + (phase+1)*gridDim.x, compared wrap-safe; a workgroup that waits
+// longer than kBarrierSpinLimit polls (~0.2 s) raises *bar_err and goes on, so the grid always drains.
+constexpr int kChainThreads = 1024;
+constexpr int kChainGroups = kChainThreads / 256;
+constexpr unsigned kBarrierSpinLimit = 1u << 18;
+
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, int* err) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kBarrierSpinLimit) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Stage the records all workgroups published for the previous evaluation and reduce them: threads 0..9 the ten sums in
+// record order, threads 16.. the carried-in |fi| of each of this workgroup's record groups.
+__device__ __forceinline__ void chain_reduce_records(const float* __restrict__ prev, int nrec_launched, int nblocks, float* rec,
+                                                     float* red, float* carry_in) {
+  const int total = min(nrec_launched, kMaxRecBlocks) * kPartStride;
+  for (int i = threadIdx.x; i < total; i += kChainThreads) rec[i] = ld_agent(prev + i);
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += rec[b * kPartStride + threadIdx.x];
+    red[threadIdx.x] = acc;
+  } else if (threadIdx.x >= 16 && threadIdx.x < 16 + kChainGroups) {
+    const int g = threadIdx.x - 16;
+    float cv = 0.f;
+    for (int b = (int)blockIdx.x * kChainGroups + g - 1; b >= 0; --b)
+      if (rec[b * kPartStride + 10] != 0.f) {
+        cv = rec[b * kPartStride + 11];
+        break;
+      }
+    carry_in[g] = fabsf(cv);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om, MapDev nm, int calls, int do_ext,
+                                                            const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
+                                                            float* __restrict__ part, unsigned* __restrict__ bar, unsigned bar_base,
+                                                            int* __restrict__ bar_err, const int* __restrict__ hist,
+                                                            unsigned frame_count, float* __restrict__ xrv_part,
+                                                            PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero) {
+  __shared__ LmState s;
+  __shared__ float red[16];
+  __shared__ float carry_in[kChainGroups];
+  __shared__ float wsum[kChainThreads / 64][28];
+  __shared__ float wlast[kChainThreads / 64];
+  __shared__ int whas[kChainThreads / 64];
+  __shared__ float rec[kMaxRecBlocks * kPartStride];
+  __shared__ int shist[128];
+
+  const int tid = threadIdx.x;
+  const int idx = blockIdx.x * kChainThreads + tid;
+  const int lane = tid & 63, wid = tid >> 6, grp = tid >> 8, wig = wid & 3;
+  const int nrec_launched = gridDim.x * kChainGroups;
+  // own keyline of the old map (tryVel) and of the new map (extRotVel): loaded once, bound-free (arrays are padded)
+  const TvIn in{om.gnorm[idx], om.rs[idx], om.pos_img[idx], om.grad[idx], om.matches[idx]};
+  float res = om.residual[idx];
+  XrvIn xk{};
+  if (do_ext) {
+    xk.mid = nm.match_id[idx];
+    xk.rs = nm.rs[idx];
+    xk.mpi = nm.mpos_img[idx];
+    xk.g = nm.grad[idx];
+    xk.gn = nm.gnorm[idx];
+    xk.q = nm.pos_img[idx];
+  }
+  const int n = om.st->n;
+  const float thr = om.st->threshold;
+  const int n_new = nm.st->n;
+  const int nblocks = (n + 255) / 256;
+  if (tid < 128) shist[tid] = (tid < p.quantile_num_bins) ? hist[tid] : 0;
+  if (tid == 0) s = *st_in;
+  if (tid < kChainGroups) carry_in[tid] = 0.f;
+  __syncthreads();
+  if (tid == 0) {
+    s.sigma_rho_min = quantile_from_hist(shist, p.quantile_num_bins, p.quantile_cutoff, n);
+    for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
+  }
+  __syncthreads();
+  const unsigned min_matches = min(p.min_match_threshold, frame_count);
+
+  for (int call = 0; call < calls; ++call) {
+    if (call >= 1) {
+      chain_reduce_records(part + (size_t)((call - 1) & 1) * nrec_launched * kPartStride, nrec_launched, nblocks, rec, red, carry_in);
+      if (tid == 0) lm_step(s, red, call, false);
+      __syncthreads();
+    }
+    const float vx = s.Vnew[0], vy = s.Vnew[1], vz = s.Vnew[2];
+    const float srm = s.sigma_rho_min;
+    const float cin = carry_in[grp];
+    const bool last = call == calls - 1;
+    TvOut e{};
+    e.mfwd = -1;
+    if (idx < n) {
+      e = try_vel_eval(p, nm, in, res, cin, vx, vy, vz, srm, thr, min_matches);
+      if (e.wrote_res) res = e.res_out;
+      if (last) {
+        if (e.matched) {
+          const unsigned long long key = ((unsigned long long)order_key(in.rs.x) << 32) | (unsigned)idx;
+          atomicMax(&nm.fwd_key[e.mfwd], key);
+        }
+        om.match_fwd[idx] = e.mfwd;
+      }
+    }
+    // carry-forward of the last written fi in index order (see k_try_vel)
+    const unsigned long long mm = __ballot(e.matched);
+    const unsigned long long below = mm & ((1ull << lane) - 1ull);
+    const int src = below ? (63 - __clzll((long long)below)) : 0;
+    const float fi_prev = __shfl(e.fi, src);
+    const int wl = mm ? (63 - __clzll((long long)mm)) : 0;
+    const float fi_wlast = __shfl(e.fi, wl);
+    if (lane == 0) {
+      whas[wid] = mm ? 1 : 0;
+      wlast[wid] = fi_wlast;
+    }
+    const float sc = e.contrib ? e.f * e.f : 0.f;
+    float v[10] = {sc, e.jx * e.jx, e.jy * e.jy, e.jz * e.jz, e.jx * e.jy, e.jx * e.jz, e.jy * e.jz, e.jx * e.f, e.jy * e.f, e.jz * e.f};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = wave_total63_f(v[k]);
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) wsum[wid][k] = v[k];
+    }
+    __syncthreads();
+    if (e.need_carry) {
+      float r;
+      if (below) {
+        r = fabsf(fi_prev);
+      } else {
+        r = kResidualCarry;
+        for (int w = wig - 1; w >= 0; --w)
+          if (whas[grp * 4 + w]) {
+            r = fabsf(wlast[grp * 4 + w]);
+            break;
+          }
+      }
+      res = r;
+    }
+    if (tid < kChainGroups * 16) {
+      const int g = tid >> 4, k = tid & 15;
+      float* out = part + ((size_t)(call & 1) * nrec_launched + (size_t)blockIdx.x * kChainGroups + g) * kPartStride;
+      if (k < 10) {
+        float acc = 0.f;
+        for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
+        st_agent(out + k, acc);
+      } else if (k == 10) {
+        float hv = 0.f, lv = 0.f;
+        for (int w = 3; w >= 0; --w)
+          if (whas[g * 4 + w]) {
+            hv = 1.f;
+            lv = wlast[g * 4 + w];
+            break;
+          }
+        st_agent(out + 10, hv);
+        st_agent(out + 11, lv);
+      }
+    }
+    grid_barrier(bar, bar_base + (unsigned)(call + 1) * gridDim.x, bar_err);
+  }
+
+  // final accept / reject of minimizeVel (core.cpp:166-185 for the last evaluation)
+  if (calls > 0) {
+    chain_reduce_records(part + (size_t)((calls - 1) & 1) * nrec_launched * kPartStride, nrec_launched, nblocks, rec, red, carry_in);
+    if (tid == 0) lm_step(s, red, calls, true);
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    *st_out = s;
+    if (slot) {  // zero-copy: the host reads these after the pair's event
+      slot->lm = s;
+      slot->new_st = *nm.st;
+      slot->old_st = *om.st;
+    }
+  }
+  if (!do_ext) return;
+  if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
+  const float vx = s.vel[0], vy = s.vel[1], vz = s.vel[2];
+  float row[6] = {0, 0, 0, 0, 0, 0};
+  float Y = 0.f;
+  int cnt = 0;
+  if (idx < n_new) {
+    xk.key = __hip_atomic_load(&nm.fwd_key[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xrv_eval(p, om, nm, idx, 1, xk, vx, vy, vz, row, &Y, &cnt);
+  }
+  float v[28];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) v[k++] = row[i] * row[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[21 + i] = row[i] * Y;
+    v[27] = (float)cnt;
+  }
+#pragma unroll
+  for (int k = 0; k < 28; ++k) v[k] = wave_total63_f(v[k]);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
+  }
+  __syncthreads();
+  if (tid < kChainGroups * 32) {
+    const int g = tid >> 5, k = tid & 31;
+    if (k < 28) {
+      float acc = 0.f;
+      for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
+      xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
+    }
   }
 }
 
@@ -1060,6 +1353,13 @@ void launch_try_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const M
                     int frame_count) {
   RH_LAUNCH(k_try_vel, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, oldm, newm, mode_lm, call, last,
                      (const LmState*)st_in, st_out, part_prev, part_out, hist, (unsigned)frame_count);
+}
+
+void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
+                     LmState* st_out, float* part, unsigned* bar, unsigned bar_base, int* bar_err, const int* hist, float* xrv_part,
+                     PairSlot* slot, int* hist_to_zero) {
+  RH_LAUNCH(k_lm_chain, dim3(lm_chain_grid(p.kmax)), dim3(kChainThreads), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in,
+            st_out, part, bar, bar_base, bar_err, hist, 0u, xrv_part, slot, hist_to_zero);
 }
 
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev) {
