@@ -71,12 +71,16 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_df_build": 340 * N,            # 80 cells x 4 B atomics + 20 B keyline
         "k_rotate": 52 * N,
         "k_try_vel": 68 * N,
+        # persistent minimizeVel + forwardMatch + extRotVel: the traffic of the launches it replaces
+        # ((iterations + 1) x k_try_vel + k_ext_rot_vel); keeping the keyline in registers only lowers
+        # what is actually moved, not the algorithmic figure the roofline fraction is quoted on
+        "k_lm_chain": 6 * 68 * N + 130 * N,
         "k_ext_rot_vel": 130 * N,
         "k_directed_match": 192 * N,
         "k_regularize": 60 * N,
         "k_depth_ekf": 48 * N,
     }
-    return float(table.get(kernel, 0))
+    return float(table.get(kernel.split("<")[0] if kernel.startswith("k_lm_chain") else kernel, 0))
 
 
 def launches_per_frame(kernel: str, iterations: int = 5) -> int:

@@ -190,10 +190,13 @@ struct rebvio_hip_ctx {
   int* dm_work_n = nullptr; // its length (zero between pairs)
   float* fscratch = nullptr;
   int maxblocks = 0;
-  // persistent LM kernel: barrier arrival counter, its host-side shadow, sticky time-out flag
-  unsigned* lm_bar = nullptr;
-  unsigned lm_bar_base = 0;
+  // persistent LM kernel: record exchange words, tags consumed so far, sticky time-out flag
+  unsigned long long* lm_xch = nullptr;
+  unsigned lm_tag_base = 0;
   int* lm_bar_err = nullptr;  // pinned, zero-copy
+  unsigned long long* lm_stamps = nullptr;  // pinned; REBVIO_HIP_LM_STAMPS diagnostic (phase stamps of workgroup 0)
+  double lm_stamp_acc[64]{};
+  uint64_t lm_stamp_n = 0;
   bool lm_persistent = true;
   rebvio_hip_map* df_map = nullptr;
   // pinned host staging
@@ -529,7 +532,7 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
                        c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, vel0, slot, c->hist);
     return 0;
   }
-  if (*c->lm_bar_err) return fail_msg("persistent LM kernel: grid barrier timed out", -9);
+  if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
   LmState* first = c->lm_zero;
   if (vel0[0] != 0.f || vel0[1] != 0.f || vel0[2] != 0.f) {
     LmState init;
@@ -539,9 +542,18 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
     (void)hipMemcpyAsync(c->lm, &c->h_lm[1], sizeof(LmState), hipMemcpyHostToDevice, c->s_trk);
     first = c->lm;
   }
-  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, 1, first, c->lm + calls + 1, c->part, c->lm_bar, c->lm_bar_base, c->lm_bar_err,
-                  c->hist, slot->xrv, slot, c->hist);
-  c->lm_bar_base += (unsigned)calls * (unsigned)lm_chain_grid(c->K.kmax);
+  if (c->lm_stamps && c->lm_stamps[0]) {  // stamps of the previous launch (the caller has synchronised on its slot since)
+    const int ns = 3 + calls * 6;
+    for (int i = 1; i < ns; ++i) c->lm_stamp_acc[i] += (double)(c->lm_stamps[i] - c->lm_stamps[i - 1]) * 0.01;
+    c->lm_stamp_n++;
+  }
+  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
+                  slot->xrv, slot, c->hist, c->lm_stamps);
+  c->lm_tag_base += (unsigned)calls + 1u;
+  if (c->lm_tag_base > 0xFFFFFF00u) {  // tags must stay unique and non-zero: restart the sequence on clean exchange words
+    (void)hipMemsetAsync(c->lm_xch, 0, 2 * (size_t)c->maxblocks * kPartStride * sizeof(unsigned long long), c->s_trk);
+    c->lm_tag_base = 0;
+  }
   return 0;
 }
 
@@ -686,11 +698,15 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->aos_dev, (size_t)p->keylines_max * sizeof(rebvio_hip_keyline)));
   HIPCHK(hipMalloc(&c->scratch_i, 2 * Pn * sizeof(int)));
 
-  c->maxblocks = lm_chain_grid(p->keylines_max) * 4;  // record groups of 256 keylines, padded to whole 1024-thread workgroups
-  HIPCHK(hipMalloc(&c->lm_bar, sizeof(unsigned)));
-  HIPCHK(hipMemset(c->lm_bar, 0, sizeof(unsigned)));
+  c->maxblocks = div_up(p->keylines_max, 1024) * 4;  // record groups of 256 keylines, padded to whole 1024-thread workgroups
+  HIPCHK(hipMalloc(&c->lm_xch, 2 * (size_t)c->maxblocks * kPartStride * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->lm_xch, 0, 2 * (size_t)c->maxblocks * kPartStride * sizeof(unsigned long long)));  // tag 0 = never published
   HIPCHK(hipHostMalloc(&c->lm_bar_err, sizeof(int), hipHostMallocDefault));
   *c->lm_bar_err = 0;
+  if (std::getenv("REBVIO_HIP_LM_STAMPS")) {
+    HIPCHK(hipHostMalloc(&c->lm_stamps, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    std::memset(c->lm_stamps, 0, 64 * sizeof(unsigned long long));
+  }
   if (const char* e = std::getenv("REBVIO_HIP_LM")) c->lm_persistent = std::strcmp(e, "percall") != 0;
   HIPCHK(hipMalloc(&c->lm, 16 * sizeof(LmState)));
   HIPCHK(hipMemset(c->lm, 0, 16 * sizeof(LmState)));
@@ -778,8 +794,9 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->undist_map) (void)hipFree(c->undist_map);
   for (int i = 0; i < 2; ++i)
     if (c->undist_img[i]) (void)hipFree(c->undist_img[i]);
-  if (c->lm_bar) (void)hipFree(c->lm_bar);
+  if (c->lm_xch) (void)hipFree(c->lm_xch);
   if (c->lm_bar_err) (void)hipHostFree(c->lm_bar_err);
+  if (c->lm_stamps) (void)hipHostFree(c->lm_stamps);
   if (c->lm_zero) (void)hipFree(c->lm_zero);
   if (c->dm_work) (void)hipFree(c->dm_work);
   if (c->dm_work_n) (void)hipFree(c->dm_work_n);
@@ -1464,6 +1481,19 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
 
 int rebvio_hip_flush(rebvio_hip_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
+  if (c->lm_stamps && c->lm_stamp_n) {
+    const int calls = (int)c->P.iterations + 1;
+    std::fprintf(stderr, "[rebvio_hip] k_lm_chain workgroup 0, mean us per segment over %llu launches\n", (unsigned long long)c->lm_stamp_n);
+    std::fprintf(stderr, "  prologue %.2f\n", c->lm_stamp_acc[1] / c->lm_stamp_n);
+    for (int k = 0; k < calls; ++k) {
+      const double* a = c->lm_stamp_acc + 1 + k * 6;
+      const double n = (double)c->lm_stamp_n;
+      std::fprintf(stderr, "  eval %d: collect %.2f  lm_step %.2f  evaluate %.2f  wave-reduce %.2f  carry+publish %.2f  (loop edge %.2f)\n", k,
+                   a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, k + 1 < calls ? a[6] / n : 0.0);
+    }
+    std::fprintf(stderr, "  final collect+lm_step %.2f  forwardMatch+extRotVel %.2f\n", c->lm_stamp_acc[1 + calls * 6] / c->lm_stamp_n,
+                 c->lm_stamp_acc[2 + calls * 6] / c->lm_stamp_n);
+  }
   if (std::getenv("REBVIO_HIP_DEBUG") && c->t_frames) {
     const double n = (double)c->t_frames;
     std::fprintf(stderr, "[rebvio_hip] per frame (us): detect-enqueue %.1f  wait %.1f  glue %.1f  B-enqueue %.1f  A-enqueue %.1f\n",

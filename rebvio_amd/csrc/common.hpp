@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "rebvio_hip.h"
@@ -149,13 +150,21 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
                         float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero);
 void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm);
-// Persistent minimizeVel (+ forwardMatch + extRotVel when do_ext): one launch, grid barriers between the evaluations.
-// `bar` counts barrier arrivals monotonically; the caller passes bar_base = arrivals before this launch and advances
-// it by calls * lm_chain_grid(kmax).
-inline int lm_chain_grid(int kmax) { return (kmax + 1023) / 1024; }
+// Persistent minimizeVel (+ forwardMatch + extRotVel when do_ext): one launch; the workgroups exchange their records
+// through `xch` ([2][record groups][kPartStride] 64-bit words {tag, value}). The caller passes tag_base = tags consumed so
+// far and advances it by calls + 1 per launch. Workgroup size 256 / 512 / 1024 threads (REBVIO_HIP_LM_THREADS).
+inline int lm_chain_threads() {
+  static const int t = [] {
+    const char* e = std::getenv("REBVIO_HIP_LM_THREADS");
+    const int v = e ? std::atoi(e) : 0;
+    return (v == 256 || v == 512 || v == 1024) ? v : 256;
+  }();
+  return t;
+}
+inline int lm_chain_grid(int kmax) { return (kmax + lm_chain_threads() - 1) / lm_chain_threads(); }
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
-                     LmState* st_out, float* part, unsigned* bar, unsigned bar_base, int* bar_err, const int* hist, float* xrv_part,
-                     PairSlot* slot, int* hist_to_zero);
+                     LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
+                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps);
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,

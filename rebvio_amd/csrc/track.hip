@@ -45,6 +45,25 @@ __device__ __forceinline__ float wave_total63_f(float v) {
   v = dpp_add_f<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
   return v;
 }
+// The same tree for N independent values at once with fused v_add_f32_dpp (one VALU op per step and value instead of
+// mov_dpp + add). Steps are emitted value-interleaved, so consecutive DPP reads of one register are N >= 8 instructions
+// apart (gfx9 needs 2 wait states between a VALU write and a DPP read of the same VGPR; the leading s_nop covers the
+// producer of the inputs). Disabled rows of the row_bcast steps keep their value, which is what the scan needs.
+template <int N>
+__device__ __forceinline__ void wave_total63_fN(float (&v)[N]) {
+  static_assert(N >= 8, "dependent DPP ops must be at least 2 wait states apart");
+  asm volatile("s_nop 1");
+#define RH_DPP_STEP(ctrl)                                                             \
+  _Pragma("unroll") for (int k = 0; k < N; ++k)                                       \
+      asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(v[k]));
+  RH_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+  RH_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+  RH_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+  RH_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+  RH_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+  RH_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef RH_DPP_STEP
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -285,19 +304,30 @@ __device__ void stage_prev_records(const float* __restrict__ part_prev, int grid
   for (int i = threadIdx.x; i < total; i += blockDim.x) rec[i] = part_prev[i];
 }
 
-__device__ void reduce_staged_records(const float* rec, int nblocks, float* red /*shared[16]*/, float* carry_in) {
-  if (threadIdx.x < 10) {
+// Fixed-order sum of the staged records with 160 threads: sum k (0..9) lives in the 16-lane row k, lane j adds the
+// records b = j, j+16, ... in ascending order, a DPP scan inside the row (row_shr 1,2,4,8) leaves the total in lane 15.
+// `first_group` = index of this workgroup's first record group, `groups` = record groups it owns (carry_in[g] for each).
+__device__ __forceinline__ void reduce_staged_records(const float* rec, int nblocks, float* red /*shared[16]*/, float* carry_in,
+                                                      int first_group, int groups) {
+  const int t = threadIdx.x;
+  if (t < 160) {
+    const int k = t >> 4, j = t & 15;
     float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += rec[b * kPartStride + threadIdx.x];
-    red[threadIdx.x] = acc;
-  } else if (threadIdx.x == 10) {
+    for (int b = j; b < nblocks; b += 16) acc += rec[b * kPartStride + k];
+    acc = dpp_add_f<0x111, 0xF>(acc);
+    acc = dpp_add_f<0x112, 0xF>(acc);
+    acc = dpp_add_f<0x114, 0xF>(acc);
+    acc = dpp_add_f<0x118, 0xF>(acc);
+    if (j == 15) red[k] = acc;
+  } else if (t >= 192 && t < 192 + groups) {
+    const int g = t - 192;
     float cv = 0.f;
-    for (int b = (int)blockIdx.x - 1; b >= 0; --b)
+    for (int b = first_group + g - 1; b >= 0; --b)
       if (rec[b * kPartStride + 10] != 0.f) {
         cv = rec[b * kPartStride + 11];
         break;
       }
-    *carry_in = fabsf(cv);
+    carry_in[g] = fabsf(cv);
   }
 }
 
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
     s = *st_in;
   }
   __syncthreads();
-  if (mode_lm && call >= 1) reduce_staged_records(rec, nblocks, red, &carry_in);
+  if (mode_lm && call >= 1) reduce_staged_records(rec, nblocks, red, &carry_in, (int)blockIdx.x, 1);
   __syncthreads();
   if (threadIdx.x == 0) {
     if (mode_lm) {
@@ -472,8 +502,7 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
 
   const float sc = contrib ? f * f : 0.f;
   float v[10] = {sc, jx * jx, jy * jy, jz * jz, jx * jy, jx * jz, jy * jz, jx * f, jy * f, jz * f};
-#pragma unroll
-  for (int k = 0; k < 10; ++k) v[k] = wave_total63_f(v[k]);
+  wave_total63_fN(v);
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) wsum[wid][k] = v[k];
@@ -511,7 +540,7 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
 }
 
 // Final accept/reject of minimizeVel for the stand-alone entry (the fused path does this in k_ext_rot_vel).
-__global__ __launch_bounds__(64) void k_lm_final(MapDev om, int calls, const LmState* __restrict__ st_in,
+__global__ __launch_bounds__(256) void k_lm_final(MapDev om, int calls, const LmState* __restrict__ st_in,
                                                  LmState* __restrict__ st_out, const float* __restrict__ part_prev) {
   __shared__ float red[16];
   __shared__ float carry_in;
@@ -519,7 +548,7 @@ __global__ __launch_bounds__(64) void k_lm_final(MapDev om, int calls, const LmS
   stage_prev_records(part_prev, kMaxRecBlocks, rec);
   const int nb = (om.st->n + 255) / 256;
   __syncthreads();
-  reduce_staged_records(rec, nb, red, &carry_in);
+  reduce_staged_records(rec, nb, red, &carry_in, 0, 1);
   __syncthreads();
   if (threadIdx.x == 0) {
     LmState s = *st_in;
@@ -623,7 +652,7 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
     const int nb_old = (om.st->n + 255) / 256;
     if (threadIdx.x == 0) s = *st_in;
     __syncthreads();
-    reduce_staged_records(rec, nb_old, red, &carry_in);
+    reduce_staged_records(rec, nb_old, red, &carry_in, (int)blockIdx.x, 1);
     __syncthreads();
     if (threadIdx.x == 0) {
       lm_step(s, red, calls, true);
@@ -663,8 +692,7 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
     for (int i = 0; i < 6; ++i) v[21 + i] = row[i] * Y;
     v[27] = (float)cnt;
   }
-#pragma unroll
-  for (int k = 0; k < 28; ++k) v[k] = wave_total63_f(v[k]);
+  wave_total63_fN(v);
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
@@ -679,65 +707,59 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
 
 // ---- persistent minimizeVel + forwardMatch + extRotVel (core.cpp:150-245, edge_map.cpp:78-96) --------------------
 // One launch instead of iterations+2: every workgroup keeps its keylines in registers across the LM evaluations and the
-// workgroups meet at a grid barrier after each evaluation (7 kernel boundaries of ~3 us + their prologue reloads become
-// 6 barriers of ~1.6 us among <= 16 workgroups at 640x480). Records stay per 256 keylines ("record groups"), summed in
-// the same fixed order as the per-call kernels, so both paths produce identical bits.
-// Cross-workgroup data (block records, forwardMatch keys) is written and read with agent-scope atomics, the barrier
-// itself is one agent-scope counter: target = base + (phase+1)*gridDim.x, compared wrap-safe; a workgroup that waits
-// longer than kBarrierSpinLimit polls (~0.2 s) raises *bar_err and goes on, so the grid always drains.
-constexpr int kChainThreads = 1024;
-constexpr int kChainGroups = kChainThreads / 256;
-constexpr unsigned kBarrierSpinLimit = 1u << 18;
+// workgroups exchange their block records after each evaluation. Records stay per 256 keylines ("record groups") and
+// are summed in the same fixed order as in the per-call kernels, so both paths produce identical bits.
+// The exchange is the grid barrier: every record word is published as one 64-bit agent-scope store {tag, float bits},
+// tag = tag_base + evaluation index + 1 (unique over the life of the context, never 0), into the parity slot of the
+// evaluation; every workgroup polls the words of all live record groups until they carry the tag - one memory round
+// trip per evaluation, no contended counter, cost independent of the number of workgroups. A consumer that has seen
+// evaluation c of every group knows every workgroup has finished reading evaluation c-1, so two parity slots suffice.
+// A poll that lasts longer than kXchSpinLimit iterations (~0.2 s) raises *err and goes on: the grid always drains.
+constexpr unsigned kXchSpinLimit = 1u << 18;
 
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target, int* err) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kBarrierSpinLimit) {
-        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
+__device__ __forceinline__ void xch_publish(unsigned long long* w, unsigned tag, float v) {
+  __hip_atomic_store(w, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float xch_wait(const unsigned long long* w, unsigned tag, int* err) {
+  unsigned spins = 0;
+  unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while ((unsigned)(v >> 32) != tag) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kXchSpinLimit) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
     }
+    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  return __uint_as_float((unsigned)v);
+}
+
+// Wait for the records every live group published for evaluation `tag`, stage them in LDS and reduce them.
+template <int kChainThreads>
+__device__ __forceinline__ void chain_collect_records(const unsigned long long* __restrict__ slot_words, unsigned tag, int nblocks,
+                                                      float* rec, float* red, float* carry_in, int* err) {
+  constexpr int kChainGroups = kChainThreads / 256;
+  const int total = min(nblocks, kMaxRecBlocks) * kPartStride;
+  for (int i = threadIdx.x; i < total; i += kChainThreads)
+    if ((i & (kPartStride - 1)) < 12) rec[i] = xch_wait(slot_words + i, tag, err);
+  __syncthreads();
+  reduce_staged_records(rec, nblocks, red, carry_in, (int)blockIdx.x * kChainGroups, kChainGroups);
   __syncthreads();
 }
 
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Stage the records all workgroups published for the previous evaluation and reduce them: threads 0..9 the ten sums in
-// record order, threads 16.. the carried-in |fi| of each of this workgroup's record groups.
-__device__ __forceinline__ void chain_reduce_records(const float* __restrict__ prev, int nrec_launched, int nblocks, float* rec,
-                                                     float* red, float* carry_in) {
-  const int total = min(nrec_launched, kMaxRecBlocks) * kPartStride;
-  for (int i = threadIdx.x; i < total; i += kChainThreads) rec[i] = ld_agent(prev + i);
-  __syncthreads();
-  if (threadIdx.x < 10) {
-    float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += rec[b * kPartStride + threadIdx.x];
-    red[threadIdx.x] = acc;
-  } else if (threadIdx.x >= 16 && threadIdx.x < 16 + kChainGroups) {
-    const int g = threadIdx.x - 16;
-    float cv = 0.f;
-    for (int b = (int)blockIdx.x * kChainGroups + g - 1; b >= 0; --b)
-      if (rec[b * kPartStride + 10] != 0.f) {
-        cv = rec[b * kPartStride + 11];
-        break;
-      }
-    carry_in[g] = fabsf(cv);
-  }
-  __syncthreads();
-}
-
+template <int kChainThreads>
 __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om, MapDev nm, int calls, int do_ext,
                                                             const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
-                                                            float* __restrict__ part, unsigned* __restrict__ bar, unsigned bar_base,
+                                                            unsigned long long* __restrict__ xch, unsigned tag_base,
                                                             int* __restrict__ bar_err, const int* __restrict__ hist,
                                                             unsigned frame_count, float* __restrict__ xrv_part,
-                                                            PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero) {
+                                                            PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
+                                                            unsigned long long* __restrict__ stamps) {
+  constexpr int kChainGroups = kChainThreads / 256;
+  // optional phase stamps of workgroup 0 (REBVIO_HIP_LM_STAMPS diagnostic): 100 MHz constant clock
+#define RH_STAMP(i) \
+  do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   __shared__ LmState s;
   __shared__ float red[16];
   __shared__ float carry_in[kChainGroups];
@@ -777,13 +799,20 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
   }
   __syncthreads();
   const unsigned min_matches = min(p.min_match_threshold, frame_count);
+  RH_STAMP(0);
 
   for (int call = 0; call < calls; ++call) {
+    RH_STAMP(1 + call * 6 + 0);
     if (call >= 1) {
-      chain_reduce_records(part + (size_t)((call - 1) & 1) * nrec_launched * kPartStride, nrec_launched, nblocks, rec, red, carry_in);
+      chain_collect_records<kChainThreads>(xch + (size_t)((call - 1) & 1) * nrec_launched * kPartStride, tag_base + (unsigned)call, nblocks,
+                                           rec, red, carry_in, bar_err);
+      RH_STAMP(1 + call * 6 + 1);
       if (tid == 0) lm_step(s, red, call, false);
       __syncthreads();
+    } else {
+      RH_STAMP(1 + call * 6 + 1);
     }
+    RH_STAMP(1 + call * 6 + 2);
     const float vx = s.Vnew[0], vy = s.Vnew[1], vz = s.Vnew[2];
     const float srm = s.sigma_rho_min;
     const float cin = carry_in[grp];
@@ -801,6 +830,7 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
         om.match_fwd[idx] = e.mfwd;
       }
     }
+    RH_STAMP(1 + call * 6 + 3);
     // carry-forward of the last written fi in index order (see k_try_vel)
     const unsigned long long mm = __ballot(e.matched);
     const unsigned long long below = mm & ((1ull << lane) - 1ull);
@@ -814,13 +844,13 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
     }
     const float sc = e.contrib ? e.f * e.f : 0.f;
     float v[10] = {sc, e.jx * e.jx, e.jy * e.jy, e.jz * e.jz, e.jx * e.jy, e.jx * e.jz, e.jy * e.jz, e.jx * e.f, e.jy * e.f, e.jz * e.f};
-#pragma unroll
-    for (int k = 0; k < 10; ++k) v[k] = wave_total63_f(v[k]);
+    wave_total63_fN(v);
     if (lane == 63) {
 #pragma unroll
       for (int k = 0; k < 10; ++k) wsum[wid][k] = v[k];
     }
     __syncthreads();
+    RH_STAMP(1 + call * 6 + 4);
     if (e.need_carry) {
       float r;
       if (below) {
@@ -836,13 +866,17 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
       res = r;
     }
     if (tid < kChainGroups * 16) {
+      // publish this evaluation's records (self-contained words, relaxed); only the last evaluation has other data to
+      // order before them: the forwardMatch keys this workgroup issued before the __syncthreads above
+      if (last) __atomic_thread_fence(__ATOMIC_RELEASE);
       const int g = tid >> 4, k = tid & 15;
-      float* out = part + ((size_t)(call & 1) * nrec_launched + (size_t)blockIdx.x * kChainGroups + g) * kPartStride;
+      unsigned long long* out = xch + ((size_t)(call & 1) * nrec_launched + (size_t)blockIdx.x * kChainGroups + g) * kPartStride;
+      const unsigned tag = tag_base + (unsigned)call + 1u;
       if (k < 10) {
         float acc = 0.f;
         for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
-        st_agent(out + k, acc);
-      } else if (k == 10) {
+        xch_publish(out + k, tag, acc);
+      } else if (k == 10 || k == 11) {
         float hv = 0.f, lv = 0.f;
         for (int w = 3; w >= 0; --w)
           if (whas[g * 4 + w]) {
@@ -850,16 +884,17 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
             lv = wlast[g * 4 + w];
             break;
           }
-        st_agent(out + 10, hv);
-        st_agent(out + 11, lv);
+        xch_publish(out + k, tag, k == 10 ? hv : lv);
       }
     }
-    grid_barrier(bar, bar_base + (unsigned)(call + 1) * gridDim.x, bar_err);
+    __syncthreads();  // wsum / whas / wlast are rewritten by the next evaluation
+    RH_STAMP(1 + call * 6 + 5);
   }
 
   // final accept / reject of minimizeVel (core.cpp:166-185 for the last evaluation)
   if (calls > 0) {
-    chain_reduce_records(part + (size_t)((calls - 1) & 1) * nrec_launched * kPartStride, nrec_launched, nblocks, rec, red, carry_in);
+    chain_collect_records<kChainThreads>(xch + (size_t)((calls - 1) & 1) * nrec_launched * kPartStride, tag_base + (unsigned)calls, nblocks,
+                                         rec, red, carry_in, bar_err);
     if (tid == 0) lm_step(s, red, calls, true);
     __syncthreads();
   }
@@ -871,6 +906,7 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
       slot->old_st = *om.st;
     }
   }
+  RH_STAMP(1 + calls * 6);
   if (!do_ext) return;
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
   const float vx = s.vel[0], vy = s.vel[1], vz = s.vel[2];
@@ -892,8 +928,7 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
     for (int i = 0; i < 6; ++i) v[21 + i] = row[i] * Y;
     v[27] = (float)cnt;
   }
-#pragma unroll
-  for (int k = 0; k < 28; ++k) v[k] = wave_total63_f(v[k]);
+  wave_total63_fN(v);
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
@@ -907,6 +942,8 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
       xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
     }
   }
+  RH_STAMP(2 + calls * 6);
+#undef RH_STAMP
 }
 
 // ---- EdgeMap::directedMatch / searchMatch (edge_map.cpp:101-218) ----------------------------------------------
@@ -1356,14 +1393,26 @@ void launch_try_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const M
 }
 
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
-                     LmState* st_out, float* part, unsigned* bar, unsigned bar_base, int* bar_err, const int* hist, float* xrv_part,
-                     PairSlot* slot, int* hist_to_zero) {
-  RH_LAUNCH(k_lm_chain, dim3(lm_chain_grid(p.kmax)), dim3(kChainThreads), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in,
-            st_out, part, bar, bar_base, bar_err, hist, 0u, xrv_part, slot, hist_to_zero);
+                     LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
+                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps) {
+  const dim3 grid(lm_chain_grid(p.kmax));
+  switch (lm_chain_threads()) {
+    case 256:
+      RH_LAUNCH(k_lm_chain<256>, grid, dim3(256), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
+                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps);
+      break;
+    case 512:
+      RH_LAUNCH(k_lm_chain<512>, grid, dim3(512), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
+                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps);
+      break;
+    default:
+      RH_LAUNCH(k_lm_chain<1024>, grid, dim3(1024), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
+                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps);
+  }
 }
 
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev) {
-  RH_LAUNCH(k_lm_final, dim3(1), dim3(64), 0, s, oldm, calls, (const LmState*)st_in, st_out, part_prev);
+  RH_LAUNCH(k_lm_final, dim3(1), dim3(256), 0, s, oldm, calls, (const LmState*)st_in, st_out, part_prev);
 }
 
 void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm) {
