@@ -185,7 +185,7 @@ def main():
     ctx.flush()
 
     tmax = shard.max_over_ranks(elapsed, world, "cuda" if backend_name == "nccl" else "cpu")
-    bad = sum(1 for s in statuses if s not in (0,))
+    bad = sum(1 for s in statuses if s not in (0, -1))  # -1: no finished pair to report in that call
     if bad:
         print(f"[rank {rank}] WARNING: {bad} of {steps} frame pairs ended with a non-zero tracking status", file=sys.stderr)
 
