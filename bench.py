@@ -68,7 +68,8 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_keyline_flag": 8 * P + 16 * N,
         "k_keyline_emit": 8 * P + 116 * N,
         "k_join_edges": 40 * N,
-        "k_df_build": 340 * N,            # 80 cells x 4 B atomics + 20 B keyline
+        "k_df_build": 340 * N,            # scatter variant: 80 cells x 4 B atomics + 20 B keyline
+        "k_df_tiles": 8 * P + 20 * N,     # tiled variant: mask read once + field written once + keyline geometry
         "k_rotate": 52 * N,
         "k_try_vel": 68 * N,
         # persistent minimizeVel + forwardMatch + extRotVel: the traffic of the launches it replaces
@@ -80,7 +81,8 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_regularize": 60 * N,
         "k_depth_ekf": 48 * N,
     }
-    return float(table.get(kernel.split("<")[0] if kernel.startswith("k_lm_chain") else kernel, 0))
+    base = kernel.split("<")[0] if kernel.startswith(("k_lm_chain", "k_df_tiles")) else kernel
+    return float(table.get(base, 0))
 
 
 def launches_per_frame(kernel: str, iterations: int = 5) -> int:

@@ -49,13 +49,9 @@ struct Profiler {
     hipEvent_t e0, e1;
     int count;  // launches bracketed by this event pair
   };
-  int group_depth = 0;  // inside prof_group_begin/end the individual launches are not bracketed again
-  int open_count = 1;
   std::vector<std::string> names;
   std::vector<Sample> samples;
   std::vector<hipEvent_t> free_events;
-  int open_name = -1;
-  hipEvent_t open_e0{}, open_e1{};
   std::map<int, std::pair<double, int>> acc;  // name -> (sum us, calls)
   size_t cap = 1 << 16;
   std::mutex mu;
@@ -91,47 +87,53 @@ struct Profiler {
   }
 };
 Profiler g_prof;
+// The open bracket belongs to the launching THREAD (the caller thread and the detect worker launch concurrently).
+struct ProfOpen {
+  int group_depth = 0;  // inside prof_group_begin/end the individual launches are not bracketed again
+  int count = 1;
+  int name = -1;
+  hipEvent_t e0{}, e1{};
+};
+thread_local ProfOpen t_open;
 }  // namespace
 
 namespace rh {
 void prof_begin(hipStream_t s, const char* name) {
   if (!g_prof.on) return;
-  std::lock_guard<std::mutex> g(g_prof.mu);
-  if (g_prof.group_depth > 0) return;
-  g_prof.open_count = 1;
-  g_prof.open_name = -1;
-  if (!g_prof.only.empty() && g_prof.only != name) return;
-  if (g_prof.stride > 1 && (g_prof.seen[name]++ % (unsigned)g_prof.stride) != 0) return;
-  if (g_prof.samples.size() >= g_prof.cap) return;
-  g_prof.open_name = g_prof.name_id(name);
-  g_prof.open_e0 = g_prof.get_event();
-  g_prof.open_e1 = g_prof.get_event();
-  (void)hipEventRecord(g_prof.open_e0, s);
+  if (t_open.group_depth > 0) return;
+  t_open.count = 1;
+  t_open.name = -1;
+  {
+    std::lock_guard<std::mutex> g(g_prof.mu);
+    if (!g_prof.only.empty() && g_prof.only != name) return;
+    if (g_prof.stride > 1 && (g_prof.seen[name]++ % (unsigned)g_prof.stride) != 0) return;
+    if (g_prof.samples.size() >= g_prof.cap) return;
+    t_open.name = g_prof.name_id(name);
+    t_open.e0 = g_prof.get_event();
+    t_open.e1 = g_prof.get_event();
+  }
+  (void)hipEventRecord(t_open.e0, s);
 }
 void prof_end(hipStream_t s) {
   if (!g_prof.on) return;
+  if (t_open.group_depth > 0) return;
+  if (t_open.name < 0) return;
+  (void)hipEventRecord(t_open.e1, s);
   std::lock_guard<std::mutex> g(g_prof.mu);
-  if (g_prof.group_depth > 0) return;
-  if (g_prof.open_name < 0) return;
-  (void)hipEventRecord(g_prof.open_e1, s);
-  g_prof.samples.push_back({g_prof.open_name, g_prof.open_e0, g_prof.open_e1, g_prof.open_count});
-  g_prof.open_name = -1;
+  g_prof.samples.push_back({t_open.name, t_open.e0, t_open.e1, t_open.count});
+  t_open.name = -1;
 }
 // One event pair around `count` back-to-back launches of the same kernel on one stream: the fixed cost of an event
 // pair (~4.5 us measured around an empty kernel) is amortised, so the per-launch average agrees with rocprofv3's.
 void prof_group_begin(hipStream_t s, const char* name, int count) {
   if (!g_prof.on) return;
   prof_begin(s, name);
-  std::lock_guard<std::mutex> g(g_prof.mu);
-  g_prof.open_count = count;
-  g_prof.group_depth = 1;
+  t_open.count = count;
+  t_open.group_depth = 1;
 }
 void prof_group_end(hipStream_t s) {
   if (!g_prof.on) return;
-  {
-    std::lock_guard<std::mutex> g(g_prof.mu);
-    g_prof.group_depth = 0;
-  }
+  t_open.group_depth = 0;
   prof_end(s);
 }
 }  // namespace rh
@@ -391,7 +393,7 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   // distance field of this map on its own stream
   HIPCHK(hipEventRecord(m->detected, c->s_key));
   HIPCHK(hipStreamWaitEvent(c->s_df, m->detected, 0));
-  launch_df_build(c->s_df, c->K, m->d, j.det_out);
+  launch_df_build(c->s_df, c->K, m->d, j.det_out, true);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(m->ready, c->s_df));
   m->enqueued.store(1, std::memory_order_release);
@@ -532,7 +534,15 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
                        c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, vel0, slot, c->hist);
     return 0;
   }
-  if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
+  if (*c->lm_bar_err) {
+    const int* e = c->lm_bar_err;
+    char msg[256];
+    std::snprintf(msg, sizeof(msg),
+                  "persistent LM kernel: record exchange timed out (workgroup %d/%d thread %d waited for tag %u, last saw tag %u; "
+                  "tags issued so far %u)",
+                  e[1], e[6], e[2], (unsigned)e[3], (unsigned)e[4], c->lm_tag_base);
+    return fail_msg(msg, -9);
+  }
   LmState* first = c->lm_zero;
   if (vel0[0] != 0.f || vel0[1] != 0.f || vel0[2] != 0.f) {
     LmState init;
@@ -551,7 +561,7 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
                   slot->xrv, slot, c->hist, c->lm_stamps);
   c->lm_tag_base += (unsigned)calls + 1u;
   if (c->lm_tag_base > 0xFFFFFF00u) {  // tags must stay unique and non-zero: restart the sequence on clean exchange words
-    (void)hipMemsetAsync(c->lm_xch, 0, 2 * (size_t)c->maxblocks * kPartStride * sizeof(unsigned long long), c->s_trk);
+    (void)hipMemsetAsync(c->lm_xch, 0, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long), c->s_trk);
     c->lm_tag_base = 0;
   }
   return 0;
@@ -699,10 +709,11 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->scratch_i, 2 * Pn * sizeof(int)));
 
   c->maxblocks = div_up(p->keylines_max, 1024) * 4;  // record groups of 256 keylines, padded to whole 1024-thread workgroups
-  HIPCHK(hipMalloc(&c->lm_xch, 2 * (size_t)c->maxblocks * kPartStride * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(c->lm_xch, 0, 2 * (size_t)c->maxblocks * kPartStride * sizeof(unsigned long long)));  // tag 0 = never published
-  HIPCHK(hipHostMalloc(&c->lm_bar_err, sizeof(int), hipHostMallocDefault));
-  *c->lm_bar_err = 0;
+  // [2 parity slots][record groups][kPartStride] + the final-velocity broadcast words
+  HIPCHK(hipMalloc(&c->lm_xch, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->lm_xch, 0, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long)));  // tag 0 = never published
+  HIPCHK(hipHostMalloc(&c->lm_bar_err, 8 * sizeof(int), hipHostMallocDefault));
+  std::memset(c->lm_bar_err, 0, 8 * sizeof(int));
   if (std::getenv("REBVIO_HIP_LM_STAMPS")) {
     HIPCHK(hipHostMalloc(&c->lm_stamps, 64 * sizeof(unsigned long long), hipHostMallocDefault));
     std::memset(c->lm_stamps, 0, 64 * sizeof(unsigned long long));
@@ -986,7 +997,7 @@ int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
   if (!m->df_built) {
     HIPCHK(hipMemsetAsync(m->d.df, 0xFF, (size_t)c->P.rows * c->P.cols * sizeof(unsigned), c->s_trk));
-    launch_df_build(c->s_trk, c->K, m->d, c->det + (c->frame_index % kDetRing));
+    launch_df_build(c->s_trk, c->K, m->d, c->det + (c->frame_index % kDetRing), false);  // keylines may have been uploaded
     HIPCHK(hipGetLastError());
     m->df_built = true;
   }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <string>
 #include <stdint.h>
 
 #include "rebvio_hip.h"
@@ -130,7 +131,17 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
                         const int widths[2][3], int* rowcount_to_zero);
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
                      const DetState* det_in, DetState* det_out, const MapState* prev_st);
-void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev);
+// Distance-field build: LDS tiles (default) or the global-atomic scatter kernel (REBVIO_HIP_DF=scatter, kept as a reference).
+inline bool df_scatter_mode() {
+  static const bool v = [] {
+    const char* e = std::getenv("REBVIO_HIP_DF");
+    return e && std::string(e) == "scatter";
+  }();
+  return v;
+}
+// mask_is_current: the map's dense mask describes its keylines (true right after detection, not after map_upload); the
+// tiled build finds the keylines through the mask, the scatter build (which needs a cleared field) through the arrays.
+void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, bool mask_is_current);
 void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out);
 
 void launch_rotate(hipStream_t s, const KParams& p, const MapDev& m, const float R[9], int* hist_or_null,

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <cstring>
+
 #include "common.hpp"
 
 namespace rh {
@@ -463,7 +465,8 @@ __device__ __forceinline__ float auto_threshold_from(const MapState& st, float p
 __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const float4* __restrict__ stash,
                                                       const unsigned long long* __restrict__ bits,
                                                       const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
-                                                      DetState* __restrict__ det_out, const MapState* __restrict__ prev_st) {
+                                                      DetState* __restrict__ det_out, const MapState* __restrict__ prev_st,
+                                                      int clear_df) {
   const int R = p.rows, C = p.cols;
   const int r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.x * 64 + threadIdx.x;
   const int lane = threadIdx.x;
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
     m.residual[rank] = 0.f;
   }
   m.mask[pix] = mk;
-  m.df[pix] = kDfEmpty;
+  if (clear_df) m.df[pix] = kDfEmpty;  // only the scatter build needs a cleared field, the tiled build writes every cell
 }
 
 // ---- joinEdges (edge_detector.cpp:125-165) + min/max of gradient_norm for tuneThreshold (:168-174) -----
@@ -595,6 +598,151 @@ __global__ __launch_bounds__(256) void k_df_build(KParams p, MapDev m, const Det
     const unsigned seq = (unsigned)(idx * nr + ri);
     const unsigned key = ((unsigned)abs(r) << kDfSeqBits) | (kDfSeqMask - seq);
     atomicMin(&m.df[(size_t)row * p.cols + col], key);
+  }
+}
+
+// ---- DistanceField::build, tiled (core.hpp:37-59) ----------------------------------------------------------------
+// Same field, no global atomics: a workgroup owns a 64x64 tile of the field in LDS. It scans the dense keyline mask of
+// the tile grown by the reach of a keyline (nr/2 + 1 pixels) in chunks of <= kDfChunk pixels, compacts the keylines it
+// finds into an LDS list (id, position, unit gradient - the divisions are done once per keyline), drops those whose
+// probe segment cannot touch the tile, and lets its threads walk the (keyline, r) pairs of the list with LDS atomicMin
+// on the same key as k_df_build. The finished tile is written with coalesced stores, empty cells included, so the
+// field needs no clearing pass. HBM traffic: mask reads of the grown tiles (L2 hits after the first tile row) + one
+// 4-byte store per cell, instead of one memory-side atomic per (keyline, r).
+constexpr int kDfChunk = 2048;  // work-list capacity = pixels per chunk of the fallback scan
+constexpr int kDfHits = 4096;   // hit-list capacity of the one-pass scan
+constexpr int kDfThreads = 512;
+
+template <int kDfTile>
+__global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, const DetState* __restrict__ det_prev) {
+  __shared__ unsigned tile[kDfTile * kDfTile];
+  __shared__ int l_idx[kDfChunk];
+  __shared__ float4 l_geo[kDfChunk];  // pos.x, pos.y, g.x/gn, g.y/gn
+  __shared__ int l_hits[kDfHits];
+  __shared__ int l_n, l_nh;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  const int n = m.st->n;
+  const float thr = auto_threshold_from(*m.st, det_prev->auto_threshold);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
+  const int nr = p.df_nr, half = nr >> 1;
+  const int x0 = blockIdx.x * kDfTile, y0 = blockIdx.y * kDfTile;
+  const int x1 = min(x0 + kDfTile, p.cols), y1 = min(y0 + kDfTile, p.rows);
+  for (int i = tid; i < kDfTile * kDfTile; i += kDfThreads) tile[i] = kDfEmpty;
+  const int reach = half + 1;
+  const int ex0 = max(x0 - reach, 0), ex1 = min(x1 + reach, p.cols);
+  const int ey0 = max(y0 - reach, 0), ey1 = min(y1 + reach, p.rows);
+  const int ew = ex1 - ex0;
+  const float inv_ew = 1.0f / (float)ew;
+  const float fx0 = (float)x0 - 1.0f, fx1 = (float)x1, fy0 = (float)y0 - 1.0f, fy1 = (float)y1;
+  // First try: the whole grown tile in one pass (its keylines that survive the reach test almost always fit the list);
+  // if they do not, nothing has touched the tile yet and the scan is redone in chunks of <= kDfChunk pixels.
+  int rows_per_chunk = ey1 - ey0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    bool overflow = false;
+    for (int cy = ey0; cy < ey1 && !overflow; cy += rows_per_chunk) {
+      if (tid == 0) {
+        l_n = 0;
+        l_nh = 0;
+      }
+      __syncthreads();
+      const int ch = min(rows_per_chunk, ey1 - cy);
+      const int px_total = ch * ew;
+      // (a) mask scan, eight independent loads per thread and trip; the keyline ids go to the hit list
+      for (int i0 = 0; i0 < px_total; i0 += kDfThreads * 8) {
+        int ids[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = i0 + j * kDfThreads + tid;
+          int id = -1;
+          if (i < px_total) {
+            // row = floor(i / ew) without an integer division: (i + 0.5) / ew is at least 0.5 / ew away from an integer,
+            // far more than the rounding error of the fp32 product for i < 2^16
+            const int ry = (int)(((float)i + 0.5f) * inv_ew), rx = i - ry * ew;
+            id = m.mask[(size_t)(cy + ry) * p.cols + ex0 + rx];
+          }
+          ids[j] = id;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // wave-aggregated append: one LDS atomic per wave and slot j
+          const bool hit = ids[j] >= 0 && ids[j] < n;
+          const unsigned long long hm = __ballot(hit);
+          if (hm) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&l_nh, __popcll(hm));
+            base = __shfl(base, 0);
+            const int slot = base + __popcll(hm & ((1ull << lane) - 1ull));
+            if (hit && slot < kDfHits) l_hits[slot] = ids[j];
+          }
+        }
+      }
+      __syncthreads();
+      const int nh = l_nh;
+      if (nh > kDfHits) {
+        overflow = true;
+      } else {
+        // (b) geometry of the hits (one gather round trip), reach test, compaction into the work list
+        for (int h0 = 0; h0 < nh; h0 += kDfThreads) {
+          const int h = h0 + tid;
+          bool keep = false;
+          int id = 0;
+          float2 pos = make_float2(0.f, 0.f);
+          float ux = 0.f, uy = 0.f;
+          if (h < nh) {
+            id = l_hits[h];
+            const float gn = m.gnorm[id];
+            const float2 g = m.grad[id];
+            pos = m.pos[id];
+            if (!(thr > 0.0f && gn < thr)) {
+              ux = g.x / gn;
+              uy = g.y / gn;
+              // conservative reach of the probe segment |r| <= half (one pixel of slack for the rounding)
+              const float rx_ = fabsf(ux) * (float)half + 1.0f, ry_ = fabsf(uy) * (float)half + 1.0f;
+              keep = !(pos.x + rx_ < fx0 || pos.x - rx_ > fx1 || pos.y + ry_ < fy0 || pos.y - ry_ > fy1);
+            }
+          }
+          const unsigned long long km = __ballot(keep);
+          if (km) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&l_n, __popcll(km));
+            base = __shfl(base, 0);
+            const int slot = base + __popcll(km & ((1ull << lane) - 1ull));
+            if (keep && slot < kDfChunk) {
+              l_idx[slot] = id;
+              l_geo[slot] = make_float4(pos.x, pos.y, ux, uy);
+            }
+          }
+        }
+        __syncthreads();
+        const int ln = l_n;
+        if (ln > kDfChunk) {
+          overflow = true;
+        } else {
+          // (c) the (keyline, r) pairs of the list: a wave per keyline, its lanes over r
+          for (int k = tid >> 6; k < ln; k += kDfThreads / 64) {
+            const float4 q = l_geo[k];
+            const unsigned seq0 = (unsigned)(l_idx[k] * nr);
+            for (int ri = lane; ri < nr; ri += 64) {
+              const int r = ri - half;
+              const float fr = q.w * float(r) + q.y;
+              const float fc = q.z * float(r) + q.x;
+              const int row = cvtt_f32(roundf(fr));
+              const int col = cvtt_f32(roundf(fc));
+              if (row < y0 || row >= y1 || col < x0 || col >= x1) continue;
+              const unsigned key = ((unsigned)abs(r) << kDfSeqBits) | (kDfSeqMask - (seq0 + (unsigned)ri));
+              atomicMin(&tile[(row - y0) * kDfTile + (col - x0)], key);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!overflow) break;
+    rows_per_chunk = max(1, kDfChunk / ew);  // a chunk of <= kDfChunk pixels cannot overflow either list
+  }
+  const int tw = x1 - x0;
+  for (int i = tid; i < kDfTile * kDfTile; i += kDfThreads) {
+    const int ty = i / kDfTile, tx = i - ty * kDfTile;
+    if (tx < tw && y0 + ty < y1) m.df[(size_t)(y0 + ty) * p.cols + x0 + tx] = tile[i];
   }
 }
 
@@ -753,14 +901,22 @@ void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const
   RH_LAUNCH(k_keyline_flag, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in,
                      db.stash, db.bits, db.rowcount);
   RH_LAUNCH(k_keyline_emit, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash,
-                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st);
+                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st, df_scatter_mode() ? 1 : 0);
   RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m);
 }
 
-void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev) {
+void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, bool mask_is_current) {
   const long long threads = (long long)p.kmax * p.df_nr;
   // measured (MI355X, 640x480 pipeline): 16 workgroups -> 316 us/frame (the field itself becomes the bottleneck), 32 -> 172, 64..128 -> 132, 512 -> 156, 2048 -> 162: the kernel is bound by
   // the memory-side atomic rate and a larger grid only takes CUs and memory queues from the latency-critical streams
+  if (mask_is_current && !df_scatter_mode()) {  // default: LDS tiles driven by the dense keyline mask, no global atomics
+    static const int kTile = (std::getenv("REBVIO_HIP_DF_TILE") && std::atoi(std::getenv("REBVIO_HIP_DF_TILE")) == 64) ? 64 : 32;
+    if (kTile == 64)
+      RH_LAUNCH(k_df_tiles<64>, dim3(div_up(p.cols, 64), div_up(p.rows, 64)), dim3(kDfThreads), 0, s, p, m, det_prev);
+    else
+      RH_LAUNCH(k_df_tiles<32>, dim3(div_up(p.cols, 32), div_up(p.rows, 32)), dim3(kDfThreads), 0, s, p, m, det_prev);
+    return;
+  }
   static const int kDfBlocks = std::getenv("REBVIO_HIP_DF_BLOCKS") ? std::max(1, std::atoi(std::getenv("REBVIO_HIP_DF_BLOCKS"))) : 128;
   const unsigned blocks = (unsigned)std::min<long long>((threads + 255) / 256, kDfBlocks);
   RH_LAUNCH(k_df_build, dim3(blocks), dim3(256), 0, s, p, m, det_prev);

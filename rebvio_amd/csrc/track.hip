@@ -727,7 +727,16 @@ __device__ __forceinline__ float xch_wait(const unsigned long long* w, unsigned 
   while ((unsigned)(v >> 32) != tag) {
     __builtin_amdgcn_s_sleep(1);
     if (++spins > kXchSpinLimit) {
-      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // err[0] = flag, err[1..7] = diagnostics of the first waiter that gave up (host-visible pinned memory)
+      if (__hip_atomic_exchange(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        err[1] = (int)blockIdx.x;
+        err[2] = (int)threadIdx.x;
+        err[3] = (int)tag;
+        err[4] = (int)(unsigned)(v >> 32);
+        err[5] = (int)(unsigned)v;
+        err[6] = (int)gridDim.x;
+        err[7] = (int)(w - (const unsigned long long*)nullptr);
+      }
       break;
     }
     v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -800,8 +809,15 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
   __syncthreads();
   const unsigned min_matches = min(p.min_match_threshold, frame_count);
   RH_STAMP(0);
+  // A workgroup none of whose record groups holds a live keyline of the OLD map takes no part in the LM exchange: the
+  // others do not wait for its records, so it could fall arbitrarily far behind them and find the parity slots already
+  // rewritten. It only needs the final velocity for the extRotVel rows of its NEW-map keylines, which workgroup 0
+  // broadcasts under the launch's last tag. (Workgroup 0 always runs the loop, also for an empty old map.)
+  const bool lm_live = blockIdx.x == 0 || (int)blockIdx.x * kChainGroups < nblocks;
+  unsigned long long* xch_final = xch + (size_t)2 * nrec_launched * kPartStride;
+  const unsigned tag_final = tag_base + (unsigned)calls + 1u;
 
-  for (int call = 0; call < calls; ++call) {
+  for (int call = 0; lm_live && call < calls; ++call) {
     RH_STAMP(1 + call * 6 + 0);
     if (call >= 1) {
       chain_collect_records<kChainThreads>(xch + (size_t)((call - 1) & 1) * nrec_launched * kPartStride, tag_base + (unsigned)call, nblocks,
@@ -892,7 +908,7 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
   }
 
   // final accept / reject of minimizeVel (core.cpp:166-185 for the last evaluation)
-  if (calls > 0) {
+  if (lm_live && calls > 0) {
     chain_collect_records<kChainThreads>(xch + (size_t)((calls - 1) & 1) * nrec_launched * kPartStride, tag_base + (unsigned)calls, nblocks,
                                          rec, red, carry_in, bar_err);
     if (tid == 0) lm_step(s, red, calls, true);
@@ -909,6 +925,11 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
   RH_STAMP(1 + calls * 6);
   if (!do_ext) return;
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
+  if (blockIdx.x == 0 && tid < 3) xch_publish(xch_final + tid, tag_final, s.vel[tid]);
+  if (!lm_live) {
+    if (tid < 3) s.vel[tid] = xch_wait(xch_final + tid, tag_final, bar_err);
+    __syncthreads();
+  }
   const float vx = s.vel[0], vy = s.vel[1], vz = s.vel[2];
   float row[6] = {0, 0, 0, 0, 0, 0};
   float Y = 0.f;
