@@ -670,7 +670,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
   HIPCHK(hipStreamCreateWithPriority(&c->s_key, hipStreamNonBlocking, prio_mid));
   HIPCHK(hipStreamCreateWithPriority(&c->s_trk, hipStreamNonBlocking, prio_greatest));
-  HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, prio_least));
+  const char* dfp = std::getenv("REBVIO_HIP_DF_PRIO");  // experiment knob: "mid" puts the distance field on the detect priority
+  HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, (dfp && std::strcmp(dfp, "mid") == 0) ? prio_mid : prio_least));
   HIPCHK(hipStreamCreateWithFlags(&c->s_cpy, hipStreamNonBlocking));
   const size_t Pn = (size_t)p->rows * p->cols;
   for (int f = 0; f < 2; ++f) {

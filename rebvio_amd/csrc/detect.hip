@@ -618,6 +618,7 @@ __global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, co
   __shared__ unsigned tile[kDfTile * kDfTile];
   __shared__ int l_idx[kDfChunk];
   __shared__ float4 l_geo[kDfChunk];  // pos.x, pos.y, g.x/gn, g.y/gn
+  __shared__ int2 l_rr[kDfChunk];     // range of r that can reach the tile
   __shared__ int l_hits[kDfHits];
   __shared__ int l_n, l_nh;
   const int tid = threadIdx.x, lane = threadIdx.x & 63;
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, co
         for (int h0 = 0; h0 < nh; h0 += kDfThreads) {
           const int h = h0 + tid;
           bool keep = false;
-          int id = 0;
+          int id = 0, r_lo = 0, r_hi = -1;
           float2 pos = make_float2(0.f, 0.f);
           float ux = 0.f, uy = 0.f;
           if (h < nh) {
@@ -695,9 +696,28 @@ __global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, co
             if (!(thr > 0.0f && gn < thr)) {
               ux = g.x / gn;
               uy = g.y / gn;
-              // conservative reach of the probe segment |r| <= half (one pixel of slack for the rounding)
-              const float rx_ = fabsf(ux) * (float)half + 1.0f, ry_ = fabsf(uy) * (float)half + 1.0f;
-              keep = !(pos.x + rx_ < fx0 || pos.x - rx_ > fx1 || pos.y + ry_ < fy0 || pos.y - ry_ > fy1);
+              // range of r whose cell can lie inside the tile (one pixel of slack on each side for the rounding; the
+              // exact in-tile test per cell stays): intersect the x and the y constraint with [-half, half)
+              float lo = -(float)half, hi = (float)(half - 1);
+              if (fabsf(ux) > 1e-6f) {
+                const float a = (fx0 - pos.x) / ux, b = (fx1 - pos.x) / ux;
+                lo = fmaxf(lo, fminf(a, b));
+                hi = fminf(hi, fmaxf(a, b));
+              } else if (pos.x < fx0 || pos.x > fx1) {
+                hi = lo - 1.0f;
+              }
+              if (fabsf(uy) > 1e-6f) {
+                const float a = (fy0 - pos.y) / uy, b = (fy1 - pos.y) / uy;
+                lo = fmaxf(lo, fminf(a, b));
+                hi = fminf(hi, fmaxf(a, b));
+              } else if (pos.y < fy0 || pos.y > fy1) {
+                hi = lo - 1.0f;
+              }
+              r_lo = (int)floorf(lo) - 1;
+              r_hi = (int)ceilf(hi) + 1;
+              r_lo = max(r_lo, -half);
+              r_hi = min(r_hi, half - 1);
+              keep = hi >= lo && r_hi >= r_lo;
             }
           }
           const unsigned long long km = __ballot(keep);
@@ -709,6 +729,7 @@ __global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, co
             if (keep && slot < kDfChunk) {
               l_idx[slot] = id;
               l_geo[slot] = make_float4(pos.x, pos.y, ux, uy);
+              l_rr[slot] = make_int2(r_lo, r_hi);
             }
           }
         }
@@ -720,9 +741,10 @@ __global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, co
           // (c) the (keyline, r) pairs of the list: a wave per keyline, its lanes over r
           for (int k = tid >> 6; k < ln; k += kDfThreads / 64) {
             const float4 q = l_geo[k];
+            const int2 rr = l_rr[k];
             const unsigned seq0 = (unsigned)(l_idx[k] * nr);
-            for (int ri = lane; ri < nr; ri += 64) {
-              const int r = ri - half;
+            for (int r = rr.x + lane; r <= rr.y; r += 64) {
+              const int ri = r + half;
               const float fr = q.w * float(r) + q.y;
               const float fc = q.z * float(r) + q.x;
               const int row = cvtt_f32(roundf(fr));
