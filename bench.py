@@ -66,7 +66,9 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_colscan": 16 * P,              # 2 filters x (in + out); the first pass (1 filter) is 8P
         "k_dog_mag": 16 * P,              # 2 integrals in, DoG + squared gradient out
         "k_keyline_flag": 8 * P + 16 * N,
-        "k_keyline_emit": 8 * P + 116 * N,
+        "k_keyline_emit": 4 * P + 116 * N,  # dense mask + SoA keylines (the tiled distance field needs no clearing pass)
+        "k_front_end_u8": 13 * P,           # u8 gather + 8-byte map in, fp32 frame out
+        "k_regularize_ekf": 108 * N,
         "k_join_edges": 40 * N,
         "k_df_build": 340 * N,            # scatter variant: 80 cells x 4 B atomics + 20 B keyline
         "k_df_tiles": 8 * P + 20 * N,     # tiled variant: mask read once + field written once + keyline geometry
