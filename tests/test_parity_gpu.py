@@ -393,3 +393,41 @@ def test_edge_image_rendering(B, c2_stream):
     assert np.array_equal(got, want)
     black = m.render_edge_image(None)
     assert black.sum() == 255 * len(np.unique(rows * cam.width + cols))
+
+
+def test_persistent_lm_kernel_equals_per_call_kernels(B, c2_stream, monkeypatch):
+    """The persistent minimizeVel / forwardMatch / extRotVel kernel (grid exchange through tagged words, keylines in
+    registers) and the seven per-evaluation kernels it replaces share the per-keyline code and the record order: every
+    output of the pair step must agree bit for bit. Also exercises workgroups without live keylines (15k keylines in a
+    16k-keyline launch) and the streaming pipeline on both paths."""
+    frames, cam = c2_stream
+
+    def run(mode):
+        monkeypatch.setenv("REBVIO_HIP_LM", mode)   # read when the context is created
+        ctx = B.Context(params_for(B, cam, **KW_C2))
+        maps = [ctx.detect_u8(frames[i], i * 50000) for i in range(len(frames))]
+        outs = []
+        for i in range(1, len(frames)):
+            o = ctx.track_pair(maps[i - 1], maps[i])
+            outs.append(np.concatenate([np.array(o.Vg), np.array(o.P_Vg), [o.F, o.sigma_rho_min], np.array(o.Xv), np.array(o.W_Xv),
+                                        np.array(o.Xgv), np.array(o.V), np.array(o.R), np.array(o.P_V),
+                                        [o.klm_num, o.kf_matches, o.reg_num, o.lm_accept_mask, o.status]]).astype(np.float32))
+        last = maps[-1].keylines()
+        # streaming driver on a fresh context of the same mode
+        ctx2 = B.Context(params_for(B, cam, **KW_C2))
+        dev = ctx2.upload_frames(frames)
+        npx = cam.width * cam.height
+        order = list(range(len(frames))) + list(range(len(frames) - 2, -1, -1)) + list(range(1, len(frames)))
+        stream = []
+        for k, i in enumerate(order):
+            out, n = ctx2.push_frame_u8_device(dev + i * npx, k * 50000)
+            if out.status >= 0:
+                stream.append((tuple(out.Vg), tuple(out.Xv), out.klm_num, out.reg_num, n))
+        ctx2.flush()
+        return np.array(outs), last, stream
+
+    a_out, a_kl, a_stream = run("persistent")
+    b_out, b_kl, b_stream = run("percall")
+    assert _bits_equal(a_out, b_out)
+    assert_keylines_equal(a_kl, b_kl, what="last map, persistent vs per-call")
+    assert len(a_stream) > 10 and a_stream == b_stream
