@@ -51,7 +51,7 @@ CONFIGS = {
     "c2": dict(width=640, height=480, keylines_ref=15000, keylines_max=16000,
                name="640x480 synthetic stream, ~15k keylines, detect+track+IRLS pose, fp32"),
     # configs[2] (parity-test case; selectable for inspection, never the default bench line)
-    "c3": dict(width=1280, height=960, keylines_ref=60000, keylines_max=64000,
+    "c3": dict(width=1280, height=960, keylines_ref=60000, keylines_max=64000, density=2.2, warmup=150,
                name="1280x960 synthetic stream, ~60k keylines, detect+track+IRLS pose, fp32"),
 }
 
@@ -124,10 +124,12 @@ def main():
 
     cfg = CONFIGS[args.config]
     W, H = cfg["width"], cfg["height"]
-    steps, warmup = args.steps, max(args.warmup, 3)
+    steps, warmup = args.steps, max(args.warmup, cfg.get("warmup", 3))
 
     # ---- synthetic stream (one per rank), frames resident in HBM -------------------------------------------
-    frames, cam = synth.render_stream(W, H, args.base_frames, stream_id=shard.stream_id_for_rank(rank))
+    # scene density: enough texture for the servo to settle at keylines_ref (1280x960 needs a denser scene for ~60k)
+    frames, cam = synth.render_stream(W, H, args.base_frames, stream_id=shard.stream_id_for_rank(rank),
+                                      density=cfg.get("density", 1.0))
     kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=cfg["keylines_ref"], keylines_max=cfg["keylines_max"],
               device_id=local_rank)
     ctx = B.Context(B.default_params(H, W, **kw))

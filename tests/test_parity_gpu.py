@@ -325,13 +325,17 @@ def test_full_size_properties(B):
     raster-order / mask consistency invariants."""
     from oracle import oracle_py as O
     from rebvio_amd import synth
-    frames, cam = synth.render_stream(1280, 960, 2, density=1.0)
-    kw = dict(keylines_ref=60000, keylines_max=64000)
+    frames, cam = synth.render_stream(1280, 960, 2, density=2.0)
+    kw = dict(keylines_ref=60000, keylines_max=64000, threshold=0.006)   # ~58k keylines on the first frame
     orc = O.Oracle(params_for(O, cam, **kw))
     ctx = B.Context(params_for(B, cam, **kw))
+    oms, gms = [], []
     for i in range(2):
-        om, gm = orc.detect_u8(frames[i]), ctx.detect_u8(frames[i])
+        om, gm = orc.detect_u8(frames[i], i * 50000), ctx.detect_u8(frames[i], i * 50000)
+        oms.append(om)
+        gms.append(gm)
         kg = gm.keylines()
+        assert len(kg) > 50000
         assert_keylines_equal(om.keylines(), kg, what=f"C3 frame {i}")
         mask = gm.mask()
         ys, xs = np.nonzero(mask >= 0)
@@ -340,6 +344,14 @@ def test_full_size_properties(B):
         px = np.floor(kg["pos"] + 0.5)
         assert (np.abs(kg["pos"][:, 0] - xs) <= 0.5).all() and (np.abs(kg["pos"][:, 1] - ys) <= 0.5).all()
         assert px.shape[0] == len(kg)
+    # the pair step at full size: 63 workgroups of the persistent LM kernel, ~230 record groups
+    po, pg = orc.track_pair(oms[0], oms[1]), ctx.track_pair(gms[0], gms[1])
+    assert po.status == pg.status == 0 and po.lm_accept_mask == pg.lm_accept_mask
+    vo, vg = np.array(po.Vg), np.array(pg.Vg)
+    assert np.abs(vo - vg).max() <= 1e-6 + 5e-2 * np.abs(vo).max(), (vo, vg)
+    assert abs(po.klm_num - pg.klm_num) <= 0.01 * po.klm_num
+    ko, kg = oms[1].keylines(), gms[1].keylines()
+    assert (ko["match_id"] == kg["match_id"]).mean() >= 0.97
 
 
 # ---- front end: u8 -> x3 -> undistort on the device ----------------------------------------------------
@@ -431,3 +443,32 @@ def test_persistent_lm_kernel_equals_per_call_kernels(B, c2_stream, monkeypatch)
     assert _bits_equal(a_out, b_out)
     assert_keylines_equal(a_kl, b_kl, what="last map, persistent vs per-call")
     assert len(a_stream) > 10 and a_stream == b_stream
+
+
+def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
+    """The throughput pipeline (detect worker + five streams + persistent pair kernel + deferred counters) against the
+    oracle's own stream driver on the same 30-frame ping-pong sequence, state carried independently on both sides:
+    per-pair translation within 5 % of its magnitude (+1e-6), visual rotation increment within 1e-4 rad, match counts
+    within 1 %; results arrive in pair order, a few pushes late, and flush() delivers nothing out of order."""
+    from rebvio_amd import synth
+    frames, cam = c2_stream
+    order = synth.pingpong_indices(len(frames), 30)
+    ref = orc_mod.Oracle(params_for(orc_mod, cam, **KW_C2)).run_stream(frames, order, threads=1)
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    dev = ctx.upload_frames(frames)
+    npx = cam.width * cam.height
+    got = []
+    for k, i in enumerate(order):
+        out, n = ctx.push_frame_u8_device(dev + int(i) * npx, k * 50000)
+        if out.status >= 0:
+            got.append((np.array(out.Vg), np.array(out.Xgv[3:6]), out.klm_num, out.status))
+    ctx.flush()
+    assert len(got) >= len(order) - 6
+    # the oracle's record k describes pair (k-1, k); the pipeline reports the pairs in the same order starting at pair 1
+    for j, (vg, dw, klm, status) in enumerate(got):
+        k = j + 1
+        assert status == 0
+        vo, wo = ref["pose"][k, :3], ref["pose"][k, 3:]
+        assert np.abs(vo - vg).max() <= 1e-6 + 5e-2 * np.abs(vo).max(), (k, vo, vg)
+        assert np.abs(wo - dw).max() <= 1e-4, (k, wo, dw)
+        assert abs(int(ref["match_counts"][k]) - klm) <= 0.01 * ref["match_counts"][k] + 2
