@@ -1447,6 +1447,17 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
                      calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual), slot, hist_to_zero);
 }
 
+// grid of the wave-per-keyline pass (REBVIO_HIP_DM_TAIL_BLOCKS to experiment): the queue holds a few thousand long
+// searches, each a chain of dependent gathers - more waves in flight shorten the pass until the CUs are full
+static int dm_tail_blocks() {
+  static const int v = [] {
+    const char* e = std::getenv("REBVIO_HIP_DM_TAIL_BLOCKS");
+    const int n = e ? std::atoi(e) : 0;
+    return n > 0 ? n : 512;
+  }();
+  return v;
+}
+
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
                            const float* R0_on_the_fly) {
@@ -1456,7 +1467,7 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
   RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
                      mat3(Rback), max_radius, work, work_n, rot, R0);
-  RH_LAUNCH(k_directed_match_tail, dim3(256), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
+  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks()), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
             (const int*)work, (const int*)work_n, rot, R0);
 }
 
