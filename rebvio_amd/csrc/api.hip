@@ -670,9 +670,15 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
   HIPCHK(hipStreamCreateWithPriority(&c->s_key, hipStreamNonBlocking, prio_mid));
   HIPCHK(hipStreamCreateWithPriority(&c->s_trk, hipStreamNonBlocking, prio_greatest));
-  const char* dfp = std::getenv("REBVIO_HIP_DF_PRIO");  // experiment knob: "mid" puts the distance field on the detect priority
-  HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, (dfp && std::strcmp(dfp, "mid") == 0) ? prio_mid : prio_least));
-  HIPCHK(hipStreamCreateWithFlags(&c->s_cpy, hipStreamNonBlocking));
+  // Three streams per context (scans | keylines + distance field | tracking), deliberately not more: on this runtime every
+  // additional stream of the process slowed the whole pipeline (measured, same code: 3 streams 9.3k frames/s, 4 streams
+  // 9.2k, 5 streams 9.1k; creating a sixth, even unused, 2.6k). REBVIO_HIP_DF_STREAM=own restores a separate
+  // low-priority distance-field stream; the copy stream of the synchronous API is the distance-field stream.
+  if (std::getenv("REBVIO_HIP_DF_STREAM") && std::strcmp(std::getenv("REBVIO_HIP_DF_STREAM"), "own") == 0)
+    HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, prio_least));
+  else
+    c->s_df = c->s_key;
+  c->s_cpy = c->s_df;
   const size_t Pn = (size_t)p->rows * p->cols;
   for (int f = 0; f < 2; ++f) {
     HIPCHK(hipMalloc(&c->sb.a[f], Pn * sizeof(float)));
@@ -790,7 +796,7 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
     if (p) (void)hipHostFree(p);
   (void)hipStreamDestroy(c->s_det);
   (void)hipStreamDestroy(c->s_trk);
-  (void)hipStreamDestroy(c->s_df);
+  if (c->s_df != c->s_key) (void)hipStreamDestroy(c->s_df);
   (void)hipStreamDestroy(c->s_key);
   for (int i = 0; i < 2; ++i) {
     if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
@@ -812,7 +818,7 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->lm_zero) (void)hipFree(c->lm_zero);
   if (c->dm_work) (void)hipFree(c->dm_work);
   if (c->dm_work_n) (void)hipFree(c->dm_work_n);
-  (void)hipStreamDestroy(c->s_cpy);
+  // (s_cpy aliases s_df)
   delete c;
 }
 
