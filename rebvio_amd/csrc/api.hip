@@ -148,6 +148,7 @@ struct rebvio_hip_map {
   hipEvent_t ready{};     // ... and distance field built (distance-field stream)
   hipEvent_t done{};   // last track-stream consumer finished, recorded at release
   bool has_done = false;
+  uint64_t release_seq = 0;  // order of release (pool reuse is oldest-first)
   bool df_built = false;
   std::atomic<int> enqueued{1};  // 0 while the detect worker still has to record `ready` (streaming driver)
   bool pre_rotated = false;  // the next pair's first rotateKeylines (+ histogram) was already applied by the fused B-chain
@@ -168,6 +169,7 @@ struct rebvio_hip_ctx {
   hipEvent_t ev_scan[2]{}, ev_flag[2]{};
   bool ev_flag_used[2] = {false, false};
   uint64_t launch_index = 0;
+  uint64_t release_counter = 0;
   ScaleBufs sb{};
   DetectBufs db{};
   DetState* det = nullptr;  // [kDetRing] servo-state ring + [kDetRing]: scratch sink
@@ -313,15 +315,20 @@ void free_map(rebvio_hip_map* m) {
 
 int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m);
 rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
+  // Oldest release first: a map is released in stream order, i.e. before its last consumer (the pair's B-chain) has
+  // run; reusing the most recently released one makes the new frame's keyline kernels wait for that consumer.
+  rebvio_hip_map* best = nullptr;
   for (auto* m : c->pool)
-    if (!m->in_use) {
-      m->in_use = true;
-      m->df_built = false;
-      m->pre_rotated = false;
-      m->n_host = -1;
-      m->thr_host = -1.0f;
-      return m;
-    }
+    if (!m->in_use && (!best || m->release_seq < best->release_seq)) best = m;
+  if (best) {
+    rebvio_hip_map* m = best;
+    m->in_use = true;
+    m->df_built = false;
+    m->pre_rotated = false;
+    m->n_host = -1;
+    m->thr_host = -1.0f;
+    return m;
+  }
   // every pooled map is alive (a caller queues detections faster than it tracks, like the reference's unbounded
   // edge_map_buffer_): grow the pool, ~4 MB per map at 640x480, bounded
   if (c->pool.size() >= 256) return nullptr;
@@ -996,6 +1003,7 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
   (void)hipEventRecord(m->done, c->s_trk);
   m->has_done = true;
   if (c->df_map == m) c->df_map = nullptr;
+  m->release_seq = ++c->release_counter;
   m->in_use = false;  // (c->last_detected may keep pointing at it: only its MapState is read, stream-ordered)
 }
 
