@@ -114,13 +114,25 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     # rehearsal knobs (never set by the driver): run several ranks on ONE card over gloo to exercise the N>1 path
     dev_index = int(os.environ.get("REBVIO_BENCH_DEVICE", local_rank))
-    backend_name = os.environ.get("REBVIO_BENCH_BACKEND", "nccl")
+    # Control plane of the bench (the data path has no collective): barrier + max over ranks on CPU tensors over gloo, so
+    # that no communicator streams share the GPU's hardware queues with the pipeline while it is timed (the
+    # runtime's stream -> queue mapping is sensitive to every extra stream in the process). REBVIO_BENCH_BACKEND=nccl puts
+    # both on RCCL instead.
+    backend_name = os.environ.get("REBVIO_BENCH_BACKEND", "gloo")
     torch.cuda.set_device(dev_index)
-    shard.init_group(backend_name, rank, world, torch.device("cuda", dev_index))  # RCCL: barrier + max-time only
+    shard.init_group(backend_name, rank, world, torch.device("cuda", dev_index))  # barrier + max-time only
     local_rank = dev_index
 
     from rebvio_amd import backend as B
     from rebvio_amd import synth
+
+    # diagnostic knob (never set by the driver): extra live streams in this process, to see how the runtime's stream -> queue
+    # mapping affects the pipeline
+    _extra = [torch.cuda.Stream() for _ in range(int(os.environ.get("REBVIO_BENCH_EXTRA_STREAMS", "0")))]
+    for _s in _extra:
+        with torch.cuda.stream(_s):
+            torch.zeros(16, device="cuda").add_(1)
+    torch.cuda.synchronize()
 
     cfg = CONFIGS[args.config]
     W, H = cfg["width"], cfg["height"]

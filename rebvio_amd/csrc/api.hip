@@ -675,7 +675,10 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   const int prio_mid = (prio_least + prio_greatest) / 2;
   HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
-  HIPCHK(hipStreamCreateWithPriority(&c->s_key, hipStreamNonBlocking, prio_mid));
+  // one stream per priority class: the runtime pools hardware queues per class (GPU_MAX_HW_QUEUES each) and lets streams of
+  // a class share a queue once the pool is full, so two of our streams in one class can end up serialised behind each
+  // other depending on what else the process created (measured with extra torch streams: 9.3k -> 7.0k frames/s)
+  HIPCHK(hipStreamCreateWithPriority(&c->s_key, hipStreamNonBlocking, prio_least));
   HIPCHK(hipStreamCreateWithPriority(&c->s_trk, hipStreamNonBlocking, prio_greatest));
   // Three streams per context (scans | keylines + distance field | tracking), deliberately not more: on this runtime every
   // additional stream of the process slowed the whole pipeline (measured, same code: 3 streams 9.3k frames/s, 4 streams
