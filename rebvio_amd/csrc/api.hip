@@ -215,8 +215,14 @@ struct rebvio_hip_ctx {
   LmState* lm_zero = nullptr;  // constant start state of minimizeVel (Vg = 0, rebvio.cpp:167)
   // streaming pipeline (rebvio_hip_push_frame_u8_device)
   static constexpr int kSlots = 4;
-  PairSlot* slot[kSlots]{};    // pinned, written by k_ext_rot_vel
+  PairSlot* slot[kSlots]{};    // pinned, written by the A-chain's last kernel
   hipEvent_t slot_ev[kSlots]{};
+  // release of the second half (streaming driver): the B-chain is queued behind a hipStreamWaitValue32 on glue_flag[slot]
+  // BEFORE the host waits for the A-chain; the host glue writes glue_host[slot] and then the flag
+  GlueDev* glue_host[kSlots]{};   // pinned
+  unsigned* glue_flag = nullptr;  // [kSlots], pinned
+  GlueDev* glue_dev = nullptr;    // [kSlots], device copies made by the first kernel behind the wait
+  bool prelaunch_b = true;        // REBVIO_HIP_PRELAUNCH=0: enqueue the B-chain after the glue (kernel arguments)
   struct PendingPair {
     rebvio_hip_map* om = nullptr;
     rebvio_hip_map* nm = nullptr;
@@ -226,6 +232,7 @@ struct rebvio_hip_ctx {
     float frame_dt = 0.f;
     rebvio_hip_pair_out out{};
     bool b_enqueued = false;
+    unsigned seq = 0;  // value that releases this pair's B-chain
   };
   std::vector<rebvio_hip_map*> frames;  // detected maps not yet consumed as "old"
   PendingPair cur{};                    // pair whose A-chain is in flight
@@ -755,6 +762,20 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->slot_ev[i], hipEventDisableTiming));
   }
   HIPCHK(hipMalloc(&c->fscratch, 64 * sizeof(float)));
+  for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
+    HIPCHK(hipHostMalloc(&c->glue_host[i], sizeof(GlueDev), hipHostMallocDefault));
+    std::memset(c->glue_host[i], 0, sizeof(GlueDev));
+  }
+  HIPCHK(hipHostMalloc(&c->glue_flag, rebvio_hip_ctx::kSlots * sizeof(unsigned), hipHostMallocDefault));
+  std::memset(c->glue_flag, 0, rebvio_hip_ctx::kSlots * sizeof(unsigned));
+  HIPCHK(hipMalloc(&c->glue_dev, rebvio_hip_ctx::kSlots * sizeof(GlueDev)));
+  HIPCHK(hipMemset(c->glue_dev, 0, rebvio_hip_ctx::kSlots * sizeof(GlueDev)));
+  {
+    int can = 0;
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
+    const char* e = std::getenv("REBVIO_HIP_PRELAUNCH");
+    c->prelaunch_b = can != 0 && !(e && std::atoi(e) == 0);
+  }
   HIPCHK(hipHostMalloc(&c->h_lm, 2 * sizeof(LmState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_part, part_call_stride(c) * sizeof(float), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_xrv, (size_t)c->maxblocks * kXrvStride * sizeof(float), hipHostMallocDefault));
@@ -823,6 +844,10 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   for (int i = 0; i < 2; ++i)
     if (c->undist_img[i]) (void)hipFree(c->undist_img[i]);
   if (c->lm_xch) (void)hipFree(c->lm_xch);
+  for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i)
+    if (c->glue_host[i]) (void)hipHostFree(c->glue_host[i]);
+  if (c->glue_flag) (void)hipHostFree(c->glue_flag);
+  if (c->glue_dev) (void)hipFree(c->glue_dev);
   if (c->lm_bar_err) (void)hipHostFree(c->lm_bar_err);
   if (c->lm_stamps) (void)hipHostFree(c->lm_stamps);
   if (c->lm_zero) (void)hipFree(c->lm_zero);
@@ -1383,6 +1408,15 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_h
 }
 
 namespace {
+// ---- streaming driver -------------------------------------------------------------------------------------------------
+// Per pair, on the track stream:   A = [rotate] + persistent minimizeVel/forwardMatch/extRotVel   (results -> pinned slot)
+//                                  W = hipStreamWaitValue32(glue_flag[slot] == seq)               (command processor waits)
+//                                  B = directedMatch (2 launches) + regularize/EKF/next rotate, parameters read from
+//                                      glue_host[slot] by the first kernel (which leaves a device copy for the others)
+// Within one push the caller enqueues W(k), B(k) and A(k+1) BEFORE it waits for A(k); then it waits for A(k)'s event, runs
+// the O(1) glue (rebvio.cpp:186-233), writes glue_host[slot] and the flag. No kernel launch sits between the end of A(k)
+// and the start of B(k), and no wait is ever left un-released when the call returns (a guard releases it on every error
+// path with nan_v = 1, so that the queued kernels fall through).
 int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   hipStream_t s = c->s_trk;
   wait_enqueued(pp.om);
@@ -1390,34 +1424,65 @@ int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   HIPCHK(hipStreamWaitEvent(s, pp.om->ready, 0));
   HIPCHK(hipStreamWaitEvent(s, pp.nm->ready, 0));
   c->df_map = pp.nm;
-  pp.R = prior_rotation(c, nullptr);  // equals the rotation a fused B-chain applied: Bg has not changed since
-  float RT[9];
-  hm::store3(hm::transpose(pp.R), RT);
-  if (!pp.om->pre_rotated) launch_rotate(s, c->K, pp.om->d, RT, c->hist, 0);  // else done by the previous B-chain
+  if (!pp.om->pre_rotated) {  // first pair of a stream: no B-chain has applied the prior rotation yet
+    pp.R = prior_rotation(c, nullptr);
+    float RT[9];
+    hm::store3(hm::transpose(pp.R), RT);
+    launch_rotate(s, c->K, pp.om->d, RT, c->hist, 0);
+  }  // else pp.R is set by the caller once the previous pair's glue has updated the gyro bias
   const float v0[3] = {0, 0, 0};
   PairSlot* slot = c->slot[pp.slot];
   int rc = enqueue_pair_lm(c, pp.om, pp.nm, v0, slot);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->slot_ev[pp.slot], s));
-  if (c->dbg) (void)hipEventRecord(c->dbg_ev[2], s);
   pp.a_enqueued = true;
   return 0;
 }
 
-// Completes the pair whose A-chain is in flight: waits for its slot, runs the glue, enqueues its B-chain.
+// W + B of a pair whose A-chain is already queued; everything that depends on the glue is read from memory at run time.
+int enqueue_b_chain_pre(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
+  hipStream_t s = c->s_trk;
+  HIPCHK(hipStreamWaitValue32(s, c->glue_flag + pp.slot, pp.seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
+  pp.b_enqueued = true;  // from here on the flag MUST be written, whatever happens
+  GlueDev* gd = c->glue_dev + pp.slot;
+  launch_directed_match_dev(s, c->K, pp.nm->d, pp.om->d, c->glue_host[pp.slot], gd, c->P.search_range, c->dm_work, c->dm_work_n);
+  const int gate = (int)c->P.global_min_matches_threshold;
+  launch_regularize_ekf_dev(s, c->K, pp.nm->d, gd, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
+  std::swap(pp.nm->d.rs, pp.nm->d.rs_tmp);
+  std::swap(pp.nm->d.grad, pp.nm->d.grad_tmp);
+  pp.nm->pre_rotated = true;
+  rebvio_hip_map_release(pp.om);  // stream-ordered: reusable once the B-chain has drained
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+void release_b_chain(rebvio_hip_ctx* c, const rebvio_hip_ctx::PendingPair& pp) {
+  __atomic_store_n(c->glue_flag + pp.slot, pp.seq, __ATOMIC_RELEASE);
+}
+
+// Completes the pair whose A-chain is in flight: waits for its slot and runs the glue; then either releases the
+// pre-enqueued B-chain or (REBVIO_HIP_PRELAUNCH=0 / per-pair API style) enqueues it with the results as kernel arguments.
 // The directedMatch / regularize counters of the PREVIOUS pair arrive with this slot (old map of this pair).
 int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* completed_keylines, bool* have_completed) {
   rebvio_hip_ctx::PendingPair& cur = c->cur;
+  struct Guard {  // never leave the stream parked behind an un-released wait
+    rebvio_hip_ctx* c;
+    rebvio_hip_ctx::PendingPair* pp;
+    bool armed;
+    ~Guard() {
+      if (armed && pp->b_enqueued) {
+        GlueDev* gh = c->glue_host[pp->slot];
+        std::memset(gh, 0, sizeof(*gh));
+        gh->nan_v = 1;
+        release_b_chain(c, *pp);
+      }
+    }
+  } guard{c, &cur, true};
   const auto tw0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventSynchronize(c->slot_ev[cur.slot]));
   const auto tw1 = std::chrono::steady_clock::now();
   c->t_wait += std::chrono::duration<double, std::micro>(tw1 - tw0).count();
-  if (c->dbg && c->dbg_n > 0) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, c->dbg_ev[0], c->dbg_ev[1]) == hipSuccess) c->dbg_b += ms * 1e3;
-    if (hipEventElapsedTime(&ms, c->dbg_ev[1], c->dbg_ev[2]) == hipSuccess) c->dbg_a += ms * 1e3;
-  }
   PairSlot* slot = c->slot[cur.slot];
   if (c->has_prev) {
     rebvio_hip_pair_out& po = c->prev.out;
@@ -1436,21 +1501,31 @@ int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* compl
   cur.nm->thr_host = slot->new_st.threshold;
   std::memset(&cur.out, 0, sizeof(cur.out));
   const GlueOut g = pair_glue(c, slot->lm, slot->xrv, cur.nm->n_host, cur.frame_dt, cur.R, &cur.out);
-  const auto tg1 = std::chrono::steady_clock::now();
-  c->t_glue += std::chrono::duration<double, std::micro>(tg1 - tw1).count();
   // the new map becomes the next pair's old map: its first rotation (prior after this glue's bias update) rides along
   float RT_next[9];
   hm::store3(hm::transpose(prior_rotation(c, nullptr)), RT_next);
-  if (c->dbg) (void)hipEventRecord(c->dbg_ev[0], c->s_trk);
-  enqueue_b_chain(c, cur.om, cur.nm, g, RT_next);
-  if (c->dbg) {
-    (void)hipEventRecord(c->dbg_ev[1], c->s_trk);
-    c->dbg_n++;
+  if (cur.b_enqueued) {
+    GlueDev* gh = c->glue_host[cur.slot];
+    rotate_inputs(c, g.V, g.P_V, g.Rgva, gh->vel_r, gh->Rvel_r);
+    std::memcpy(gh->Rgva, g.Rgva, sizeof(g.Rgva));
+    std::memcpy(gh->R0a, g.R0a, sizeof(g.R0a));
+    std::memcpy(gh->V, g.V, sizeof(g.V));
+    std::memcpy(gh->RT_next, RT_next, sizeof(RT_next));
+    gh->nan_v = g.nan_v ? 1 : 0;
+    gh->has_next = 1;
+    release_b_chain(c, cur);
+    guard.armed = false;
+    c->t_glue += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count();
+  } else {
+    const auto tg1 = std::chrono::steady_clock::now();
+    c->t_glue += std::chrono::duration<double, std::micro>(tg1 - tw1).count();
+    enqueue_b_chain(c, cur.om, cur.nm, g, RT_next);
+    c->t_b_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tg1).count();
+    HIPCHK(hipGetLastError());
+    rebvio_hip_map_release(cur.om);  // stream-ordered: reusable once the B-chain has drained
+    guard.armed = false;
   }
-  c->t_b_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tg1).count();
-  HIPCHK(hipGetLastError());
   if (g.nan_v) cur.out.status = 1;
-  rebvio_hip_map_release(cur.om);  // stream-ordered: reusable once the B-chain has drained
   c->prev = cur;
   c->has_prev = true;
   c->has_cur = false;
@@ -1460,12 +1535,11 @@ int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* compl
 
 int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
                                     int* keylines) {
-  // Software pipeline over three HIP streams (one host sync per frame):
-  //   detect stream : scale space + keylines of frame f            (this call)
-  //   df stream     : distance field of frame f                     (this call, after detect)
-  //   track stream  : B-chain of pair (f-3, f-2) then A-chain of pair (f-2, f-1)
-  // The returned record is the most recent COMPLETE pair (its match counters travel with the next pair's slot),
-  // i.e. pair (f-4, f-3) in steady state; status -1 while the pipeline fills.
+  // Software pipeline over the three HIP streams of the context (one host synchronisation per frame):
+  //   scan / keyline streams : frame f (this call, through the detect worker)
+  //   track stream           : see the comment above enqueue_a_chain
+  // The returned record is the most recent COMPLETE pair (its match counters travel with the next pair's slot), a few
+  // frames behind f in steady state; status -1 while the pipeline fills.
   rebvio_hip_map* m = nullptr;
   const auto td0 = std::chrono::steady_clock::now();
   HIPCHK(hipSetDevice(c->device));
@@ -1480,6 +1554,28 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
     out->status = -1;
   }
   if (keylines) *keylines = -1;
+  // 1. second half of the pair in flight, parked behind its wait; 2. first half of the next pair behind that
+  int rc_pre = 0;
+  const auto tb0 = std::chrono::steady_clock::now();
+  if (c->has_cur && c->prelaunch_b) rc_pre = enqueue_b_chain_pre(c, c->cur);
+  const auto ta0 = std::chrono::steady_clock::now();
+  c->t_b_enq += std::chrono::duration<double, std::micro>(ta0 - tb0).count();
+  rebvio_hip_ctx::PendingPair pp;
+  bool have_next = false;
+  if (rc_pre == 0 && c->frames.size() >= 3 && (!c->has_cur || c->prelaunch_b)) {
+    // frames[1] was detected at least one call ago: the track stream will not stall on it
+    pp.om = c->frames[0];
+    pp.nm = c->frames[1];
+    pp.slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
+    pp.seq = (unsigned)(++c->pair_seq);
+    if (pp.seq == 0) pp.seq = (unsigned)(++c->pair_seq);  // 0 is the idle value of the flags
+    pp.frame_dt = (float)((double)(float)(pp.nm->ts - pp.om->ts) / 1000000.0);  // rebvio.cpp:183
+    rc_pre = enqueue_a_chain(c, pp);
+    have_next = rc_pre == 0;
+    if (have_next) c->frames.erase(c->frames.begin());
+  }
+  c->t_a_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta0).count();
+  // 3. wait for the pair in flight, glue, release (also on the error paths above: finish_current's guard releases)
   if (c->has_cur) {
     bool have = false;
     rebvio_hip_pair_out done;
@@ -1491,19 +1587,22 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
       if (keylines) *keylines = nk;
     }
   }
-  if (c->frames.size() >= 3) {  // frames[1] was detected at least one call ago: the track stream will not stall on it
-    rebvio_hip_ctx::PendingPair pp;
+  if (rc_pre) return rc_pre;
+  if (!c->prelaunch_b && c->frames.size() >= 3) {  // classic order: the next first half goes behind the B-chain just enqueued
     pp.om = c->frames[0];
     pp.nm = c->frames[1];
-    pp.slot = (int)(c->pair_seq++ % rebvio_hip_ctx::kSlots);
-    pp.frame_dt = (float)((double)(float)(pp.nm->ts - pp.om->ts) / 1000000.0);  // rebvio.cpp:183
-    const auto ta0 = std::chrono::steady_clock::now();
+    pp.slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
+    pp.seq = (unsigned)(++c->pair_seq);
+    pp.frame_dt = (float)((double)(float)(pp.nm->ts - pp.om->ts) / 1000000.0);
     rc = enqueue_a_chain(c, pp);
     if (rc) return rc;
-    c->t_a_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta0).count();
+    have_next = true;
+    c->frames.erase(c->frames.begin());
+  }
+  if (have_next) {
+    if (pp.om->pre_rotated) pp.R = prior_rotation(c, nullptr);  // what the previous B-chain applies (gyro bias as of now)
     c->cur = pp;
     c->has_cur = true;
-    c->frames.erase(c->frames.begin());
   }
   return 0;
 }
@@ -1527,14 +1626,14 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     const double n = (double)c->t_frames;
     std::fprintf(stderr, "[rebvio_hip] per frame (us): detect-enqueue %.1f  wait %.1f  glue %.1f  B-enqueue %.1f  A-enqueue %.1f\n",
                  c->t_detect_enq / n, c->t_wait / n, c->t_glue / n, c->t_b_enq / n, c->t_a_enq / n);
-    if (c->dbg_n > 1)
-      std::fprintf(stderr, "[rebvio_hip] GPU spans on the track stream (us): B-chain %.1f  A-chain %.1f\n", c->dbg_b / (c->dbg_n - 1),
-                   c->dbg_a / (c->dbg_n - 1));
   }
   while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   if (c->has_cur) {
-    int rc = finish_current(c, nullptr, nullptr, nullptr);
+    int rc = 0;
+    if (c->prelaunch_b) rc = enqueue_b_chain_pre(c, c->cur);
+    const int rc2 = finish_current(c, nullptr, nullptr, nullptr);  // releases the wait in every case
     if (rc) return rc;
+    if (rc2) return rc2;
   }
   if (c->has_prev) {
     rebvio_hip_map_release(c->prev.nm);

@@ -157,6 +157,19 @@ struct PairSlot {
   MapState old_st;     // snapshot of the old map's scalars (directedMatch / regularize counters of the previous pair)
   float xrv[1];        // [nblocks][kXrvStride] block records follow
 };
+// Result of the host glue of one pair (rebvio.cpp:186-233) as the second half of the pair step reads it from memory
+// (streaming driver): the host writes it into pinned memory and releases the stream (hipStreamWaitValue32 on a pinned
+// flag); the first kernel behind the wait reads it in place and leaves a device copy for the kernels after it.
+struct GlueDev {
+  float vel_r[3];    // Rback * V            (edge_map.cpp:193)
+  float Rvel_r[9];   // Rback * P_V * Rback' (edge_map.cpp:194)
+  float Rgva[9];     // Rback
+  float R0a[9];      // second rotateKeylines of the old map, applied on the fly by directedMatch
+  float V[3];        // translation for the depth EKF
+  float RT_next[9];  // first rotateKeylines of the NEXT pair (new map becomes its old map)
+  int nan_v;         // rebvio.cpp:236: no matching / regularisation / depth update for this pair
+  int has_next;      // RT_next valid
+};
 void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
                         float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero);
@@ -180,6 +193,12 @@ void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_i
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
                            const float* R0_on_the_fly);
+// the same two launches with vel / Rvel / Rback / R0 taken from memory at run time: the first kernel reads *g_pinned and
+// copies it to *g_dev, the second reads *g_dev
+void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* g_pinned,
+                               GlueDev* g_dev, float max_radius, int* work, int* work_n);
+void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* work_n_reset,
+                               int* hist);
 // fused regularize1Iter + depth EKF: reads m.rs, writes m.rs_tmp (caller swaps the pointers); Rnext != null also
 // applies the next pair's first rotation and bins sigma_rho into hist
 void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, int* work_n_reset,

@@ -1087,9 +1087,51 @@ constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-
 // fetched together, acceptance runs in the reference's order. Keylines whose search is longer and still open are
 // queued for pass 2 (a wave with one such lane would otherwise idle 63 lanes for up to 40 more dependent steps).
 // vel / Rvel are already rotated by Rback on the host (:193-194).
-__global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel, Mat3 Rvel, Mat3 Rback,
+// gd != null: vel / Rvel / Rback / R0 come from *gd (uniform scalar loads) instead of the kernel arguments.
+struct DmArgs {
+  Vec3 vel;
+  Mat3 Rvel, Rback, R0;
+  int rot;
+  bool skip;
+};
+__device__ __forceinline__ DmArgs dm_args(const GlueDev* __restrict__ gd, const Vec3& vel, const Mat3& Rvel, const Mat3& Rback, int rot,
+                                          const Mat3& R0) {
+  DmArgs a;
+  if (gd) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.vel.a[i] = gd->vel_r[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      a.Rvel.a[i] = gd->Rvel_r[i];
+      a.Rback.a[i] = gd->Rgva[i];
+      a.R0.a[i] = gd->R0a[i];
+    }
+    a.rot = 1;
+    a.skip = gd->nan_v != 0;
+  } else {
+    a.vel = vel;
+    a.Rvel = Rvel;
+    a.Rback = Rback;
+    a.R0 = R0;
+    a.rot = rot;
+    a.skip = false;
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                        int rot, Mat3 R0) {
+                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
+                                                        GlueDev* __restrict__ gd_copy) {
+  if (gd && gd_copy && blockIdx.x == 0) {  // device copy for the kernels queued behind this one
+    constexpr int kWords = (int)(sizeof(GlueDev) / sizeof(int));
+    if ((int)threadIdx.x < kWords) reinterpret_cast<int*>(gd_copy)[threadIdx.x] = reinterpret_cast<const int*>(gd)[threadIdx.x];
+  }
+  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
+  if (A.skip) return;
+  const Vec3& vel = A.vel;
+  const Mat3 &Rvel = A.Rvel, &Rback = A.Rback, &R0 = A.R0;
+  const int rot = A.rot;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid)
   const float2 rsq = nm.rs[idx];
@@ -1163,9 +1205,15 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
 // Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
 // sequence; the first accepted slot in that order (lowest slot index) is the match, found with a ballot.
 // tn/tp are produced by the same repeated -1.0f / +1.0f steps as the sequential loop (not dq_rho -/+ k).
-__global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev nm, MapDev om, Vec3 vel, Mat3 Rvel, Mat3 Rback,
+__global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                              float max_radius, const int* __restrict__ work,
-                                                             const int* __restrict__ work_n, int rot, Mat3 R0) {
+                                                             const int* __restrict__ work_n, int rot_, Mat3 R0_,
+                                                             const GlueDev* __restrict__ gd) {
+  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
+  if (A.skip) return;
+  const Vec3& vel = A.vel;
+  const Mat3 &Rvel = A.Rvel, &Rback = A.Rback, &R0 = A.R0;
+  const int rot = A.rot;
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int total = *work_n;
@@ -1294,9 +1342,22 @@ __global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel
 // Jacobi semantics need the neighbours' OLD depths: read rs, write rs_tmp; the host then swaps the two pointers of
 // this map. Optionally (streaming driver) the keyline is also put through the NEXT pair's first rotateKeylines
 // (rebvio.cpp:165) and binned for its estimateQuantile, which removes that pair's k_rotate launch.
-__global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec3 vel, int gate_min_matches,
-                                                        int* __restrict__ work_n_reset, int next_rot, Mat3 Rnext,
-                                                        int* __restrict__ hist, int hist_bins) {
+// gd != null: vel / next rotation come from *gd; gd->nan_v (rebvio.cpp:236) leaves rho untouched like the match gate.
+__global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
+                                                        int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
+                                                        int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
+  Vec3 vel = vel_;
+  Mat3 Rnext = Rnext_;
+  int next_rot = next_rot_;
+  bool skip_pair = false;
+  if (gd) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vel.a[i] = gd->V[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rnext.a[i] = gd->RT_next[i];
+    next_rot = gd->has_next;
+    skip_pair = gd->nan_v != 0;
+  }
   __shared__ int sh[128];
   if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1309,7 +1370,7 @@ __global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec
   const float mgn = m.mgnorm[idx];
   float2 g = m.grad[idx];
   const int n = m.st->n;
-  const bool gated = gate_min_matches > 0 && m.st->dm_matches < gate_min_matches;
+  const bool gated = skip_pair || (gate_min_matches > 0 && m.st->dm_matches < gate_min_matches);
   if (next_rot) {
     if (threadIdx.x < 128) sh[threadIdx.x] = 0;
     __syncthreads();
@@ -1466,9 +1527,18 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
   RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
-                     mat3(Rback), max_radius, work, work_n, rot, R0);
+                     mat3(Rback), max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks()), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
-            (const int*)work, (const int*)work_n, rot, R0);
+            (const int*)work, (const int*)work_n, rot, R0, (const GlueDev*)nullptr);
+}
+
+void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* g_pinned,
+                               GlueDev* g_dev, float max_radius, int* work, int* work_n) {
+  const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+  RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, work,
+            work_n, 1, mat3(I), g_pinned, g_dev);
+  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks()), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
+            (const int*)work, (const int*)work_n, 1, mat3(I), (const GlueDev*)g_dev);
 }
 
 void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate, int* work_n_reset) {
@@ -1479,7 +1549,14 @@ void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, con
                            const float* Rnext, int* hist) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(vel), gate, work_n_reset, Rnext ? 1 : 0,
-            mat3(Rnext ? Rnext : I), hist, p.quantile_num_bins);
+            mat3(Rnext ? Rnext : I), hist, p.quantile_num_bins, (const GlueDev*)nullptr);
+}
+
+void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* work_n_reset,
+                               int* hist) {
+  const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+  RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(z), gate, work_n_reset, 0, mat3(I), hist,
+            p.quantile_num_bins, g_dev);
 }
 
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp, int gate) {
