@@ -385,13 +385,14 @@ void sym_pinv_solve_d(const double* A_, const double* b_, double* x_) {
       V[i][j] = (i == j) ? 1.0 : 0.0;
     }
   for (int sweep = 0; sweep < 80; ++sweep) {
-    double off = 0;
-    for (int p = 0; p < N; ++p)
-      for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
-    if (off < 1e-300) break;
+    // cyclic Jacobi with the relative criterion: an off-diagonal element that is negligible against its two diagonal
+    // elements is left alone, a sweep without any rotation ends the iteration (an absolute threshold never triggers when
+    // the spectrum spans 1e15, as the information matrix of this filter does)
+    int rotations = 0;
     for (int p = 0; p < N; ++p)
       for (int q = p + 1; q < N; ++q) {
-        if (A[p][q] == 0.0) continue;
+        if (A[p][q] == 0.0 || std::fabs(A[p][q]) <= 1e-17 * std::sqrt(std::fabs(A[p][p] * A[q][q]))) continue;
+        ++rotations;
         double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
         double t = ((theta >= 0) ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
         double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
@@ -411,6 +412,7 @@ void sym_pinv_solve_d(const double* A_, const double* b_, double* x_) {
           V[k][q] = sn * vkp + cs * vkq;
         }
       }
+    if (rotations == 0) break;
   }
   double dmax = 0;
   for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(A[i][i]));

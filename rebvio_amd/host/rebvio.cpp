@@ -14,6 +14,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <limits>
 
@@ -95,6 +97,17 @@ void Rebvio::dataAcquisitionProcess() {
       std::this_thread::sleep_for(std::chrono::milliseconds(1));
       continue;
     }
+    // back-pressure: the reference's edge-map queue is unbounded (rebvio.cpp:86-90); here every queued map holds device
+    // memory from a bounded pool, so detection waits while the tracker is more than a few maps behind
+    for (;;) {
+      size_t queued;
+      {
+        std::lock_guard<std::mutex> guard(edge_map_buffer_mutex_);
+        queued = edge_map_buffer_.size();
+      }
+      if (queued < 8 || !run_) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
     rebvio::EdgeMap::SharedPtr edge_map = edge_detector_.detect(img);
     if (!edge_image_callbacks_.empty()) {
       // callbacks see the undistorted frame, as in the reference; for a raw u8 frame of a distorting lens it is fetched
@@ -124,8 +137,34 @@ void Rebvio::dataAcquisitionProcess() {
   }
 }
 
+namespace {
+// stand-in for the reference's REBVIO_TIMER accumulators (util/timer.hpp): per-stage host times of the tracking worker,
+// printed when the worker ends if REBVIO_HOST_TIMERS is set
+struct StageTimers {
+  bool on = std::getenv("REBVIO_HOST_TIMERS") != nullptr;
+  double t[4] = {0, 0, 0, 0};
+  unsigned n = 0;
+  std::chrono::steady_clock::time_point last;
+  void start() {
+    if (on) last = std::chrono::steady_clock::now();
+  }
+  void lap(int i) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    t[i] += std::chrono::duration<double, std::micro>(now - last).count();
+    last = now;
+  }
+  ~StageTimers() {
+    if (on && n)
+      std::fprintf(stderr, "[Rebvio] per pair (us): first half on device %.1f  acceleration + bias/scale filter %.1f  second half on device %.1f  pose + callbacks %.1f\n",
+                   t[0] / n, t[1] / n, t[2] / n, t[3] / n);
+  }
+};
+}  // namespace
+
 void Rebvio::stateEstimationProcess() {
   REBVIO_INFO("Starting State Estimation Process..");
+  StageTimers timers;
   rebvio_hip_ctx* ctx = core_.session()->ctx();
   const types::Float FMAX = std::numeric_limits<types::Float>::max();
   types::Vector3f Pos = TooN::Zeros;
@@ -193,6 +232,7 @@ void Rebvio::stateEstimationProcess() {
     store3(imu.R(), Rp);
     const types::Float frame_dt = types::Float(new_edge_map->ts_us() - old_edge_map->ts_us()) / 1000000.0;
     rebvio_hip_pair_mid mid;
+    timers.start();
     backend::check("rebvio_hip_track_pair_begin",
                    rebvio_hip_track_pair_begin(ctx, old_edge_map->handle(), new_edge_map->handle(), Rp, frame_dt, &mid));
     {
@@ -204,6 +244,7 @@ void Rebvio::stateEstimationProcess() {
     // the noise models the backend applied in gyroBiasCorrection (rebvio.cpp:186-187); RGBias feeds next frame's W_Bg init
     imu_state_.RGBias = TooN::Identity * (double)(config_.imu_state.gyro_bias_std_dev * config_.imu_state.gyro_bias_std_dev * frame_dt * frame_dt);
     imu_state_.RGyro = TooN::Identity * (double)(config_.imu_state.gyro_std_dev * config_.imu_state.gyro_std_dev * frame_dt * frame_dt);
+    timers.lap(0);
     imu_state_.Vg = TooN::makeVector(mid.Vg[0], mid.Vg[1], mid.Vg[2]);
     imu_state_.P_Vg = load3(mid.P_Vg);
     types::Vector6f Xgv, Xgva;
@@ -263,8 +304,10 @@ void Rebvio::stateEstimationProcess() {
     store3(Rgva, rg);
     store3(R_second, r2);
     int klm_num = 0, kf_matches = 0, reg_num = 0, status = 0;
+    timers.lap(1);
     backend::check("rebvio_hip_track_pair_finish", rebvio_hip_track_pair_finish(ctx, old_edge_map->handle(), new_edge_map->handle(), V,
                                                                                 pv, rg, r2, &klm_num, &kf_matches, &reg_num, &status));
+    timers.lap(2);
     old_edge_map->invalidateMirror();
     new_edge_map->invalidateMirror();
     if (status == 1) {  // rebvio.cpp:236-241
@@ -297,6 +340,8 @@ void Rebvio::stateEstimationProcess() {
     odometry.gyro_bias = imu_state_.Bg;
     odometry.klm_num = klm_num;
     for (auto& cb : odometry_callbacks_) cb(odometry);
+    timers.lap(3);
+    timers.n++;
     ++num_frames_;
   }
 }
