@@ -179,11 +179,11 @@ struct rebvio_hip_ctx {
   std::vector<rebvio_hip_map*> pool;
   float* img_dev = nullptr;
   uint8_t* img8_dev = nullptr;
-  static constexpr int kPin8 = 4;  // pinned staging ring of rebvio_hip_detect_u8 (allocated on first use)
-  uint8_t* pin8[kPin8]{};
-  hipEvent_t pin8_ev[kPin8]{};
-  bool pin8_used[kPin8]{};
-  uint64_t pin8_next = 0;
+  static constexpr int kPin = 4;  // pinned staging ring of the host-frame detect entries (allocated on first use)
+  void* pin[kPin]{};
+  hipEvent_t pin_ev[kPin]{};
+  bool pin_used[kPin]{};
+  uint64_t pin_next = 0;
   int2* undist_map = nullptr;      // fixed-point source coordinates (null: no lens distortion, front end = x3 only)
   float* undist_img[2]{};          // undistorted fp32 frame, double-buffered like dog2 / mag2
   rebvio_hip_keyline* aos_dev = nullptr;
@@ -586,6 +586,28 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
   return 0;
 }
 
+// Host frame -> pinned ring slot (plain memcpy) -> asynchronous copy on the scan stream. A copy straight from pageable
+// memory is staged inside the runtime, which stays busy for the whole transfer and stalls the launches of the tracking
+// thread of rebvio::Rebvio (measured: second half of the pair step 215 us -> 47 us); it also must not outlive the caller's
+// buffer. The device staging frames are read by the scan stream's own kernels only, so stream order is reuse order.
+int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, size_t row_bytes, void* dst_dev) {
+  if (!c->pin[0]) {
+    for (int i = 0; i < rebvio_hip_ctx::kPin; ++i) {
+      HIPCHK(hipHostMalloc(&c->pin[i], (size_t)c->P.rows * c->P.cols * sizeof(float), hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+    }
+  }
+  const int ps = (int)(c->pin_next++ % rebvio_hip_ctx::kPin);
+  if (c->pin_used[ps]) HIPCHK(hipEventSynchronize(c->pin_ev[ps]));  // its previous copy has left the slot
+  uint8_t* dst = static_cast<uint8_t*>(c->pin[ps]);
+  const uint8_t* src = static_cast<const uint8_t*>(img);
+  for (int r = 0; r < c->P.rows; ++r) std::memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * pitch_bytes, row_bytes);
+  HIPCHK(hipMemcpyAsync(dst_dev, dst, (size_t)c->P.rows * row_bytes, hipMemcpyHostToDevice, c->s_det));
+  HIPCHK(hipEventRecord(c->pin_ev[ps], c->s_det));
+  c->pin_used[ps] = true;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -849,9 +871,9 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   for (int i = 0; i < 2; ++i)
     if (c->undist_img[i]) (void)hipFree(c->undist_img[i]);
   if (c->lm_xch) (void)hipFree(c->lm_xch);
-  for (int i = 0; i < rebvio_hip_ctx::kPin8; ++i) {
-    if (c->pin8[i]) (void)hipHostFree(c->pin8[i]);
-    if (c->pin8_ev[i]) (void)hipEventDestroy(c->pin8_ev[i]);
+  for (int i = 0; i < rebvio_hip_ctx::kPin; ++i) {
+    if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+    if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
   }
   for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i)
     if (c->glue_host[i]) (void)hipHostFree(c->glue_host[i]);
@@ -891,7 +913,8 @@ int rebvio_hip_detect(rebvio_hip_ctx* c, const float* img, size_t pitch_bytes, u
   HIPCHK(hipSetDevice(c->device));
   const size_t rowb = (size_t)c->P.cols * sizeof(float);
   if (pitch_bytes == 0) pitch_bytes = rowb;
-  HIPCHK(hipMemcpy2DAsync(c->img_dev, rowb, img, pitch_bytes, rowb, c->P.rows, hipMemcpyHostToDevice, c->s_det));
+  int rc = stage_host_frame(c, img, pitch_bytes, rowb, c->img_dev);
+  if (rc) return rc;
   return detect_common(c, c->img_dev, 0, ts_us, out);
 }
 
@@ -904,22 +927,8 @@ int rebvio_hip_detect_u8(rebvio_hip_ctx* c, const uint8_t* img, size_t pitch_byt
   HIPCHK(hipSetDevice(c->device));
   const size_t rowb = (size_t)c->P.cols;
   if (pitch_bytes == 0) pitch_bytes = rowb;
-  // Host frame -> pinned ring slot (plain memcpy) -> asynchronous copy on the scan stream. A copy straight from pageable
-  // memory is staged synchronously inside the runtime and keeps its lock for the whole transfer, which stalls the
-  // launches of the tracking thread of rebvio::Rebvio (measured: second half of the pair step 215 us -> see DESIGN.md).
-  // The device staging frame is read by the scan stream's own kernels only, so stream order is reuse order.
-  if (!c->pin8[0]) {
-    for (int i = 0; i < rebvio_hip_ctx::kPin8; ++i) {
-      HIPCHK(hipHostMalloc(&c->pin8[i], (size_t)c->P.rows * c->P.cols, hipHostMallocDefault));
-      HIPCHK(hipEventCreateWithFlags(&c->pin8_ev[i], hipEventDisableTiming));
-    }
-  }
-  const int ps = (int)(c->pin8_next++ % rebvio_hip_ctx::kPin8);
-  if (c->pin8_used[ps]) HIPCHK(hipEventSynchronize(c->pin8_ev[ps]));  // its previous copy has left the slot
-  for (int r = 0; r < c->P.rows; ++r) std::memcpy(c->pin8[ps] + (size_t)r * rowb, img + (size_t)r * pitch_bytes, rowb);
-  HIPCHK(hipMemcpyAsync(c->img8_dev, c->pin8[ps], (size_t)c->P.rows * rowb, hipMemcpyHostToDevice, c->s_det));
-  HIPCHK(hipEventRecord(c->pin8_ev[ps], c->s_det));
-  c->pin8_used[ps] = true;
+  int rc = stage_host_frame(c, img, pitch_bytes, rowb, c->img8_dev);
+  if (rc) return rc;
   return detect_common(c, c->img8_dev, 1, ts_us, out);
 }
 
