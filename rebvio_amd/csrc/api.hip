@@ -572,9 +572,17 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
     first = c->lm;
   }
   if (c->lm_stamps && c->lm_stamps[0]) {  // stamps of the previous launch (the caller has synchronised on its slot since)
+    // the buffer may be half rewritten by a launch that is already running (streaming driver): take a snapshot and use it
+    // only if it is monotonic and spans less than a millisecond
     const int ns = 3 + calls * 6;
-    for (int i = 1; i < ns; ++i) c->lm_stamp_acc[i] += (double)(c->lm_stamps[i] - c->lm_stamps[i - 1]) * 0.01;
-    c->lm_stamp_n++;
+    unsigned long long snap[64];
+    for (int i = 0; i < ns; ++i) snap[i] = c->lm_stamps[i];
+    bool sane = snap[ns - 1] > snap[0] && snap[ns - 1] - snap[0] < 100000ull;
+    for (int i = 1; i < ns && sane; ++i) sane = snap[i] >= snap[i - 1];
+    if (sane) {
+      for (int i = 1; i < ns; ++i) c->lm_stamp_acc[i] += (double)(snap[i] - snap[i - 1]) * 0.01;
+      c->lm_stamp_n++;
+    }
   }
   launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
                   slot->xrv, slot, c->hist, c->lm_stamps);

@@ -337,7 +337,23 @@ struct TvIn {
   float gn;
   float2 rs, pi, g2;
   unsigned nmatches;
+  // velocity-independent sub-expressions of calculatefJ, evaluated once per keyline instead of once per evaluation
+  // (same operands, same operations -> same bits): 1/rho and 1/sigma in double, search_range / sigma
+  double inv_rho_d, inv_sig_d;
+  float range_over_sig;
 };
+__device__ __forceinline__ TvIn make_tvin(const KParams& p, float gn, float2 rs, float2 pi, float2 g2, unsigned nmatches) {
+  TvIn k;
+  k.gn = gn;
+  k.rs = rs;
+  k.pi = pi;
+  k.g2 = g2;
+  k.nmatches = nmatches;
+  k.inv_rho_d = 1.0 / (double)rs.x;
+  k.inv_sig_d = 1.0 / (double)rs.y;
+  k.range_over_sig = p.search_range / rs.y;
+  return k;
+}
 struct TvOut {
   float f, jx, jy, jz, fi, res_out;
   int mfwd;
@@ -357,7 +373,7 @@ __device__ __forceinline__ TvOut try_vel_eval(const KParams& p, const MapDev& nm
     res_out = res;
     float weight = 1.0f;
     if (res > p.reweight_distance) weight = p.reweight_distance / res;
-    const float z_p = (float)(1.0 / (double)rs.x + (double)vz);
+    const float z_p = (float)(k.inv_rho_d + (double)vz);
     bool penalty1 = false;
     float rho_p = 0.f, p_x = 0.f, p_y = 0.f, p_xc = 0.f, p_yc = 0.f;
     int x = 0, y = 0;
@@ -375,7 +391,7 @@ __device__ __forceinline__ TvOut try_vel_eval(const KParams& p, const MapDev& nm
     }
     contrib = true;
     if (penalty1) {
-      f = (float)(((1.0 / (double)rs.y) * (double)p.search_range) * (double)weight);
+      f = (float)((k.inv_sig_d * (double)p.search_range) * (double)weight);
     } else {
       float df_dx = 0.f, df_dy = 0.f;
       const unsigned key = nm.df[(size_t)y * p.cols + x];
@@ -400,7 +416,7 @@ __device__ __forceinline__ TvOut try_vel_eval(const KParams& p, const MapDev& nm
         }
       }
       if (!matched) {
-        f = p.search_range / rs.y;
+        f = k.range_over_sig;
         need_carry = true;
       }
       f *= weight;
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(256) void k_try_vel(KParams p, MapDev om, MapDev nm
   TvOut e{};
   e.mfwd = -1;
   if (idx < n) {
-    const TvIn in{gn, rs, pi, g2, nmatches};
+    const TvIn in = make_tvin(p, gn, rs, pi, g2, nmatches);
     e = try_vel_eval(p, nm, in, res_in, cin, vx, vy, vz, srm, thr, min_matches);
     if (e.wrote_res) om.residual[idx] = e.res_out;
     if (e.matched && last) {
@@ -783,7 +799,7 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
   const int lane = tid & 63, wid = tid >> 6, grp = tid >> 8, wig = wid & 3;
   const int nrec_launched = gridDim.x * kChainGroups;
   // own keyline of the old map (tryVel) and of the new map (extRotVel): loaded once, bound-free (arrays are padded)
-  const TvIn in{om.gnorm[idx], om.rs[idx], om.pos_img[idx], om.grad[idx], om.matches[idx]};
+  const TvIn in = make_tvin(p, om.gnorm[idx], om.rs[idx], om.pos_img[idx], om.grad[idx], om.matches[idx]);
   float res = om.residual[idx];
   XrvIn xk{};
   if (do_ext) {
