@@ -231,14 +231,24 @@ bool SABEstimator::problem(rebvio::types::Matrix7f& JtJ_, rebvio::types::Vector7
   const Mx<7, 7> Wp = chol_inverse<7>(Pp);
   for (int i = 0; i < 7; ++i)
     for (int j = 0; j < 7; ++j) W.a[4 + i][4 + j] = Wp.a[i][j];
+  // dP/da is non-zero in the 3x3 measurement block only, so dW/da = -W dP/da W and dW/da P dW/da live there too: the
+  // products are formed on the 3x3 blocks (the dense 11x11 products add exact zeros to the same terms)
+  Mx<3, 3> dPz;
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) dPda.a[i][j] = 2.0 * sa * ca * (cfg.Rv(i, j) - cfg.Rs(i, j));
-  Mx<11, 11> dWda = mul(mul(W, dPda), W);
-  for (int i = 0; i < 11; ++i)
-    for (int j = 0; j < 11; ++j) dWda.a[i][j] = -dWda.a[i][j];
+    for (int j = 0; j < 3; ++j) {
+      dPz.a[i][j] = 2.0 * sa * ca * (cfg.Rv(i, j) - cfg.Rs(i, j));
+      dPda.a[i][j] = dPz.a[i][j];
+    }
+  Mx<3, 3> dWz = mul(mul(Wz, dPz), Wz);
+  Mx<11, 11> dWda = Mx<11, 11>::zeros();
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      dWz.a[i][j] = -dWz.a[i][j];
+      dWda.a[i][j] = dWz.a[i][j];
+    }
   {
-    const Mx<11, 11> M = mul(mul(dWda, P), dWda);
-    JtJ_(0, 0) = 0.25 * quad<11>(F, M, F) + quad<11>(dFda, dWda, F) + quad<11>(dFda, W, dFda);
+    const Mx<3, 3> Mz = mul(mul(dWz, Pz), dWz);
+    JtJ_(0, 0) = 0.25 * quad<3>(F, Mz, F) + quad<11>(dFda, dWda, F) + quad<11>(dFda, W, dFda);
   }
   const Mx<6, 11> dT = tr(dFdx1);
   {
