@@ -94,8 +94,8 @@ def launches_per_frame(kernel: str, iterations: int = 5) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--base-frames", type=int, default=24, help="distinct rendered frames (ping-pong replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,8 +182,9 @@ def main():
 
     # ---- timed region: EXACTLY `steps` frames ------------------------------------------------------------------
     ctx.profile_reset()
-    # HIP events around every 8th launch of the dominant kernel, recorded on the stream it is launched on
-    ctx.profile(True, only=dominant, stride=8)
+    # HIP events around every n-th launch of the dominant kernel (n >= 8, at most ~200 samples: the event pool is
+    # preallocated, creating events inside the timed region would cost more than it measures), on the stream it runs on
+    ctx.profile(True, only=dominant, stride=max(8, (steps * launches_per_frame(dominant.split("<")[0])) // 200))
     statuses = []
     matches = []
     barrier()

@@ -262,7 +262,7 @@ struct rebvio_hip_ctx {
   bool det_stop = false;
   std::string det_error;
   // host-side phase timing of the streaming driver (printed by flush when REBVIO_HIP_DEBUG is set)
-  double t_detect_enq = 0, t_wait = 0, t_glue = 0, t_b_enq = 0, t_a_enq = 0;
+  double t_detect_enq = 0, t_wait = 0, t_glue = 0, t_b_enq = 0, t_a_enq = 0, t_queued = 0;
   bool dbg = false;
   hipEvent_t dbg_ev[3]{};  // B start, B end / A start, A end
   double dbg_b = 0, dbg_a = 0;
@@ -1532,6 +1532,7 @@ int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* compl
       po.reg_num = slot->old_st.reg_count;
       if ((unsigned)po.klm_num < c->P.global_min_matches_threshold) po.status = 2;
     }
+    c->t_queued += (double)slot->old_st.dm_queued;
     if (completed) *completed = po;
     if (completed_keylines) *completed_keylines = slot->old_st.n;
     if (have_completed) *have_completed = true;
@@ -1664,8 +1665,10 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
   }
   if (std::getenv("REBVIO_HIP_DEBUG") && c->t_frames) {
     const double n = (double)c->t_frames;
-    std::fprintf(stderr, "[rebvio_hip] per frame (us): detect-enqueue %.1f  wait %.1f  glue %.1f  B-enqueue %.1f  A-enqueue %.1f\n",
-                 c->t_detect_enq / n, c->t_wait / n, c->t_glue / n, c->t_b_enq / n, c->t_a_enq / n);
+    std::fprintf(stderr,
+                 "[rebvio_hip] per frame (us): detect-enqueue %.1f  wait %.1f  glue %.1f  B-enqueue %.1f  A-enqueue %.1f | long "
+                 "directedMatch searches per pair %.0f\n",
+                 c->t_detect_enq / n, c->t_wait / n, c->t_glue / n, c->t_b_enq / n, c->t_a_enq / n, c->t_queued / n);
   }
   while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   if (c->has_cur) {

@@ -33,7 +33,8 @@ struct MapState {
   int dm_matches;      // directedMatch counters
   int dm_kf;
   int reg_count;
-  int pad[8];
+  int dm_queued;       // directedMatch: long searches handed to the wave-per-keyline pass (diagnostic)
+  int pad[7];
 };
 
 // EdgeDetector servo state (edge_detector.hpp:84-91), ping-ponged between frames.

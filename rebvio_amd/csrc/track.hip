@@ -1233,47 +1233,104 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int total = *work_n;
-  int nfound = 0, nkf = 0;
-  for (int w = wave; w < total; w += (gridDim.x * 256) >> 6) {
-    const int idx = work[w];
-    const float2 gq = nm.grad[idx];
-    const float gnq = nm.gnorm[idx];
-    const SearchSetup S = search_setup(p, nm.pos_img[idx], nm.rs[idx], gq, gnq, vel, Rvel, Rback, max_radius);
-    int found = -1;
-    for (int slot0 = 2 * kHeadSteps; slot0 < 2 * S.t_steps && found < 0; slot0 += 64) {
-      const int slot = slot0 + lane;
-      const int step = slot >> 1, i_idx = slot & 1;
-      float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
-      for (int j = 0; j < step; ++j) {
-        tp += 1.0f;
-        tn -= 1.0f;
-      }
-      const float t = i_idx ? tp : tn;
-      bool ok = (step < S.t_steps) && (i_idx ? !(t > S.dq_max) : !(t < S.dq_min));
-      int cand = -1;
-      if (ok) {
-        const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
-        const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
-        if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) cand = om.mask[(size_t)row * p.cols + col];
-      }
-      bool acc = false;
-      if (cand >= 0) {
-        const OldKl ck = load_old(om, cand, rot, R0, p.fm);
-        acc = search_accept(p, S, t, ck.g, ck.gn, ck.rs, gq, gnq);
-      }
-      const unsigned long long am = __ballot(acc);
-      if (am) found = __shfl(cand, __ffsll((long long)am) - 1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) nm.st->dm_queued = total;
+  int nfound = 0, nkf = 0;  // per lane: the lane that holds the accepted candidate commits it
+  const int wstride = (gridDim.x * 256) >> 6;
+
+  // software pipeline over this wave's queue entries: the next entry's keyline is loaded while the current one is searched
+  int idx = (wave < total) ? work[wave] : 0;
+  float2 gq = nm.grad[idx], piq = nm.pos_img[idx], rsq = nm.rs[idx];
+  float gnq = nm.gnorm[idx];
+  for (int w = wave; w < total; w += wstride) {
+    const int idx_cur = idx;
+    const float2 gq_cur = gq, piq_cur = piq, rsq_cur = rsq;
+    const float gnq_cur = gnq;
+    if (w + wstride < total) {
+      idx = work[w + wstride];
+      gq = nm.grad[idx];
+      piq = nm.pos_img[idx];
+      rsq = nm.rs[idx];
+      gnq = nm.gnorm[idx];
     }
-    if (found >= 0 && lane == 0) {
-      int kf = 0;
-      search_commit(nm, om, idx, found, load_old(om, found, rot, R0, p.fm), &kf);
-      nfound += 1;
-      nkf += kf;
+    const SearchSetup S = search_setup(p, piq_cur, rsq_cur, gq_cur, gnq_cur, vel, Rvel, Rback, max_radius);
+    bool done = false;
+    // two probe slots per lane and trip (slot, slot + 64): a search over the full +-42 range (what an unmatched keyline
+    // runs through) is ONE gather round trip instead of two; acceptance is still taken in slot order
+    for (int slot0 = 2 * kHeadSteps; slot0 < 2 * S.t_steps && !done; slot0 += 128) {
+      float tt[2];
+      int cand[2];
+      // t of this lane's two slots. The reference reaches step k by k repeated +1.0f / -1.0f (not dq_rho +- k: the
+      // roundings differ), so the sequence is walked ONCE, uniformly for the wave, and every lane picks its two elements
+      // (a per-lane loop to its own step count is the same arithmetic but diverges and costs ~3 us per entry).
+      const int stepA = (slot0 + lane) >> 1, stepB = stepA + 32;
+      const int odd = (slot0 + lane) & 1;  // both slots of a lane have the same parity
+      {
+        float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
+        float ta = 0.f, tb = 0.f;
+        const int jmax = min(S.t_steps - 1, (slot0 + 127) >> 1);
+        for (int j = 0; j <= jmax; ++j) {
+          const float cur = odd ? tp : tn;
+          ta = (j == stepA) ? cur : ta;
+          tb = (j == stepB) ? cur : tb;
+          tp += 1.0f;
+          tn -= 1.0f;
+        }
+        tt[0] = ta;
+        tt[1] = tb;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int step = h ? stepB : stepA;
+        const float t = tt[h];
+        const bool ok = (step < S.t_steps) && (odd ? !(t > S.dq_max) : !(t < S.dq_min));
+        int cd = -1;
+        if (ok) {
+          const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
+          const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
+          if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) cd = om.mask[(size_t)row * p.cols + col];
+        }
+        cand[h] = cd;
+      }
+      OldKl ck[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (cand[h] >= 0) ck[h] = load_old(om, cand[h], rot, R0, p.fm);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bool acc = false;
+        if (!done && cand[h] >= 0) acc = search_accept(p, S, tt[h], ck[h].g, ck[h].gn, ck[h].rs, gq_cur, gnq_cur);
+        const unsigned long long am = __ballot(acc);
+        if (!done && am) {
+          done = true;
+          if (lane == __ffsll((long long)am) - 1) {  // first accepted slot in reference order: this lane owns the match
+            int kf = 0;
+            search_commit(nm, om, idx_cur, cand[h], ck[h], &kf);
+            nfound += 1;
+            nkf += kf;
+          }
+        }
+      }
     }
   }
+  // match counters: wave -> workgroup (LDS) -> one global atomic per workgroup. A global atomic per wave meant ~2.4k
+  // same-address device-scope atomics per launch, which execute one after the other at the memory side and, not the
+  // searches, set the duration of this kernel.
+  __shared__ int blk_found, blk_kf;
+  if (threadIdx.x == 0) {
+    blk_found = 0;
+    blk_kf = 0;
+  }
+  __syncthreads();
+  nfound = wave_sum_i(nfound);
+  nkf = wave_sum_i(nkf);
   if (lane == 0) {
-    if (nfound) atomicAdd(&nm.st->dm_matches, nfound);
-    if (nkf) atomicAdd(&nm.st->dm_kf, nkf);
+    if (nfound) atomicAdd(&blk_found, nfound);
+    if (nkf) atomicAdd(&blk_kf, nkf);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (blk_found) atomicAdd(&nm.st->dm_matches, blk_found);
+    if (blk_kf) atomicAdd(&nm.st->dm_kf, blk_kf);
   }
 }
 
