@@ -564,9 +564,21 @@ __global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m) {
     gb = min(gb, (unsigned)__shfl_xor((int)gb, o));
     gB = max(gB, (unsigned)__shfl_xor((int)gB, o));
   }
+  // min / max of the gradient norm: wave -> workgroup (LDS) -> one global atomic pair per workgroup
+  __shared__ unsigned b_min, b_max;
+  if (threadIdx.x == 0) {
+    b_min = 0xFFFFFFFFu;
+    b_max = 0u;
+  }
+  __syncthreads();
   if ((threadIdx.x & 63) == 0 && gB != 0u) {
-    atomicMin(&m.st->gmin_bits, gb);
-    atomicMax(&m.st->gmax_bits, gB);
+    atomicMin(&b_min, gb);
+    atomicMax(&b_max, gB);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && b_max != 0u) {
+    atomicMin(&m.st->gmin_bits, b_min);
+    atomicMax(&m.st->gmax_bits, b_max);
   }
 }
 

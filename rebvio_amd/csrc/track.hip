@@ -1201,20 +1201,37 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
     if (found >= 0) search_commit(nm, om, idx, found, hit, &kf);
     more = (found < 0) && (S.t_steps > kHeadSteps);
   }
-  // queue the open long searches (order in the queue is irrelevant: each entry only touches its own keyline)
+  // queue the open long searches (order in the queue is irrelevant: each entry only touches its own keyline) and count
+  // the matches: ONE global atomic per workgroup and counter (same-address device-scope atomics execute one after the
+  // other at the memory side; per-wave atomics were a measurable part of this kernel)
+  __shared__ int w_more[4], w_base[4], b_found, b_kf;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned long long mm = __ballot(more);
-  if (mm) {
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(work_n, __popcll(mm));
-    base = __shfl(base, 0);
-    if (more) work[base + __popcll(mm & ((1ull << lane) - 1ull))] = idx;
-  }
   const int c1 = wave_sum_i(found >= 0 ? 1 : 0);
   const int c2 = wave_sum_i(kf);
-  if ((threadIdx.x & 63) == 0) {
-    if (c1) atomicAdd(&nm.st->dm_matches, c1);
-    if (c2) atomicAdd(&nm.st->dm_kf, c2);
+  if (threadIdx.x == 0) {
+    b_found = 0;
+    b_kf = 0;
+  }
+  if (lane == 0) w_more[wid] = __popcll(mm);
+  __syncthreads();
+  if (lane == 0) {
+    if (c1) atomicAdd(&b_found, c1);
+    if (c2) atomicAdd(&b_kf, c2);
+  }
+  if (threadIdx.x == 0) {
+    const int tot = w_more[0] + w_more[1] + w_more[2] + w_more[3];
+    int base = tot ? atomicAdd(work_n, tot) : 0;
+    for (int w = 0; w < 4; ++w) {
+      w_base[w] = base;
+      base += w_more[w];
+    }
+  }
+  __syncthreads();
+  if (more) work[w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull))] = idx;
+  if (threadIdx.x == 0) {
+    if (b_found) atomicAdd(&nm.st->dm_matches, b_found);
+    if (b_kf) atomicAdd(&nm.st->dm_kf, b_kf);
   }
 }
 
@@ -1510,10 +1527,15 @@ __global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec
     }
     m.rs_tmp[idx] = out;
   }
+  // regularised-keyline count: one global atomic per workgroup (see k_directed_match)
+  __shared__ int b_reg;
+  if (threadIdx.x == 0) b_reg = 0;
+  __syncthreads();
   const int c = wave_sum_i(set);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&m.st->reg_count, c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&b_reg, c);
+  __syncthreads();
+  if (threadIdx.x == 0 && b_reg) atomicAdd(&m.st->reg_count, b_reg);
   if (next_rot) {
-    __syncthreads();
     if ((int)threadIdx.x < hist_bins && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
   }
 }
