@@ -95,7 +95,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=1000,
+                    help="untimed frames; the stream needs ~1000 frames until depths / match queues reach their steady state")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--base-frames", type=int, default=24, help="distinct rendered frames (ping-pong replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
