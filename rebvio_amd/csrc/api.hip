@@ -264,9 +264,6 @@ struct rebvio_hip_ctx {
   // host-side phase timing of the streaming driver (printed by flush when REBVIO_HIP_DEBUG is set)
   double t_detect_enq = 0, t_wait = 0, t_glue = 0, t_b_enq = 0, t_a_enq = 0, t_queued = 0;
   bool dbg = false;
-  hipEvent_t dbg_ev[3]{};  // B start, B end / A start, A end
-  double dbg_b = 0, dbg_a = 0;
-  uint64_t dbg_n = 0;
   uint64_t t_frames = 0;
 };
 
@@ -828,8 +825,6 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   }
   rebvio_hip_reset_state(c);
   c->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
-  if (c->dbg)
-    for (auto& e : c->dbg_ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipDeviceSynchronize());
   *out = c;
   return 0;

@@ -751,7 +751,7 @@ __device__ __forceinline__ float xch_wait(const unsigned long long* w, unsigned 
         err[4] = (int)(unsigned)(v >> 32);
         err[5] = (int)(unsigned)v;
         err[6] = (int)gridDim.x;
-        err[7] = (int)(w - (const unsigned long long*)nullptr);
+        err[7] = (int)(reinterpret_cast<uintptr_t>(w) & 0x7FFFFFFFu);
       }
       break;
     }
