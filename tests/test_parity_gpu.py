@@ -472,3 +472,34 @@ def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
         assert np.abs(vo - vg).max() <= 1e-6 + 5e-2 * np.abs(vo).max(), (k, vo, vg)
         assert np.abs(wo - dw).max() <= 1e-4, (k, wo, dw)
         assert abs(int(ref["match_counts"][k]) - klm) <= 0.01 * ref["match_counts"][k] + 2
+
+
+def test_euroc_frame_size_with_lens_model(orc_mod, B):
+    """752x480 (the reference's built-in EuRoC camera, camera.hpp:25-45: a width that is not a multiple of the 32- and
+    64-pixel tiles) with its rad-tan lens model: front end + detection bit-exact, distance field exact, one pair step
+    within the usual tolerances."""
+    from rebvio_amd import synth
+    W, H = 752, 480
+    frames, cam = synth.render_stream(W, H, 3, dist=EUROC_D)
+    kw = dict(fm=457.975, cx=367.215, cy=248.375, keylines_ref=12000, keylines_max=16000)
+    orc = orc_mod.Oracle(orc_mod.default_params(H, W, **kw))
+    ctx = B.Context(B.default_params(H, W, **kw))
+    ctx.set_undistort(kw["fm"], kw["fm"], kw["cx"], kw["cy"], EUROC_D)
+    oms, gms = [], []
+    for i in range(3):
+        om = orc.detect(orc.front_end_u8(frames[i], kw["fm"], kw["fm"], kw["cx"], kw["cy"], EUROC_D), i * 50000)
+        gm = ctx.detect_u8_host(frames[i], i * 50000)
+        assert_keylines_equal(om.keylines(), gm.keylines(), what=f"752x480 frame {i}")
+        oms.append(om)
+        gms.append(gm)
+    orc.build_distance_field(oms[1])
+    ctx.build_distance_field(gms[1])
+    ido, dso = orc.distance_field()
+    idg, dsg = ctx.distance_field()
+    assert np.array_equal(ido, idg)
+    assert np.array_equal(dso[ido >= 0], dsg[idg >= 0])
+    po, pg = orc.track_pair(oms[0], oms[1]), ctx.track_pair(gms[0], gms[1])
+    assert po.status == pg.status == 0 and po.lm_accept_mask == pg.lm_accept_mask
+    vo, vg = np.array(po.Vg), np.array(pg.Vg)
+    assert np.abs(vo - vg).max() <= 1e-6 + 5e-2 * np.abs(vo).max(), (vo, vg)
+    assert abs(po.klm_num - pg.klm_num) <= 0.01 * po.klm_num + 2
