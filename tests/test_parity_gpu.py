@@ -503,3 +503,24 @@ def test_euroc_frame_size_with_lens_model(orc_mod, B):
     vo, vg = np.array(po.Vg), np.array(pg.Vg)
     assert np.abs(vo - vg).max() <= 1e-6 + 5e-2 * np.abs(vo).max(), (vo, vg)
     assert abs(po.klm_num - pg.klm_num) <= 0.01 * po.klm_num + 2
+
+
+@pytest.mark.parametrize("size", [(324, 250), (100, 37), (1028, 33)])
+def test_ragged_sizes_detect_and_distance_field(orc_mod, B, size):
+    """Widths / heights that are multiples of none of the tile sizes (4-row strips, 16-column strips, 64x4 keyline tiles,
+    32x32 distance-field tiles): detection bit-exact, distance field exact."""
+    from rebvio_amd import synth
+    W, H = size
+    frames, cam = synth.render_stream(W, H, 2)
+    kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=3000, keylines_max=4000)
+    orc = orc_mod.Oracle(orc_mod.default_params(H, W, **kw))
+    ctx = B.Context(B.default_params(H, W, **kw))
+    for i in range(2):
+        om, gm = orc.detect_u8(frames[i], i * 50000), ctx.detect_u8(frames[i], i * 50000)
+        assert_keylines_equal(om.keylines(), gm.keylines(), what=f"{W}x{H} frame {i}")
+    orc.build_distance_field(om)
+    ctx.build_distance_field(gm)
+    ido, dso = orc.distance_field()
+    idg, dsg = ctx.distance_field()
+    assert np.array_equal(ido, idg)
+    assert np.array_equal(dso[ido >= 0], dsg[idg >= 0])
