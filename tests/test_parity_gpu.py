@@ -524,3 +524,40 @@ def test_ragged_sizes_detect_and_distance_field(orc_mod, B, size):
     idg, dsg = ctx.distance_field()
     assert np.array_equal(ido, idg)
     assert np.array_equal(dso[ido >= 0], dsg[idg >= 0])
+
+
+def test_pair_step_failure_paths(orc_mod, B, small_stream):
+    """rebvio.cpp:236-252: a pair whose directedMatch finds fewer than global_min_matches_threshold keylines ends with
+    status 2 and no regularisation / depth update (the device gates both kernels on the counter), on the oracle and on
+    the device alike; the streaming driver reports the same status and keeps running."""
+    from rebvio_amd import synth
+    frames, cam = small_stream
+    other, _ = synth.render_stream(cam.width, cam.height, 1, stream_id=7)   # an unrelated scene
+    kw = dict(keylines_ref=1500, keylines_max=2500, global_min_matches_threshold=900)
+    orc = orc_mod.Oracle(params_for(orc_mod, cam, **kw))
+    ctx = B.Context(params_for(B, cam, **kw))
+    o0, g0 = orc.detect_u8(frames[0], 0), ctx.detect_u8(frames[0], 0)
+    o1, g1 = orc.detect_u8(other[0], 50000), ctx.detect_u8(other[0], 50000)
+    assert_keylines_equal(o1.keylines(), g1.keylines())
+    po, pg = orc.track_pair(o0, o1), ctx.track_pair(g0, g1)
+    assert po.status == 2 and pg.status == 2
+    assert po.reg_num == 0 and pg.reg_num == 0
+    assert abs(po.klm_num - pg.klm_num) <= 0.05 * max(po.klm_num, 1) + 5
+    ko, kg = o1.keylines(), g1.keylines()
+    unmatched = (ko["match_id"] < 0) & (kg["match_id"] < 0)
+    assert unmatched.sum() > 100
+    # no depth update happened: unmatched keylines still carry the initial depth state on both sides
+    assert (ko["rho"][unmatched] == 1.0).all() and (kg["rho"][unmatched] == 1.0).all()
+    assert (ko["sigma_rho"][unmatched] == 20.0).all() and (kg["sigma_rho"][unmatched] == 20.0).all()
+    # streaming driver: the bad pair is reported with status 2, the following pairs are tracked again
+    ctx2 = B.Context(params_for(B, cam, **kw))
+    seq = np.concatenate([frames[:3], other, frames[3:8]])
+    dev = ctx2.upload_frames(seq)
+    npx = cam.width * cam.height
+    st = []
+    for k in range(len(seq)):
+        out, n = ctx2.push_frame_u8_device(dev + k * npx, k * 50000)
+        if out.status >= 0:
+            st.append(out.status)
+    ctx2.flush()
+    assert 2 in st and st[0] == 0
