@@ -561,3 +561,22 @@ def test_pair_step_failure_paths(orc_mod, B, small_stream):
             st.append(out.status)
     ctx2.flush()
     assert 2 in st and st[0] == 0
+
+
+def test_pair_step_nan_path(orc_mod, B, small_stream):
+    """rebvio.cpp:236-241: a NaN velocity (here forced through NaN inverse depths in the old map) ends the pair with
+    status 1 before directedMatch; the new map keeps its detection state."""
+    frames, cam = small_stream
+    kw = dict(keylines_ref=1500, keylines_max=2500, global_min_matches_threshold=100)
+    orc = orc_mod.Oracle(params_for(orc_mod, cam, **kw))
+    ctx = B.Context(params_for(B, cam, **kw))
+    o0, g0 = orc.detect_u8(frames[0], 0), ctx.detect_u8(frames[0], 0)
+    o1, g1 = orc.detect_u8(frames[1], 50000), ctx.detect_u8(frames[1], 50000)
+    k0 = o0.keylines().copy()
+    k0["rho"][:] = np.nan
+    o0.set_keylines(k0)
+    g0.upload(k0)
+    po, pg = orc.track_pair(o0, o1), ctx.track_pair(g0, g1)
+    assert po.status == 1 and pg.status == 1
+    assert po.klm_num == 0 and pg.klm_num == 0
+    assert (g1.keylines()["match_id"] < 0).all() and (o1.keylines()["match_id"] < 0).all()
