@@ -93,7 +93,9 @@ void rebvio_hip_default_params(rebvio_hip_params* p, int rows, int cols);
 
 /* Replaces the constructors EdgeDetector(camera, config) (edge_detector.cpp:17-26), ScaleSpace /
  * FastGaussian (scale_space.cpp:14-41,184-190), Core(camera, config) + DistanceField (core.cpp:17-24,
- * core.hpp:22-28): allocates every device buffer once. */
+ * core.hpp:22-28): allocates every device buffer once.
+ * Sensor sizes: rows, cols >= 32 and cols a multiple of 4 (the row / column scans move 16-byte vectors); -3 otherwise.
+ * Every sensor the reference ships a camera for satisfies this (752x480, camera.hpp:25-45). */
 int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out);
 void rebvio_hip_destroy(rebvio_hip_ctx* ctx);
 
