@@ -75,6 +75,7 @@ def lib(path: str | None = None):
         "orc_default_params": (None, [C.POINTER(Params), C.c_int, C.c_int]),
         "orc_create": (vp, [C.POINTER(Params)]),
         "orc_destroy": (None, [vp]),
+        "orc_set_wide_sums": (None, [vp, C.c_int]),
         "orc_scale_space": (None, [vp, fp, fp, fp, fp, fp]),
         "orc_integral_image": (None, [C.c_int, C.c_int, fp, fp]),
         "orc_box_average": (None, [C.c_int, C.c_int, C.c_int, fp, fp]),
@@ -188,6 +189,10 @@ class Oracle:
         if getattr(self, "h", None):
             self.L.orc_destroy(self.h)
             self.h = None
+
+    def set_wide_sums(self, on: bool):
+        """DIAGNOSTIC, not the reference: accumulate the keyline sums of tryVel / extRotVel in double."""
+        self.L.orc_set_wide_sums(self.h, int(bool(on)))
 
     # --- detection -------------------------------------------------------------------------
     def scale_space(self, img):

@@ -799,6 +799,9 @@ struct orc_ctx {
   std::vector<int> df_id, df_dist;
   orc_map* df_map = nullptr;
   unsigned frame_count = 0;
+  // DIAGNOSTIC, not the reference: 1 = the keyline sums of tryVel / extRotVel are accumulated in double (terms still
+  // fp32). Used by tools/tolerance_probe.py to measure how much of the reference's own result is summation rounding.
+  int wide_sums = 0;
   // glue state (imu.hpp:171-187)
   float Bg[3];
   M3 W_Bg, RGBias, RGyro;
@@ -1128,13 +1131,25 @@ int search_match(const orc_ctx* c, const orc_map* old_map, const orc_keyline& kq
   return -1;
 }
 
+// fp32 running sum in index order, as the reference adds (wide = 0); see orc_ctx::wide_sums for the diagnostic mode.
+struct Acc {
+  float f = 0.0f;
+  double d = 0.0;
+  bool wide = false;
+  inline void add(float x) {
+    if (wide) d += (double)x;
+    else f += x;
+  }
+  inline float get() const { return wide ? (float)d : f; }
+};
+
 // Core::tryVel + calculatefJ + testfk (core.cpp:39-148)
 float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float vel[3], float sigma_rho_min,
               float* residuals) {
   const orc_params& P = c->p;
   const orc_map* nm = c->df_map;
-  float score = 0.0;
-  float J00 = 0, J11 = 0, J22 = 0, J01 = 0, J02 = 0, J12 = 0, F0 = 0, F1 = 0, F2 = 0;
+  Acc score, J00, J11, J22, J01, J02, J12, F0, F1, F2;
+  for (Acc* a : {&score, &J00, &J11, &J22, &J01, &J02, &J12, &F0, &F1, &F2}) a->wide = c->wide_sums != 0;
   float fi = 0.0f;  // reference leaves this uninitialised: carry-forward semantics (header note)
   const unsigned min_matches = std::min(P.min_match_threshold, c->frame_count);
   for (int idx = 0; idx < (int)map->kl.size(); ++idx) {
@@ -1150,7 +1165,7 @@ float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float 
     float f;
     if (z_p <= 0.0) {
       f = (1.0 / k.sigma_rho) * P.search_range * weight;
-      score += f * f;
+      score.add(f * f);
       continue;
     }
     float rho_p = 1.0 / z_p;
@@ -1162,7 +1177,7 @@ float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float 
     int y = cvtt(p_yc + 0.5);
     if (x < 1 || y < 1 || (unsigned)x >= (unsigned)P.cols - 1 || (unsigned)y >= (unsigned)P.rows - 1) {
       f = (1.0 / k.sigma_rho) * P.search_range * weight;
-      score += f * f;
+      score.add(f * f);
       continue;
     }
     float df_dx, df_dy;
@@ -1194,20 +1209,20 @@ float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float 
       }
     }
     f *= weight;
-    score += f * f;
+    score.add(f * f);
     float jx = rho_p * P.fm * df_dx * weight;
     float jy = rho_p * P.fm * df_dy * weight;
     float jz = -rho_p * (p_x * df_dx + p_y * df_dy) * weight;
-    J00 += jx * jx; J11 += jy * jy; J22 += jz * jz;
-    J01 += jx * jy; J02 += jx * jz; J12 += jy * jz;
-    F0 += jx * f; F1 += jy * f; F2 += jz * f;
+    J00.add(jx * jx); J11.add(jy * jy); J22.add(jz * jz);
+    J01.add(jx * jy); J02.add(jx * jz); J12.add(jy * jz);
+    F0.add(jx * f); F1.add(jy * f); F2.add(jz * f);
     residuals[idx] = std::fabs(fi);
   }
-  JtJ[0] = J00; JtJ[1] = J01; JtJ[2] = J02;
-  JtJ[3] = J01; JtJ[4] = J11; JtJ[5] = J12;
-  JtJ[6] = J02; JtJ[7] = J12; JtJ[8] = J22;
-  JtF[0] = F0; JtF[1] = F1; JtF[2] = F2;
-  return score;
+  JtJ[0] = J00.get(); JtJ[1] = J01.get(); JtJ[2] = J02.get();
+  JtJ[3] = J01.get(); JtJ[4] = J11.get(); JtJ[5] = J12.get();
+  JtJ[6] = J02.get(); JtJ[7] = J12.get(); JtJ[8] = J22.get();
+  JtF[0] = F0.get(); JtF[1] = F1.get(); JtF[2] = F2.get();
+  return score.get();
 }
 
 float estimate_quantile(const orc_map* m, float percentile, int num_bins) {
@@ -1305,8 +1320,11 @@ int forward_match(orc_map* old_map, orc_map* new_map) {
 int ext_rot_vel(orc_ctx* c, const float vel[3], float Wx[36], float X[6], float JtF_out[6]) {
   const orc_params& P = c->p;
   const orc_map* m = c->df_map;
-  float JtJ[6][6] = {{0}};
-  float JtF[6] = {0};
+  Acc JtJ[6][6], JtF[6];
+  for (int i = 0; i < 6; ++i) {
+    JtF[i].wide = c->wide_sums != 0;
+    for (int j = 0; j < 6; ++j) JtJ[i][j].wide = c->wide_sums != 0;
+  }
   for (int idx = 0; idx < (int)m->kl.size(); ++idx) {
     const orc_keyline& k = m->kl[idx];
     if (k.match_id < 0) continue;
@@ -1333,15 +1351,18 @@ int ext_rot_vel(orc_ctx* c, const float vel[3], float Wx[36], float X[6], float 
     for (int i = 0; i < 6; ++i) row[i] /= dv;
     Y /= dv;
     for (int i = 0; i < 6; ++i) {
-      for (int j = 0; j < 6; ++j) JtJ[i][j] += row[i] * row[j];
-      JtF[i] += row[i] * Y;
+      for (int j = 0; j < 6; ++j) JtJ[i][j].add(row[i] * row[j]);
+      JtF[i].add(row[i] * Y);
     }
   }
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) Wx[i * 6 + j] = JtJ[i][j];
+  float JtF_f[6];
+  for (int i = 0; i < 6; ++i) {
+    JtF_f[i] = JtF[i].get();
+    for (int j = 0; j < 6; ++j) Wx[i * 6 + j] = JtJ[i][j].get();
+  }
   if (JtF_out)
-    for (int i = 0; i < 6; ++i) JtF_out[i] = JtF[i];
-  sym_pinv_solve<6>(Wx, JtF, X);
+    for (int i = 0; i < 6; ++i) JtF_out[i] = JtF_f[i];
+  sym_pinv_solve<6>(Wx, JtF_f, X);
   for (int i = 0; i < 6; ++i)
     if (std::isnan(X[i])) return 0;
   return 1;
@@ -1635,6 +1656,8 @@ void orc_rotate_keylines(orc_ctx* c, orc_map* m, const float R_[9]) {
 }
 
 float orc_estimate_quantile(orc_map* m, float percentile, int num_bins) { return estimate_quantile(m, percentile, num_bins); }
+
+void orc_set_wide_sums(orc_ctx* c, int on) { c->wide_sums = on; }
 
 float orc_try_vel(orc_ctx* c, orc_map* m, const float vel[3], float sigma_rho_min, float* residuals, float JtJ[9],
                   float JtF[3]) {

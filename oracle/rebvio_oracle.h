@@ -84,6 +84,8 @@ typedef struct orc_pair_out {
 
 void orc_default_params(orc_params* p, int rows, int cols);
 orc_ctx* orc_create(const orc_params* p);
+/* DIAGNOSTIC (not the reference): accumulate the keyline sums of tryVel / extRotVel in double; default 0 = fp32 in index order. */
+void orc_set_wide_sums(orc_ctx* c, int on);
 void orc_destroy(orc_ctx* c);
 
 /* scale space on an fp32 image (values 0..765), outputs are rows*cols floats (any may be NULL) */

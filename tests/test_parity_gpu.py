@@ -319,6 +319,44 @@ def test_track_pair_sequence(orc_mod, B, c2_stream):
         assert np.median(rel) < 1e-3
 
 
+def test_pose_deviation_is_the_references_own_rounding_noise(orc_mod, B, c2_stream):
+    """Why the pose tolerance above is 5 %: the pose of a pair is a 6-step LM on sums over ~15k keylines, and early in a
+    stream (all depths at their initial value) it is sensitive to the LAST BITS of those sums. Measured here: the oracle with
+    the same fp32 terms accumulated in double (diagnostic mode, not the reference) against (a) the sequential-fp32 oracle and
+    (b) the GPU's fixed-tree fp32 sums, states carried independently over the stream. The GPU must be no further from the
+    wide-sum result than the reference's own order of summation is - and within 5e-3 of it."""
+    frames, cam = c2_stream
+    kw = dict(KW_C2)
+    seq = orc_mod.Oracle(params_for(orc_mod, cam, **kw))
+    wide = orc_mod.Oracle(params_for(orc_mod, cam, **kw))
+    wide.set_wide_sums(True)
+    gpu = B.Context(params_for(B, cam, **kw))
+    ms, mw, mg = [], [], []
+    d_seq = d_gpu = 0.0
+    agree_seq = agree_gpu = 1.0
+    for i in range(len(frames)):
+        ms.append(seq.detect_u8(frames[i], i * 50000))
+        mw.append(wide.detect_u8(frames[i], i * 50000))
+        mg.append(gpu.detect_u8(frames[i], i * 50000))
+        if len(ms) > 2:
+            ms.pop(0)
+            mw.pop(0)
+            mg.pop(0).release()
+        if i == 0:
+            continue
+        vs = np.array(seq.track_pair(ms[0], ms[1]).Vg)
+        vw = np.array(wide.track_pair(mw[0], mw[1]).Vg)
+        vg = np.array(gpu.track_pair(mg[0], mg[1]).Vg)
+        d_seq = max(d_seq, float(np.abs(vs - vw).max() / np.abs(vw).max()))
+        d_gpu = max(d_gpu, float(np.abs(vg - vw).max() / np.abs(vw).max()))
+        kw_, ks_, kg_ = mw[1].keylines(), ms[1].keylines(), mg[1].keylines()
+        agree_seq = min(agree_seq, float((ks_["match_id"] == kw_["match_id"]).mean()))
+        agree_gpu = min(agree_gpu, float((kg_["match_id"] == kw_["match_id"]).mean()))
+    assert d_gpu <= 5e-3, (d_gpu, d_seq)
+    assert d_gpu <= max(d_seq, 1e-3), (d_gpu, d_seq)
+    assert agree_gpu >= min(agree_seq, 0.995), (agree_gpu, agree_seq)
+
+
 def test_full_size_properties(B):
     """1280x960 (~60k keylines): properties that need no oracle pass over the image at this size are cheap
     to state - here the oracle still finishes in well under a second per frame, so compare directly, plus
