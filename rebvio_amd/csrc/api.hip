@@ -675,6 +675,12 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipSetDevice(p->device_id));
 
   rebvio_hip_ctx* c = new rebvio_hip_ctx;
+  struct Guard {  // every early return below (HIPCHK, fail_msg) frees what was allocated so far
+    rebvio_hip_ctx* c;
+    ~Guard() {
+      if (c) rebvio_hip_destroy(c);
+    }
+  } guard{c};
   c->P = *p;
   c->device = p->device_id;
   KParams& K = c->K;
@@ -698,10 +704,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   hm::kovesi_widths(st0 * 1.2599, 3, c->widths[1], &st1);
   for (int f = 0; f < 2; ++f)
     for (int k = 0; k < 3; ++k)
-      if (c->widths[f][k] < 3 || c->widths[f][k] > 11) {
-        delete c;
-        return fail_msg("unexpected box width", -5);
-      }
+      if (c->widths[f][k] < 3 || c->widths[f][k] > 11) return fail_msg("unexpected box width", -5);
   float recip[128], pinv[75];
   recip[0] = 0.f;
   for (int n = 1; n < 128; ++n) recip[n] = (float)(1.0 / (double)(float)n);
@@ -826,6 +829,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   rebvio_hip_reset_state(c);
   c->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
   HIPCHK(hipDeviceSynchronize());
+  guard.c = nullptr;
   *out = c;
   return 0;
 }
@@ -855,10 +859,10 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   void* hptr[] = {c->h_lm, c->h_part, c->h_xrv, c->h_st, c->h_f};
   for (void* p : hptr)
     if (p) (void)hipHostFree(p);
-  (void)hipStreamDestroy(c->s_det);
-  (void)hipStreamDestroy(c->s_trk);
-  if (c->s_df != c->s_key) (void)hipStreamDestroy(c->s_df);
-  (void)hipStreamDestroy(c->s_key);
+  if (c->s_det) (void)hipStreamDestroy(c->s_det);
+  if (c->s_trk) (void)hipStreamDestroy(c->s_trk);
+  if (c->s_df && c->s_df != c->s_key) (void)hipStreamDestroy(c->s_df);
+  if (c->s_key) (void)hipStreamDestroy(c->s_key);
   for (int i = 0; i < 2; ++i) {
     if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
     if (c->ev_flag[i]) (void)hipEventDestroy(c->ev_flag[i]);
@@ -1581,7 +1585,10 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   HIPCHK(hipSetDevice(c->device));
   int rc = detect_async(c, frame_dev, 1, ts_us, &m);
   if (rc) return rc;
-  if (!c->det_error.empty()) return fail_msg(c->det_error.c_str(), -8);
+  {
+    std::lock_guard<std::mutex> lk(c->det_mu);  // written by the detect worker
+    if (!c->det_error.empty()) return fail_msg(c->det_error.c_str(), -8);
+  }
   c->t_detect_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td0).count();
   c->t_frames++;
   c->frames.push_back(m);
