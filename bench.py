@@ -121,6 +121,11 @@ def main():
     # both on RCCL instead.
     backend_name = os.environ.get("REBVIO_BENCH_BACKEND", "gloo")
     torch.cuda.set_device(dev_index)
+    numa_node = -1
+    if os.environ.get("REBVIO_BENCH_NUMA", "1") != "0":  # before any thread or pinned buffer of the pipeline exists
+        pr = torch.cuda.get_device_properties(dev_index)
+        if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            numa_node = shard.bind_to_gpu_numa_node(f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0")
     shard.init_group(backend_name, rank, world, torch.device("cuda", dev_index))  # barrier + max-time only
     local_rank = dev_index
 
@@ -231,7 +236,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["name"], "streams": world, "keylines": n_keylines,
                        "mean_matches": float(np.mean([m for m in matches if m > 0])) if any(m > 0 for m in matches) else 0.0,
-                       "frames_in_hbm": args.base_frames, "parallelism": f"{world} independent streams, 1 per GPU"},
+                       "frames_in_hbm": args.base_frames, "parallelism": f"{world} independent streams, 1 per GPU",
+                       "rank0_numa_node": numa_node},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dominant),
                          "avg_launch_us": dom_us, "launches": dom[1], "algorithmic_bytes_per_launch": ab,

@@ -15,6 +15,38 @@ def stream_id_for_rank(rank: int) -> int:
     return rank
 
 
+def _parse_cpulist(text: str) -> set:
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa_node(pci_bus_id: str, sysfs: str = "/sys") -> int:
+    """Pins the calling thread (and every thread it creates afterwards: the detect worker, the pinned staging buffers'
+    first touch) to the CPUs of the NUMA node the GPU hangs off, so that on a two-socket 8-GPU node no rank polls or fills
+    its pinned glue slots across the socket link. pci_bus_id as "0000:c1:00.0". Returns the node, or -1 when nothing was
+    changed (single-node host, node unknown, or none of its CPUs are in this process's allowed set)."""
+    try:
+        with open(f"{sysfs}/bus/pci/devices/{pci_bus_id.lower()}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return -1
+        with open(f"{sysfs}/devices/system/node/node{node}/cpulist") as f:
+            cpus = _parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0)
+        target = cpus & allowed
+        if len(target) < 2 or target == allowed:
+            return -1 if len(target) < 2 else node
+        os.sched_setaffinity(0, target)
+        return node
+    except (OSError, ValueError):
+        return -1
+
+
 def init_group(backend: str, rank: int, world: int, device=None):
     import torch.distributed as dist
     if world <= 1:

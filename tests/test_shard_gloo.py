@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 
@@ -56,3 +57,30 @@ def test_two_ranks_independent_streams():
     assert n0 > 0 and n1 > 0
     assert t0 == t1 == 2.0                   # max over ranks
     assert f0 == f1 == 2 * 100 / 2.0         # whole-job frames / slowest rank
+
+
+def test_numa_binding_helper(tmp_path):
+    """bind_to_gpu_numa_node against a fake sysfs tree: binds to the node's CPUs that this process may use, and leaves
+    the affinity alone when the node is unknown or lists none of them."""
+    import os
+    from rebvio_amd import shard
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 3:
+        pytest.skip("needs at least 3 usable CPUs")
+    dev = tmp_path / "bus/pci/devices/0000:c1:00.0"
+    dev.mkdir(parents=True)
+    node = tmp_path / "devices/system/node/node1"
+    node.mkdir(parents=True)
+    try:
+        (dev / "numa_node").write_text("-1\n")
+        assert shard.bind_to_gpu_numa_node("0000:C1:00.0", str(tmp_path)) == -1
+        (dev / "numa_node").write_text("1\n")
+        (node / "cpulist").write_text("100000-100003\n")  # nothing this process may run on
+        assert shard.bind_to_gpu_numa_node("0000:c1:00.0", str(tmp_path)) == -1
+        assert sorted(os.sched_getaffinity(0)) == allowed
+        (node / "cpulist").write_text(f"{allowed[0]}-{allowed[0]},{allowed[1]},100000\n")
+        assert shard.bind_to_gpu_numa_node("0000:c1:00.0", str(tmp_path)) == 1
+        assert sorted(os.sched_getaffinity(0)) == allowed[:2]
+        assert shard.bind_to_gpu_numa_node("0000:ff:00.0", str(tmp_path)) == -1  # unknown device
+    finally:
+        os.sched_setaffinity(0, allowed)
