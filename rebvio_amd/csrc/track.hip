@@ -10,6 +10,8 @@
 // no dense contraction exists on this path (largest product is 6x6), so MFMA does not apply.
 #include "common.hpp"
 
+#include <cstring>
+
 namespace rh {
 
 constexpr float kRhoMax = 20.0f;   // types/keyline.hpp:17
@@ -1235,6 +1237,95 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
   }
 }
 
+// Pass 1, wide form: EIGHT lanes per keyline of the NEW map, one per probe slot of the head (2 * kHeadSteps == 8). The
+// per-thread form above executes ~2900 instructions per wave (eight unrolled candidate fetches, each with the on-the-fly
+// rotation: six IEEE divisions and a double-precision 3x3 product) on 60 workgroups: it is bound by instruction latency
+// with one wave per SIMD, while 3/4 of the chip idles. Here every lane evaluates the (bit-identical) probe geometry of its
+// keyline, then ONE probe and at most ONE candidate; the first accepted slot in the reference's order is found with a
+// ballot over the eight lanes and that lane, which holds the rotated candidate, commits it. Same arithmetic per probe,
+// hence the same bits; ~1/6 of the instructions per wave on eight times the waves.
+__global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
+                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
+                                                         GlueDev* __restrict__ gd_copy) {
+  static_assert(kHeadSteps == 4, "eight probe slots per keyline");
+  if (gd && gd_copy && blockIdx.x == 0) {  // device copy for the kernels queued behind this one
+    constexpr int kWords = (int)(sizeof(GlueDev) / sizeof(int));
+    if ((int)threadIdx.x < kWords) reinterpret_cast<int*>(gd_copy)[threadIdx.x] = reinterpret_cast<const int*>(gd)[threadIdx.x];
+  }
+  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
+  if (A.skip) return;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int idx = gid >> 3, slot = gid & 7;  // keyline, probe slot (slot = 2 * step + side; side 0: tn, 1: tp)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float2 pi = nm.pos_img[idx];  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024)
+  const float2 rsq = nm.rs[idx];
+  const float2 gq = nm.grad[idx];
+  const float gnq = nm.gnorm[idx];
+  const int n = nm.st->n;
+  bool acc = false, more = false;
+  int cand = -1;
+  OldKl ck{};
+  if (idx < n) {
+    const SearchSetup S = search_setup(p, pi, rsq, gq, gnq, A.vel, A.Rvel, A.Rback, max_radius);
+    // t of this slot: the reference reaches step j by j repeated +1.0f / -1.0f (not dq_rho +- j: the roundings differ)
+    const int step = slot >> 1, side = slot & 1;
+    float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
+    for (int j = 0; j < step; ++j) {
+      tp += 1.0f;
+      tn -= 1.0f;
+    }
+    const float t = side ? tp : tn;
+    const bool ok = (step < S.t_steps) && (side ? !(t > S.dq_max) : !(t < S.dq_min));
+    if (ok) {
+      const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
+      const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
+      if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) cand = om.mask[row * p.cols + col];
+    }
+    if (cand >= 0) {
+      ck = load_old(om, cand, A.rot, A.R0, p.fm);
+      acc = search_accept(p, S, t, ck.g, ck.gn, ck.rs, gq, gnq);
+    }
+    more = (slot == 0) && (S.t_steps > kHeadSteps);  // provisional: cleared below when one of the eight slots accepted
+  }
+  // first accepted slot of each keyline, in slot order
+  const unsigned long long am = __ballot(acc);
+  const unsigned grp = (unsigned)((am >> (lane & 56)) & 0xFFull);  // the eight lanes of this keyline
+  const bool winner = acc && ((grp & ((1u << slot) - 1u)) == 0u);
+  int kf = 0;
+  if (winner) search_commit(nm, om, idx, cand, ck, &kf);
+  more = more && (grp == 0u);
+  // queue + counters: wave -> workgroup (LDS) -> one global atomic per workgroup (see k_directed_match)
+  __shared__ int w_more[4], w_base[4], b_found, b_kf;
+  const unsigned long long mm = __ballot(more);
+  const int c1 = __popcll(__ballot(winner));
+  const int c2 = __popcll(__ballot(kf != 0));
+  if (threadIdx.x == 0) {
+    b_found = 0;
+    b_kf = 0;
+  }
+  if (lane == 0) w_more[wid] = __popcll(mm);
+  __syncthreads();
+  if (lane == 0) {
+    if (c1) atomicAdd(&b_found, c1);
+    if (c2) atomicAdd(&b_kf, c2);
+  }
+  if (threadIdx.x == 0) {
+    const int tot = w_more[0] + w_more[1] + w_more[2] + w_more[3];
+    int base = tot ? atomicAdd(work_n, tot) : 0;
+    for (int w = 0; w < 4; ++w) {
+      w_base[w] = base;
+      base += w_more[w];
+    }
+  }
+  __syncthreads();
+  if (more) work[w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull))] = idx;
+  if (threadIdx.x == 0) {
+    if (b_found) atomicAdd(&nm.st->dm_matches, b_found);
+    if (b_kf) atomicAdd(&nm.st->dm_kf, b_kf);
+  }
+}
+
 // Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
 // sequence; the first accepted slot in that order (lowest slot index) is the match, found with a ballot.
 // tn/tp are produced by the same repeated -1.0f / +1.0f steps as the sequential loop (not dq_rho -/+ k).
@@ -1614,6 +1705,15 @@ static int dm_tail_blocks() {
   return v;
 }
 
+// REBVIO_HIP_DM_HEAD=thread: one thread per keyline (k_directed_match); default: eight lanes per keyline
+static bool dm_head_wide() {
+  static const bool wide = [] {
+    const char* e = std::getenv("REBVIO_HIP_DM_HEAD");
+    return !(e && std::strcmp(e, "thread") == 0);
+  }();
+  return wide;
+}
+
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
                            const float* R0_on_the_fly) {
@@ -1621,8 +1721,12 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
   const int rot = R0_on_the_fly ? 1 : 0;
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
-  RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
-                     mat3(Rback), max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
+  if (dm_head_wide())
+    RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback),
+              max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
+  else
+    RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
+                       mat3(Rback), max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks()), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
             (const int*)work, (const int*)work_n, rot, R0, (const GlueDev*)nullptr);
 }
@@ -1630,8 +1734,12 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
 void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* g_pinned,
                                GlueDev* g_dev, float max_radius, int* work, int* work_n) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-  RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, work,
-            work_n, 1, mat3(I), g_pinned, g_dev);
+  if (dm_head_wide())
+    RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
+              work, work_n, 1, mat3(I), g_pinned, g_dev);
+  else
+    RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, work,
+              work_n, 1, mat3(I), g_pinned, g_dev);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks()), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
             (const int*)work, (const int*)work_n, 1, mat3(I), (const GlueDev*)g_dev);
 }
