@@ -1253,16 +1253,18 @@ __global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, M
     constexpr int kWords = (int)(sizeof(GlueDev) / sizeof(int));
     if ((int)threadIdx.x < kWords) reinterpret_cast<int*>(gd_copy)[threadIdx.x] = reinterpret_cast<const int*>(gd)[threadIdx.x];
   }
-  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
-  if (A.skip) return;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int idx = gid >> 3, slot = gid & 7;  // keyline, probe slot (slot = 2 * step + side; side 0: tn, 1: tp)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const float2 pi = nm.pos_img[idx];  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024)
+  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024), issued before the parameter block is
+  // read: with gd that is a round trip to pinned host memory (~1.7 us), the longest single wait of this kernel
+  const float2 pi = nm.pos_img[idx];
   const float2 rsq = nm.rs[idx];
   const float2 gq = nm.grad[idx];
   const float gnq = nm.gnorm[idx];
   const int n = nm.st->n;
+  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
+  if (A.skip) return;
   bool acc = false, more = false;
   int cand = -1;
   OldKl ck{};
