@@ -1335,20 +1335,23 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
                                                              float max_radius, const int* __restrict__ work,
                                                              const int* __restrict__ work_n, int rot_, Mat3 R0_,
                                                              const GlueDev* __restrict__ gd) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  // queue length, this wave's first entry (speculative: the queue array has kmax entries) and the parameter block are three
+  // independent loads: one round trip instead of three dependent ones
+  const int total = *work_n;
+  const int idx_first = work[min(wave, p.kmax - 1)];
   const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
   if (A.skip) return;
   const Vec3& vel = A.vel;
   const Mat3 &Rvel = A.Rvel, &Rback = A.Rback, &R0 = A.R0;
   const int rot = A.rot;
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  const int total = *work_n;
   if (blockIdx.x == 0 && threadIdx.x == 0) nm.st->dm_queued = total;
   int nfound = 0, nkf = 0;  // per lane: the lane that holds the accepted candidate commits it
   const int wstride = (gridDim.x * 256) >> 6;
 
   // software pipeline over this wave's queue entries: the next entry's keyline is loaded while the current one is searched
-  int idx = (wave < total) ? work[wave] : 0;
+  int idx = (wave < total) ? idx_first : 0;
   float2 gq = nm.grad[idx], piq = nm.pos_img[idx], rsq = nm.rs[idx];
   float gnq = nm.gnorm[idx];
   for (int w = wave; w < total; w += wstride) {
@@ -1529,6 +1532,19 @@ __global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel
 __global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
                                                         int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
                                                         int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
+  __shared__ int sh[128];
+  if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float2 rs = m.rs[idx];  // bound-free early loads, issued before the parameter block is read
+  const int in = m.id_next[idx], ip = m.id_prev[idx];
+  const int mid = m.match_id[idx];
+  float2 q = m.pos_img[idx];
+  const float2 q0 = m.mpos_img[idx];
+  const float2 mg = m.mgrad[idx];
+  const float mgn = m.mgnorm[idx];
+  float2 g = m.grad[idx];
+  const int n = m.st->n;
+  const int dm_matches = m.st->dm_matches;
   Vec3 vel = vel_;
   Mat3 Rnext = Rnext_;
   int next_rot = next_rot_;
@@ -1541,19 +1557,14 @@ __global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec
     next_rot = gd->has_next;
     skip_pair = gd->nan_v != 0;
   }
-  __shared__ int sh[128];
-  if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const float2 rs = m.rs[idx];  // bound-free early loads
-  const int in = m.id_next[idx], ip = m.id_prev[idx];
-  const int mid = m.match_id[idx];
-  float2 q = m.pos_img[idx];
-  const float2 q0 = m.mpos_img[idx];
-  const float2 mg = m.mgrad[idx];
-  const float mgn = m.mgnorm[idx];
-  float2 g = m.grad[idx];
-  const int n = m.st->n;
-  const bool gated = skip_pair || (gate_min_matches > 0 && m.st->dm_matches < gate_min_matches);
+  // both neighbours' depth, gradient and norm in ONE gather round trip (index 0 stands in where there is no neighbour pair;
+  // the values are only used under the same conditions as before)
+  const bool has_nb = idx < n && in >= 0 && ip >= 0;  // (rows past n hold no valid ids)
+  const int in_s = has_nb ? in : 0, ip_s = has_nb ? ip : 0;
+  const float2 rn = m.rs[in_s], rp = m.rs[ip_s];
+  const float2 gn = m.grad[in_s], gp = m.grad[ip_s];
+  const float gnn = m.gnorm[in_s], gnp = m.gnorm[ip_s];
+  const bool gated = skip_pair || (gate_min_matches > 0 && dm_matches < gate_min_matches);
   if (next_rot) {
     if (threadIdx.x < 128) sh[threadIdx.x] = 0;
     __syncthreads();
@@ -1562,11 +1573,9 @@ __global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec
   if (idx < n) {
     float2 out = rs;
     if (!gated) {
-      if (in >= 0 && ip >= 0) {
-        const float2 rn = m.rs[in], rp = m.rs[ip];
+      if (has_nb) {
         if (!((rn.x - rp.x) * (rn.x - rp.x) > (rn.y * rn.y + rp.y * rp.y))) {
-          const float2 gn = m.grad[in], gp = m.grad[ip];
-          float alpha = (gn.x * gp.x + gn.y * gp.y) / (m.gnorm[in] * m.gnorm[ip]);
+          float alpha = (gn.x * gp.x + gn.y * gp.y) / (gnn * gnp);
           if (!(alpha < p.regularization_threshold)) {
             alpha = (float)((double)(alpha - p.regularization_threshold) / (1.0 - (double)p.regularization_threshold));
             alpha = (float)((double)alpha / ((double)(fabsf(rn.x - rp.x) / (rn.y + rp.y)) + 1.0));
