@@ -1075,6 +1075,8 @@ __device__ __forceinline__ bool search_accept(const KParams& p, const SearchSetu
 struct OldKl {
   float2 pi, rs, g;
   float gn;
+  unsigned matches;  // fetched with the rest (same gather round trip) so that the commit of the accepted candidate does
+  int kf;            // not start another one
 };
 __device__ __forceinline__ OldKl load_old(const MapDev& om, int i, int rot, const Mat3& R0, float fm) {
   OldKl k;
@@ -1082,20 +1084,22 @@ __device__ __forceinline__ OldKl load_old(const MapDev& om, int i, int rot, cons
   k.rs = om.rs[i];
   k.g = om.grad[i];
   k.gn = om.gnorm[i];
+  k.matches = om.matches[i];
+  k.kf = om.match_kf[i];
   if (rot) rotate_one(R0, fm, k.pi, k.rs, k.g);
   return k;
 }
 
 __device__ __forceinline__ void search_commit(MapDev& nm, const MapDev& om, int idx, int found, const OldKl& k, int* kf) {
+  (void)om;
   nm.rs[idx] = k.rs;
   nm.match_id[idx] = found;
-  nm.matches[idx] = om.matches[found] + 1u;
+  nm.matches[idx] = k.matches + 1u;
   nm.mpos_img[idx] = k.pi;
   nm.mgrad[idx] = k.g;
   nm.mgnorm[idx] = k.gn;
-  const int kfi = om.match_kf[found];
-  nm.match_kf[idx] = kfi;
-  *kf = (kfi >= 0) ? 1 : 0;
+  nm.match_kf[idx] = k.kf;
+  *kf = (k.kf >= 0) ? 1 : 0;
 }
 
 constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-keyline pass
