@@ -80,6 +80,7 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_lm_chain": 6 * 68 * N + 130 * N,
         "k_ext_rot_vel": 130 * N,
         "k_directed_match": 192 * N,
+        "k_directed_match8": 192 * N,     # eight lanes per keyline: same compulsory bytes
         "k_regularize": 60 * N,
         "k_depth_ekf": 48 * N,
     }

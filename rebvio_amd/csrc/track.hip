@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
     float tn = S.dq_rho;
     float tp = S.dq_rho + 1.0f;
     float tq[2 * kHeadSteps];
-    int pix[2 * kHeadSteps];
+    int prow[2 * kHeadSteps], pcol[2 * kHeadSteps];
 #pragma unroll
     for (int j = 0; j < kHeadSteps; ++j) {
       const bool active = j < S.t_steps;
@@ -1176,21 +1176,25 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
       for (int i_idx = 0; i_idx < 2; ++i_idx) {
         const float t = i_idx ? tp : tn;
         const bool ok = active && (i_idx ? !(t > S.dq_max) : !(t < S.dq_min));
-        int px = -1;
+        int pr = -1, pc = 0;
         if (ok) {
           const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
           const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
-          if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) px = row * p.cols + col;
+          if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) {
+            pr = row;
+            pc = col;
+          }
         }
         tq[j * 2 + i_idx] = t;
-        pix[j * 2 + i_idx] = px;
+        prow[j * 2 + i_idx] = pr;
+        pcol[j * 2 + i_idx] = pc;
       }
       tp += 1.0f;
       tn -= 1.0f;
     }
     int cand[2 * kHeadSteps];
 #pragma unroll
-    for (int k = 0; k < 2 * kHeadSteps; ++k) cand[k] = (pix[k] >= 0) ? om.mask[pix[k]] : -1;
+    for (int k = 0; k < 2 * kHeadSteps; ++k) cand[k] = (prow[k] >= 0) ? om.mask[prow[k] * p.cols + pcol[k]] : -1;
     OldKl ck[2 * kHeadSteps];
 #pragma unroll
     for (int k = 0; k < 2 * kHeadSteps; ++k)
@@ -1710,23 +1714,29 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
 }
 
 // grid of the wave-per-keyline pass (REBVIO_HIP_DM_TAIL_BLOCKS to experiment): the queue holds a few thousand long
-// searches, each a chain of dependent gathers - more waves in flight shorten the pass until the CUs are full
-static int dm_tail_blocks() {
-  static const int v = [] {
+// searches, each a chain of dependent gathers - more waves in flight shorten the pass until the dispatch of the grid itself
+// shows (640x480 / 16k keylines: 512 workgroups beat 768, 1024 and 2048 by 3 %; 1280x960 / 64k: ~10k queue entries)
+static int dm_tail_blocks(int kmax) {
+  static const int env = [] {
     const char* e = std::getenv("REBVIO_HIP_DM_TAIL_BLOCKS");
-    const int n = e ? std::atoi(e) : 0;
-    return n > 0 ? n : 512;
+    return e ? std::atoi(e) : 0;
   }();
-  return v;
+  if (env > 0) return env;
+  return std::max(512, std::min(1024, kmax / 32));
 }
 
-// REBVIO_HIP_DM_HEAD=thread: one thread per keyline (k_directed_match); default: eight lanes per keyline
-static bool dm_head_wide() {
-  static const bool wide = [] {
+// Pass 1 form. Eight lanes per keyline shorten the dependent instruction chain of a wave sixfold and pay for it with an
+// eightfold redundant probe set-up: a win while the launch is latency-bound on a mostly idle chip (16k keylines: 11.6 vs
+// 13.8 us), a loss once the eight-fold grid fills it (64k keylines: 36 vs 24 us). REBVIO_HIP_DM_HEAD=thread|wide overrides.
+static bool dm_head_wide(int kmax) {
+  static const int env = [] {
     const char* e = std::getenv("REBVIO_HIP_DM_HEAD");
-    return !(e && std::strcmp(e, "thread") == 0);
+    if (e && std::strcmp(e, "thread") == 0) return 1;
+    if (e && std::strcmp(e, "wide") == 0) return 2;
+    return 0;
   }();
-  return wide;
+  if (env) return env == 2;
+  return kmax <= 32768;
 }
 
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
@@ -1736,26 +1746,26 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
   const int rot = R0_on_the_fly ? 1 : 0;
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
-  if (dm_head_wide())
+  if (dm_head_wide(p.kmax))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback),
               max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
   else
     RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
                        mat3(Rback), max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
-  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks()), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
+  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
             (const int*)work, (const int*)work_n, rot, R0, (const GlueDev*)nullptr);
 }
 
 void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* g_pinned,
                                GlueDev* g_dev, float max_radius, int* work, int* work_n) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-  if (dm_head_wide())
+  if (dm_head_wide(p.kmax))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
               work, work_n, 1, mat3(I), g_pinned, g_dev);
   else
     RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, work,
               work_n, 1, mat3(I), g_pinned, g_dev);
-  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks()), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
+  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
             (const int*)work, (const int*)work_n, 1, mat3(I), (const GlueDev*)g_dev);
 }
 
