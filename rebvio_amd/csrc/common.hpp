@@ -182,7 +182,7 @@ inline int lm_chain_threads() {
   static const int t = [] {
     const char* e = std::getenv("REBVIO_HIP_LM_THREADS");
     const int v = e ? std::atoi(e) : 0;
-    return (v == 256 || v == 512 || v == 1024) ? v : 1024;
+    return (v == 256 || v == 512 || v == 1024) ? v : 512;
   }();
   return t;
 }
