@@ -1386,15 +1386,16 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
       const int stepA = (slot0 + lane) >> 1, stepB = stepA + 32;
       const int odd = (slot0 + lane) & 1;  // both slots of a lane have the same parity
       {
-        float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
+        // a lane needs only the chain of its parity: tp (+1.0f steps from dq_rho + 1) on odd slots, tn (-1.0f steps from
+        // dq_rho) on even ones; x - 1.0f and x + (-1.0f) are the same IEEE operation
+        float x = odd ? S.dq_rho + 1.0f : S.dq_rho;
+        const float d = odd ? 1.0f : -1.0f;
         float ta = 0.f, tb = 0.f;
         const int jmax = min(S.t_steps - 1, (slot0 + 127) >> 1);
         for (int j = 0; j <= jmax; ++j) {
-          const float cur = odd ? tp : tn;
-          ta = (j == stepA) ? cur : ta;
-          tb = (j == stepB) ? cur : tb;
-          tp += 1.0f;
-          tn -= 1.0f;
+          ta = (j == stepA) ? x : ta;
+          tb = (j == stepB) ? x : tb;
+          x += d;
         }
         tt[0] = ta;
         tt[1] = tb;
@@ -1412,23 +1413,41 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
         }
         cand[h] = cd;
       }
-      OldKl ck[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (cand[h] >= 0) ck[h] = load_old(om, cand[h], rot, R0, p.fm);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        bool acc = false;
-        if (!done && cand[h] >= 0) acc = search_accept(p, S, tt[h], ck[h].g, ck[h].gn, ck[h].rs, gq_cur, gnq_cur);
-        const unsigned long long am = __ballot(acc);
-        if (!done && am) {
-          done = true;
-          if (lane == __ffsll((long long)am) - 1) {  // first accepted slot in reference order: this lane owns the match
-            int kf = 0;
-            search_commit(nm, om, idx_cur, cand[h], ck[h], &kf);
-            nfound += 1;
-            nkf += kf;
+      // Candidates are sparse (~5 % of the probed pixels hold a keyline), so fetching + rotating + testing both slots of
+      // every lane runs that code twice for mostly idle lanes. Pass 1 handles each lane's EARLIEST candidate (slot A if it
+      // has one, else slot B); only if no slot-A candidate was accepted anywhere and some lane holds two candidates does
+      // pass 2 evaluate those lanes' slot B. Order of acceptance is unchanged: every A slot (slot0 + lane) precedes every
+      // B slot (slot0 + 64 + lane), within a pass the lowest lane.
+      const int h1 = (cand[0] >= 0) ? 0 : 1;
+      int c_sel = h1 ? cand[1] : cand[0];
+      float t_sel = h1 ? tt[1] : tt[0];
+      OldKl ck{};
+      bool acc = false;
+      if (c_sel >= 0) {
+        ck = load_old(om, c_sel, rot, R0, p.fm);
+        acc = search_accept(p, S, t_sel, ck.g, ck.gn, ck.rs, gq_cur, gnq_cur);
+      }
+      unsigned long long am = __ballot(acc && h1 == 0);
+      if (!am) {
+        const bool both = cand[0] >= 0 && cand[1] >= 0;
+        bool acc_b = acc && h1 == 1;
+        if (__ballot(both)) {
+          if (both) {
+            c_sel = cand[1];
+            ck = load_old(om, c_sel, rot, R0, p.fm);
+            acc_b = search_accept(p, S, tt[1], ck.g, ck.gn, ck.rs, gq_cur, gnq_cur);
           }
+        }
+        acc = acc_b;
+        am = __ballot(acc_b);
+      }
+      if (am) {
+        done = true;
+        if (lane == __ffsll((long long)am) - 1) {  // first accepted slot in reference order: this lane owns the match
+          int kf = 0;
+          search_commit(nm, om, idx_cur, c_sel, ck, &kf);
+          nfound += 1;
+          nkf += kf;
         }
       }
     }
