@@ -104,6 +104,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout. Native libraries write there too (gloo reports its mesh connections on
+    # stdout, "[Gloo] Rank 0 is connected to ..."): everything this process prints before the result goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from rebvio_amd import shard
     rank, local_rank, world = shard.env_ranks()
     if world != args.gpus and world > 1:
@@ -248,7 +254,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(frames, cam, cfg, order, args.cpu_seconds)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(result), flush=True)
+        os.dup2(2, 1)  # process-group teardown may log again
     if world > 1:
         dist.destroy_process_group()
 
