@@ -157,6 +157,8 @@ def main():
                                       density=cfg.get("density", 1.0))
     kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=cfg["keylines_ref"], keylines_max=cfg["keylines_max"],
               device_id=local_rank)
+    if os.environ.get("REBVIO_BENCH_POOL"):  # diagnostic: edge maps allocated up front (the pool grows by itself otherwise)
+        kw["map_pool"] = int(os.environ["REBVIO_BENCH_POOL"])
     ctx = B.Context(B.default_params(H, W, **kw))
     dev = ctx.upload_frames(frames)
     npx = W * H

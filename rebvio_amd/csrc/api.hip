@@ -228,6 +228,7 @@ struct rebvio_hip_ctx {
   unsigned* glue_flag = nullptr;  // [kSlots], pinned
   GlueDev* glue_dev = nullptr;    // [kSlots], device copies made by the first kernel behind the wait
   bool prelaunch_b = true;        // REBVIO_HIP_PRELAUNCH=0: enqueue the B-chain after the glue (kernel arguments)
+  int lead = 5;                   // detected frames queued when a pair is started (REBVIO_HIP_LEAD 3..12, see push_frame)
   struct PendingPair {
     rebvio_hip_map* om = nullptr;
     rebvio_hip_map* nm = nullptr;
@@ -810,6 +811,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
     const char* e = std::getenv("REBVIO_HIP_PRELAUNCH");
     c->prelaunch_b = can != 0 && !(e && std::atoi(e) == 0);
+    if (const char* l = std::getenv("REBVIO_HIP_LEAD")) c->lead = std::min(12, std::max(3, std::atoi(l)));
   }
   HIPCHK(hipHostMalloc(&c->h_lm, 2 * sizeof(LmState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_part, part_call_stride(c) * sizeof(float), hipHostMallocDefault));
@@ -1580,6 +1582,11 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   //   track stream           : see the comment above enqueue_a_chain
   // The returned record is the most recent COMPLETE pair (its match counters travel with the next pair's slot), a few
   // frames behind f in steady state; status -1 while the pipeline fills.
+  // Lead: pair (k-1, k) is started once frame k+lead-2 has been queued for detection. A frame's detection takes ~130 us
+  // from enqueue to its distance field (scan chain, then keyline chain) while the tracker needs a new map every ~90 us: with
+  // the minimum lead of 3 the kernel trace showed k_lm_chain starting 11-12 us after the previous pair's last kernel,
+  // waiting for that map; lead 5 keeps two more detections in flight (10.7 k -> 11.3 k frames/s; 4 and 6+ measured no
+  // better). Costs latency of the returned records, not throughput; flush() drops the pairs not yet started.
   rebvio_hip_map* m = nullptr;
   const auto td0 = std::chrono::steady_clock::now();
   HIPCHK(hipSetDevice(c->device));
@@ -1605,7 +1612,7 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   c->t_b_enq += std::chrono::duration<double, std::micro>(ta0 - tb0).count();
   rebvio_hip_ctx::PendingPair pp;
   bool have_next = false;
-  if (rc_pre == 0 && c->frames.size() >= 3 && (!c->has_cur || c->prelaunch_b)) {
+  if (rc_pre == 0 && (int)c->frames.size() >= c->lead && (!c->has_cur || c->prelaunch_b)) {
     // frames[1] was detected at least one call ago: the track stream will not stall on it
     pp.om = c->frames[0];
     pp.nm = c->frames[1];
@@ -1631,7 +1638,7 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
     }
   }
   if (rc_pre) return rc_pre;
-  if (!c->prelaunch_b && c->frames.size() >= 3) {  // classic order: the next first half goes behind the B-chain just enqueued
+  if (!c->prelaunch_b && (int)c->frames.size() >= c->lead) {  // classic order: the next first half goes behind the B-chain just enqueued
     pp.om = c->frames[0];
     pp.nm = c->frames[1];
     pp.slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);

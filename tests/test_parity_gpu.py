@@ -501,7 +501,7 @@ def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
         if out.status >= 0:
             got.append((np.array(out.Vg), np.array(out.Xgv[3:6]), out.klm_num, out.status))
     ctx.flush()
-    assert len(got) >= len(order) - 6
+    assert len(got) >= len(order) - 8  # the last few frames only fill the pipeline (lead of the detect stage)
     # the oracle's record k describes pair (k-1, k); the pipeline reports the pairs in the same order starting at pair 1
     for j, (vg, dw, klm, status) in enumerate(got):
         k = j + 1
@@ -589,7 +589,7 @@ def test_pair_step_failure_paths(orc_mod, B, small_stream):
     assert (ko["sigma_rho"][unmatched] == 20.0).all() and (kg["sigma_rho"][unmatched] == 20.0).all()
     # streaming driver: the bad pair is reported with status 2, the following pairs are tracked again
     ctx2 = B.Context(params_for(B, cam, **kw))
-    seq = np.concatenate([frames[:3], other, frames[3:8]])
+    seq = np.concatenate([frames[:3], other, frames[3:12]])  # enough frames behind the bad one to drain the pipeline
     dev = ctx2.upload_frames(seq)
     npx = cam.width * cam.height
     st = []
