@@ -209,9 +209,11 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, r
                                  const float P_V[9], const float Rgva[9], const float R_second[9], int* klm_num,
                                  int* kf_matches, int* reg_num, int* status);
 
-/* Streaming driver used by bench/Rebvio: detect(frame) on the detect stream overlapped with
- * track(previous pair) on the track stream. `out` describes the pair (previous, this) and is filled
- * when the call returns (status -1 for the very first frame). */
+/* Streaming driver used by the bench: a software pipeline, detect(frame) on the scan / keyline streams overlapped with
+ * the tracking of EARLIER pairs on the track stream. `out` receives the most recent COMPLETE pair, in pair order, several
+ * calls behind `frame` (the detect stage leads the tracker by REBVIO_HIP_LEAD frames, default 5, and a pair's match
+ * counters arrive with the next pair); status -1 while nothing is complete yet. rebvio_hip_flush() finishes the pair in
+ * flight and drops the frames no pair was started for. */
 int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_dev, uint64_t ts_us,
                                     rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_flush(rebvio_hip_ctx* ctx);
