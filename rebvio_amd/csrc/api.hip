@@ -154,6 +154,7 @@ struct rebvio_hip_map {
   bool pre_rotated = false;  // the next pair's first rotateKeylines (+ histogram) was already applied by the fused B-chain
   int n_host = -1;
   float thr_host = -1.0f;
+  bool trk_waited = false;  // the track stream already holds a wait on `ready` (a second one is another barrier packet)
 };
 
 struct rebvio_hip_ctx {
@@ -228,6 +229,7 @@ struct rebvio_hip_ctx {
   unsigned* glue_flag = nullptr;  // [kSlots], pinned
   GlueDev* glue_dev = nullptr;    // [kSlots], device copies made by the first kernel behind the wait
   bool prelaunch_b = true;        // REBVIO_HIP_PRELAUNCH=0: enqueue the B-chain after the glue (kernel arguments)
+  bool slim_ops = true;           // REBVIO_HIP_SLIM_OPS=0: event waits / map release between B(k) and A(k+1), as enqueued
   int lead = 5;                   // detected frames queued when a pair is started (REBVIO_HIP_LEAD 3..12, see push_frame)
   struct PendingPair {
     rebvio_hip_map* om = nullptr;
@@ -337,6 +339,7 @@ rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
     m->pre_rotated = false;
     m->n_host = -1;
     m->thr_host = -1.0f;
+    m->trk_waited = false;
     return m;
   }
   // every pooled map is alive (a caller queues detections faster than it tracks, like the reference's unbounded
@@ -811,6 +814,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
     const char* e = std::getenv("REBVIO_HIP_PRELAUNCH");
     c->prelaunch_b = can != 0 && !(e && std::atoi(e) == 0);
+    if (const char* so = std::getenv("REBVIO_HIP_SLIM_OPS")) c->slim_ops = std::atoi(so) != 0;
     if (const char* l = std::getenv("REBVIO_HIP_LEAD")) c->lead = std::min(12, std::max(3, std::atoi(l)));
   }
   HIPCHK(hipHostMalloc(&c->h_lm, 2 * sizeof(LmState), hipHostMallocDefault));
@@ -1458,12 +1462,27 @@ namespace {
 // the O(1) glue (rebvio.cpp:186-233), writes glue_host[slot] and the flag. No kernel launch sits between the end of A(k)
 // and the start of B(k), and no wait is ever left un-released when the call returns (a guard releases it on every error
 // path with nan_v = 1, so that the queued kernels fall through).
+// Cross-stream dependencies of a pair's first half (its two maps detected). Every stream operation between two kernels
+// of the track stream is a packet of its own for the command processor (the kernel trace shows ~7 us between the end of
+// k_regularize_ekf(k) and the start of k_lm_chain(k+1), filled by an event record and two event waits). So a map is waited
+// for once (the old map of a pair was the new map of the previous one), and with slim_ops the streaming driver enqueues the
+// waits of pair k+1 BEFORE the parked second half of pair k, where they are absorbed by the host glue's bubble (the detect
+// stage leads by `lead` frames, so they are long satisfied).
+int enqueue_a_waits(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
+  hipStream_t s = c->s_trk;
+  for (rebvio_hip_map* m : {pp.om, pp.nm}) {
+    if (m->trk_waited && c->slim_ops) continue;
+    wait_enqueued(m);
+    HIPCHK(hipStreamWaitEvent(s, m->ready, 0));
+    m->trk_waited = true;
+  }
+  return 0;
+}
+
 int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   hipStream_t s = c->s_trk;
-  wait_enqueued(pp.om);
-  wait_enqueued(pp.nm);
-  HIPCHK(hipStreamWaitEvent(s, pp.om->ready, 0));
-  HIPCHK(hipStreamWaitEvent(s, pp.nm->ready, 0));
+  int rcw = enqueue_a_waits(c, pp);
+  if (rcw) return rcw;
   c->df_map = pp.nm;
   if (!pp.om->pre_rotated) {  // first pair of a stream: no B-chain has applied the prior rotation yet
     pp.R = prior_rotation(c, nullptr);
@@ -1482,7 +1501,7 @@ int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
 }
 
 // W + B of a pair whose A-chain is already queued; everything that depends on the glue is read from memory at run time.
-int enqueue_b_chain_pre(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
+int enqueue_b_chain_pre(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp, bool defer_release = false) {
   hipStream_t s = c->s_trk;
   HIPCHK(hipStreamWaitValue32(s, c->glue_flag + pp.slot, pp.seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
   pp.b_enqueued = true;  // from here on the flag MUST be written, whatever happens
@@ -1493,7 +1512,7 @@ int enqueue_b_chain_pre(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   std::swap(pp.nm->d.rs, pp.nm->d.rs_tmp);
   std::swap(pp.nm->d.grad, pp.nm->d.grad_tmp);
   pp.nm->pre_rotated = true;
-  rebvio_hip_map_release(pp.om);  // stream-ordered: reusable once the B-chain has drained
+  if (!defer_release) rebvio_hip_map_release(pp.om);  // stream-ordered: reusable once the B-chain has drained
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1607,15 +1626,24 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   // 1. second half of the pair in flight, parked behind its wait; 2. first half of the next pair behind that
   int rc_pre = 0;
   const auto tb0 = std::chrono::steady_clock::now();
-  if (c->has_cur && c->prelaunch_b) rc_pre = enqueue_b_chain_pre(c, c->cur);
-  const auto ta0 = std::chrono::steady_clock::now();
-  c->t_b_enq += std::chrono::duration<double, std::micro>(ta0 - tb0).count();
   rebvio_hip_ctx::PendingPair pp;
   bool have_next = false;
-  if (rc_pre == 0 && (int)c->frames.size() >= c->lead && (!c->has_cur || c->prelaunch_b)) {
-    // frames[1] was detected at least one call ago: the track stream will not stall on it
+  const bool next_ready = (int)c->frames.size() >= c->lead && (!c->has_cur || c->prelaunch_b);
+  if (next_ready) {
+    // frames[1] was detected at least lead - 2 calls ago: the track stream will not stall on it
     pp.om = c->frames[0];
     pp.nm = c->frames[1];
+    if (c->slim_ops) rc_pre = enqueue_a_waits(c, pp);  // ahead of the parked second half (see enqueue_a_waits)
+  }
+  const bool defer_release = c->slim_ops && next_ready && rc_pre == 0;
+  rebvio_hip_map* deferred = nullptr;
+  if (rc_pre == 0 && c->has_cur && c->prelaunch_b) {
+    rc_pre = enqueue_b_chain_pre(c, c->cur, defer_release);
+    if (defer_release) deferred = c->cur.om;
+  }
+  const auto ta0 = std::chrono::steady_clock::now();
+  c->t_b_enq += std::chrono::duration<double, std::micro>(ta0 - tb0).count();
+  if (rc_pre == 0 && next_ready) {
     pp.slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
     pp.seq = (unsigned)(++c->pair_seq);
     if (pp.seq == 0) pp.seq = (unsigned)(++c->pair_seq);  // 0 is the idle value of the flags
@@ -1624,6 +1652,9 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
     have_next = rc_pre == 0;
     if (have_next) c->frames.erase(c->frames.begin());
   }
+  // the old map of the pair in flight: its release (an event record) goes behind the next first half, off the path between
+  // k_regularize_ekf(k) and k_lm_chain(k+1)
+  if (deferred) rebvio_hip_map_release(deferred);
   c->t_a_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta0).count();
   // 3. wait for the pair in flight, glue, release (also on the error paths above: finish_current's guard releases)
   if (c->has_cur) {
