@@ -512,6 +512,38 @@ def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
         assert abs(int(ref["match_counts"][k]) - klm) <= 0.01 * ref["match_counts"][k] + 2
 
 
+def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeypatch):
+    """The detect stage leads the tracker by REBVIO_HIP_LEAD frames and the stream operations of consecutive pairs are
+    interleaved (REBVIO_HIP_SLIM_OPS); both only move work in time. Same frames -> the same records, bit for bit, in the
+    same order; a deeper pipeline merely delivers them later (and starts fewer pairs before the flush)."""
+    from rebvio_amd import synth
+    frames, cam = c2_stream
+    order = synth.pingpong_indices(len(frames), 40)
+    npx = cam.width * cam.height
+
+    def run(lead, slim):
+        monkeypatch.setenv("REBVIO_HIP_LEAD", str(lead))
+        monkeypatch.setenv("REBVIO_HIP_SLIM_OPS", str(slim))
+        ctx = B.Context(params_for(B, cam, **KW_C2))
+        dev = ctx.upload_frames(frames)
+        rec = []
+        for k, i in enumerate(order):
+            out, n = ctx.push_frame_u8_device(dev + int(i) * npx, k * 50000)
+            if out.status >= 0:
+                rec.append((tuple(out.Vg), tuple(out.V), tuple(out.Xgv), tuple(out.R), out.klm_num, out.kf_matches, out.reg_num,
+                            out.lm_accept_mask, out.status, n))
+        ctx.flush()
+        ctx.close()
+        return rec
+
+    base = run(3, 0)
+    assert len(base) >= 30
+    for lead, slim in ((3, 1), (5, 1), (8, 1), (5, 0)):
+        got = run(lead, slim)
+        assert len(got) >= len(order) - lead - 3
+        assert got == base[:len(got)], (lead, slim)
+
+
 def test_euroc_frame_size_with_lens_model(orc_mod, B):
     """752x480 (the reference's built-in EuRoC camera, camera.hpp:25-45: a width that is not a multiple of the 32- and
     64-pixel tiles) with its rad-tan lens model: front end + detection bit-exact, distance field exact, one pair step
