@@ -243,7 +243,19 @@ __device__ __forceinline__ void sym6_to_9(const float* J, float* M) {
 // One Levenberg-Marquardt bookkeeping step of Core::minimizeVel (core.cpp:161-185), run redundantly and
 // identically by thread 0 of every workgroup; `red` = fixed-order sum of the previous call's block records.
 // call: index of the tryVel evaluation about to run (0..iterations); final: no further evaluation follows.
-__device__ void lm_step(LmState& s, const float* red, int call, bool final_only) {
+// The state lives in LDS and `red` may alias it as far as the compiler can tell, so working on it in place turns every
+// field access into its own LDS round trip on a lone thread; the step therefore runs on register copies (same
+// operations in the same order) and writes the state back once.
+__device__ void lm_step_regs(LmState& s, const float (&red)[10], int call, bool final_only);
+__device__ void lm_step(LmState& s_lds, const float* red_lds, int call, bool final_only) {
+  LmState t = s_lds;
+  float r[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r[i] = red_lds[i];
+  lm_step_regs(t, r, call, final_only);
+  s_lds = t;
+}
+__device__ __forceinline__ void lm_step_regs(LmState& s, const float (&red)[10], int call, bool final_only) {
   if (call == 1) {
     s.F = red[0];
     for (int i = 0; i < 6; ++i) s.JtJ[i] = red[1 + i];
