@@ -824,7 +824,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->xrv_part, (size_t)c->maxblocks * kXrvStride * sizeof(float)));
   HIPCHK(hipMalloc(&c->hist, 128 * sizeof(int)));
   HIPCHK(hipMemset(c->hist, 0, 128 * sizeof(int)));
-  HIPCHK(hipMalloc(&c->dm_work, (size_t)div_up(p->keylines_max, 256) * 256 * sizeof(int)));
+  // long-search queue: keyline indices, then three float4 of probe geometry per entry (dm_queue_put in track.hip)
+  HIPCHK(hipMalloc(&c->dm_work, (size_t)div_up(p->keylines_max, 256) * 256 * (sizeof(int) + 3 * sizeof(float4))));
   HIPCHK(hipMalloc(&c->dm_work_n, sizeof(int)));
   HIPCHK(hipMemset(c->dm_work_n, 0, sizeof(int)));
   HIPCHK(hipMalloc(&c->lm_zero, sizeof(LmState)));

@@ -1114,6 +1114,28 @@ __device__ __forceinline__ void search_commit(MapDev& nm, const MapDev& om, int 
   *kf = (k.kf >= 0) ? 1 : 0;
 }
 
+// The long-search queue carries each entry's probe geometry next to its keyline index, so that pass 2 does not evaluate
+// search_setup (five IEEE divisions, a square root, two 3x3 products) a second time: work[0 .. cap) = keyline indices,
+// then cap records of three float4 (cap = keylines_max rounded up to 256).
+__device__ __forceinline__ int dm_queue_cap(const KParams& p) { return ((p.kmax + 255) / 256) * 256; }
+__device__ __forceinline__ float4* dm_queue_geom(int* work, const KParams& p) {
+  return reinterpret_cast<float4*>(work + dm_queue_cap(p));
+}
+__device__ __forceinline__ void dm_queue_put(int* work, const KParams& p, int pos, int idx, const SearchSetup& S) {
+  work[pos] = idx;
+  float4* g = dm_queue_geom(work, p) + 3 * (size_t)pos;
+  g[0] = make_float4(S.t_x, S.t_y, S.norm_t, S.pi0x);
+  g[1] = make_float4(S.pi0y, S.sigma2_t, S.dq_min, S.dq_max);
+  g[2] = make_float4(S.dq_rho, __int_as_float(S.t_steps), 0.f, 0.f);
+}
+__device__ __forceinline__ SearchSetup dm_queue_get(const float4& a, const float4& b, const float4& c) {
+  SearchSetup S;
+  S.t_x = a.x; S.t_y = a.y; S.norm_t = a.z; S.pi0x = a.w;
+  S.pi0y = b.x; S.sigma2_t = b.y; S.dq_min = b.z; S.dq_max = b.w;
+  S.dq_rho = c.x; S.t_steps = __float_as_int(c.y);
+  return S;
+}
+
 constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-keyline pass
 
 // Pass 1: one thread per keyline of the NEW map, the first kHeadSteps steps of the reference's alternating probe
@@ -1175,8 +1197,9 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
   int found = -1;
   int kf = 0;
   bool more = false;
+  SearchSetup S{};
   if (idx < n) {
-    const SearchSetup S = search_setup(p, pi, rsq, gq, gnq, vel, Rvel, Rback, max_radius);
+    S = search_setup(p, pi, rsq, gq, gnq, vel, Rvel, Rback, max_radius);
     float tn = S.dq_rho;
     float tp = S.dq_rho + 1.0f;
     float tq[2 * kHeadSteps];
@@ -1250,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
     }
   }
   __syncthreads();
-  if (more) work[w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull))] = idx;
+  if (more) dm_queue_put(work, p, w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull)), idx, S);
   if (threadIdx.x == 0) {
     if (b_found) atomicAdd(&nm.st->dm_matches, b_found);
     if (b_kf) atomicAdd(&nm.st->dm_kf, b_kf);
@@ -1288,8 +1311,9 @@ __global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, M
   bool acc = false, more = false;
   int cand = -1;
   OldKl ck{};
+  SearchSetup S{};
   if (idx < n) {
-    const SearchSetup S = search_setup(p, pi, rsq, gq, gnq, A.vel, A.Rvel, A.Rback, max_radius);
+    S = search_setup(p, pi, rsq, gq, gnq, A.vel, A.Rvel, A.Rback, max_radius);
     // t of this slot: the reference reaches step j by j repeated +1.0f / -1.0f (not dq_rho +- j: the roundings differ)
     const int step = slot >> 1, side = slot & 1;
     float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
@@ -1341,7 +1365,7 @@ __global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, M
     }
   }
   __syncthreads();
-  if (more) work[w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull))] = idx;
+  if (more) dm_queue_put(work, p, w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull)), idx, S);
   if (threadIdx.x == 0) {
     if (b_found) atomicAdd(&nm.st->dm_matches, b_found);
     if (b_kf) atomicAdd(&nm.st->dm_kf, b_kf);
@@ -1371,21 +1395,25 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
   const int wstride = (gridDim.x * 256) >> 6;
 
   // software pipeline over this wave's queue entries: the next entry's keyline is loaded while the current one is searched
+  const float4* geom = dm_queue_geom(const_cast<int*>(work), p);
   int idx = (wave < total) ? idx_first : 0;
-  float2 gq = nm.grad[idx], piq = nm.pos_img[idx], rsq = nm.rs[idx];
+  const int w0 = min(wave, p.kmax - 1);
+  float4 ga = geom[3 * (size_t)w0], gb = geom[3 * (size_t)w0 + 1], gc = geom[3 * (size_t)w0 + 2];
+  float2 gq = nm.grad[idx];
   float gnq = nm.gnorm[idx];
   for (int w = wave; w < total; w += wstride) {
     const int idx_cur = idx;
-    const float2 gq_cur = gq, piq_cur = piq, rsq_cur = rsq;
+    const float2 gq_cur = gq;
     const float gnq_cur = gnq;
+    const SearchSetup S = dm_queue_get(ga, gb, gc);  // probe geometry as the first pass computed it
     if (w + wstride < total) {
       idx = work[w + wstride];
+      ga = geom[3 * (size_t)(w + wstride)];
+      gb = geom[3 * (size_t)(w + wstride) + 1];
+      gc = geom[3 * (size_t)(w + wstride) + 2];
       gq = nm.grad[idx];
-      piq = nm.pos_img[idx];
-      rsq = nm.rs[idx];
       gnq = nm.gnorm[idx];
     }
-    const SearchSetup S = search_setup(p, piq_cur, rsq_cur, gq_cur, gnq_cur, vel, Rvel, Rback, max_radius);
     bool done = false;
     // two probe slots per lane and trip (slot, slot + 64): a search over the full +-42 range (what an unmatched keyline
     // runs through) is ONE gather round trip instead of two; acceptance is still taken in slot order
