@@ -707,6 +707,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   const int nr = 2 * (int)p->search_range;
   if (nr < 2 || (long long)p->keylines_max * nr >= (1ll << kDfSeqBits) || (int)p->search_range > 255)
     return fail_msg("keylines_max * 2*search_range must stay below 2^23", -3);
+  if (!(p->pixel_uncertainty_match >= 0.0f) || p->search_range + 2.0f * p->pixel_uncertainty_match + 2.0f > 260.0f)
+    return fail_msg("search_range + 2 * pixel_uncertainty_match must stay below 258 (probe sequence buffer)", -3);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) return fail_msg("no HIP device present: the gfx950 backend has no CPU fallback", -4);

@@ -1136,6 +1136,7 @@ __device__ __forceinline__ SearchSetup dm_queue_get(const float4& a, const float
   return S;
 }
 
+constexpr int kDmSeqMax = 264;  // probe steps of one search: t_steps <= search_range + pixel_uncertainty_match + 1, search_range <= 255
 constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-keyline pass
 
 // Pass 1: one thread per keyline of the NEW map, the first kHeadSteps steps of the reference's alternating probe
@@ -1391,6 +1392,7 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
   const Mat3 &Rvel = A.Rvel, &Rback = A.Rback, &R0 = A.R0;
   const int rot = A.rot;
   if (blockIdx.x == 0 && threadIdx.x == 0) nm.st->dm_queued = total;
+  __shared__ float seq[4][2][kDmSeqMax];  // per wave: the probe sequences of the entry in work (see below)
   int nfound = 0, nkf = 0;  // per lane: the lane that holds the accepted candidate commits it
   const int wstride = (gridDim.x * 256) >> 6;
 
@@ -1426,19 +1428,26 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
       const int stepA = (slot0 + lane) >> 1, stepB = stepA + 32;
       const int odd = (slot0 + lane) & 1;  // both slots of a lane have the same parity
       {
-        // a lane needs only the chain of its parity: tp (+1.0f steps from dq_rho + 1) on odd slots, tn (-1.0f steps from
-        // dq_rho) on even ones; x - 1.0f and x + (-1.0f) are the same IEEE operation
-        float x = odd ? S.dq_rho + 1.0f : S.dq_rho;
-        const float d = odd ? 1.0f : -1.0f;
-        float ta = 0.f, tb = 0.f;
-        const int jmax = min(S.t_steps - 1, (slot0 + 127) >> 1);
-        for (int j = 0; j <= jmax; ++j) {
-          ta = (j == stepA) ? x : ta;
-          tb = (j == stepB) ? x : tb;
-          x += d;
+        // The two chains (tn: -1.0f steps from dq_rho, even slots; tp: +1.0f steps from dq_rho + 1, odd slots; x - 1.0f
+        // and x + (-1.0f) are the same IEEE operation) are produced ONCE per wave by lanes 0 and 1 into LDS - one add and
+        // one LDS store per step - and every lane then reads its two elements, instead of all lanes walking a chain with
+        // two compares and two selects per step.
+        const int jmax = min(min(S.t_steps - 1, (slot0 + 127) >> 1), kDmSeqMax - 1);  // (rebvio_hip_create bounds t_steps)
+        float* sq = seq[threadIdx.x >> 6][odd];
+        if (lane < 2) {
+          float x = odd ? S.dq_rho + 1.0f : S.dq_rho;
+          const float d = odd ? 1.0f : -1.0f;
+          for (int j = 0; j <= jmax; ++j) {
+            sq[j] = x;
+            x += d;
+          }
         }
-        tt[0] = ta;
-        tt[1] = tb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        tt[0] = (stepA <= jmax) ? sq[stepA] : 0.f;
+        tt[1] = (stepB <= jmax) ? sq[stepB] : 0.f;
+        __builtin_amdgcn_wave_barrier();  // the next round / entry rewrites the sequence
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
