@@ -1388,9 +1388,9 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
   const int idx_first = work[min(wave, p.kmax - 1)];
   const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
   if (A.skip) return;
-  const Vec3& vel = A.vel;
-  const Mat3 &Rvel = A.Rvel, &Rback = A.Rback, &R0 = A.R0;
+  const Mat3& R0 = A.R0;  // (velocity, its covariance and Rback only enter the probe geometry, which the queue carries)
   const int rot = A.rot;
+  (void)max_radius;
   if (blockIdx.x == 0 && threadIdx.x == 0) nm.st->dm_queued = total;
   __shared__ float seq[4][2][kDmSeqMax];  // per wave: the probe sequences of the entry in work (see below)
   int nfound = 0, nkf = 0;  // per lane: the lane that holds the accepted candidate commits it
