@@ -96,8 +96,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=1000,
-                    help="untimed frames; the stream needs ~1000 frames until depths / match queues reach their steady state")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed frames, exactly as given; default 1000: the stream needs ~1000 frames until depths / match "
+                         "queues reach their steady state")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--base-frames", type=int, default=24, help="distinct rendered frames (ping-pong replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +150,8 @@ def main():
 
     cfg = CONFIGS[args.config]
     W, H = cfg["width"], cfg["height"]
-    steps, warmup = args.steps, max(args.warmup, cfg.get("warmup", 3))
+    steps = args.steps
+    warmup = max(1000, cfg.get("warmup", 3)) if args.warmup is None else max(0, args.warmup)
 
     # ---- synthetic stream (one per rank), frames resident in HBM -------------------------------------------
     # scene density: enough texture for the servo to settle at keylines_ref (1280x960 needs a denser scene for ~60k)
