@@ -16,16 +16,16 @@ def main():
     for r in range(rounds):
         try:
             for _ in range(50):
-                ctx.push_frame_u8_device(dev + int(order[k]) * 640 * 480, k * 50000); k += 1
+                ctx.push_frame_u8_device(dev + int(order[k % len(order)]) * 640 * 480, k * 50000); k += 1
             torch.cuda.synchronize()
             ctx.profile_reset(); ctx.profile(True)
             for _ in range(24):
-                ctx.push_frame_u8_device(dev + int(order[k]) * 640 * 480, k * 50000); k += 1
+                ctx.push_frame_u8_device(dev + int(order[k % len(order)]) * 640 * 480, k * 50000); k += 1
             torch.cuda.synchronize()
             prof = ctx.profile_read(); ctx.profile(False)
             ctx.profile_reset(); ctx.profile(True, only="k_lm_chain<512>", stride=8)
             for _ in range(1000):
-                ctx.push_frame_u8_device(dev + int(order[k]) * 640 * 480, k * 50000); k += 1
+                ctx.push_frame_u8_device(dev + int(order[k % len(order)]) * 640 * 480, k * 50000); k += 1
             torch.cuda.synchronize()
             ctx.profile_read(); ctx.profile(False)
             ctx.flush()
