@@ -211,19 +211,13 @@ bool SABEstimator::problem(rebvio::types::Matrix7f& JtJ_, rebvio::types::Vector7
       dFdx1.a[5 + i][3 + j] = Gx[i][j];
     }
   for (int i = 0; i < 3; ++i) dFdx1.a[8 + i][3 + i] = 1.0f;
-  Mx<11, 11> P = Mx<11, 11>::zeros(), W = Mx<11, 11>::zeros(), dPda = Mx<11, 11>::zeros();
+  Mx<11, 11> W = Mx<11, 11>::zeros();  // P = blockdiag(Pz, Rg, Pp) itself is only needed through its 3x3 block (below)
   Mx<3, 3> Pz;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) Pz.a[i][j] = sa * sa * cfg.Rv(i, j) + ca * ca * cfg.Rs(i, j);
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) P.a[i][j] = Pz.a[i][j];
-  P.a[3][3] = cfg.Rg;
   Mx<7, 7> Pp;
   for (int i = 0; i < 7; ++i)
-    for (int j = 0; j < 7; ++j) {
-      Pp.a[i][j] = cfg.Pp(i, j);
-      P.a[4 + i][4 + j] = cfg.Pp(i, j);
-    }
+    for (int j = 0; j < 7; ++j) Pp.a[i][j] = cfg.Pp(i, j);
   const Mx<3, 3> Wz = chol_inverse<3>(Pz);
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) W.a[i][j] = Wz.a[i][j];
@@ -235,10 +229,7 @@ bool SABEstimator::problem(rebvio::types::Matrix7f& JtJ_, rebvio::types::Vector7
   // products are formed on the 3x3 blocks (the dense 11x11 products add exact zeros to the same terms)
   Mx<3, 3> dPz;
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      dPz.a[i][j] = 2.0 * sa * ca * (cfg.Rv(i, j) - cfg.Rs(i, j));
-      dPda.a[i][j] = dPz.a[i][j];
-    }
+    for (int j = 0; j < 3; ++j) dPz.a[i][j] = 2.0 * sa * ca * (cfg.Rv(i, j) - cfg.Rs(i, j));
   Mx<3, 3> dWz = mul(mul(Wz, dPz), Wz);
   Mx<11, 11> dWda = Mx<11, 11>::zeros();
   for (int i = 0; i < 3; ++i)
