@@ -513,17 +513,19 @@ def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
 
 
 def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeypatch):
-    """The detect stage leads the tracker by REBVIO_HIP_LEAD frames and the stream operations of consecutive pairs are
-    interleaved (REBVIO_HIP_SLIM_OPS); both only move work in time. Same frames -> the same records, bit for bit, in the
+    """The detect stage leads the tracker by REBVIO_HIP_LEAD frames, the stream operations of consecutive pairs are
+    interleaved (REBVIO_HIP_SLIM_OPS) and the glue slots live in device or pinned memory (REBVIO_HIP_GLUE); all of these
+    only move work or bytes around. Same frames -> the same records, bit for bit, in the
     same order; a deeper pipeline merely delivers them later (and starts fewer pairs before the flush)."""
     from rebvio_amd import synth
     frames, cam = c2_stream
     order = synth.pingpong_indices(len(frames), 40)
     npx = cam.width * cam.height
 
-    def run(lead, slim):
+    def run(lead, slim, glue="auto"):
         monkeypatch.setenv("REBVIO_HIP_LEAD", str(lead))
         monkeypatch.setenv("REBVIO_HIP_SLIM_OPS", str(slim))
+        monkeypatch.setenv("REBVIO_HIP_GLUE", glue)  # "pinned": host memory; anything else: device memory where it works
         ctx = B.Context(params_for(B, cam, **KW_C2))
         dev = ctx.upload_frames(frames)
         rec = []
@@ -538,10 +540,10 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
 
     base = run(3, 0)
     assert len(base) >= 30
-    for lead, slim in ((3, 1), (5, 1), (8, 1), (5, 0)):
-        got = run(lead, slim)
+    for lead, slim, glue in ((3, 1, "auto"), (5, 1, "auto"), (8, 1, "auto"), (5, 0, "auto"), (5, 1, "pinned")):
+        got = run(lead, slim, glue)
         assert len(got) >= len(order) - lead - 3
-        assert got == base[:len(got)], (lead, slim)
+        assert got == base[:len(got)], (lead, slim, glue)
 
 
 def test_euroc_frame_size_with_lens_model(orc_mod, B):
