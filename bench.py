@@ -27,12 +27,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 
 
 def pmc_traffic_bytes(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/r01_pmc_hbm.json:
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/rNN_pmc_hbm.json:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs). Counters are in KiB; per
     MI355X_MICROARCH.md §HBM FETCH_SIZE reads half of a wide coalesced stream on gfx950 -> doubled; other access
     widths are uncalibrated, so this is an upper estimate for gather-style kernels. None when no pass is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_hbm.json") for r in (2, 1)) if os.path.exists(q)), None)
+    if path is None:
         return None
     try:
         d = json.load(open(path)).get(kernel)
@@ -92,6 +92,60 @@ def launches_per_frame(kernel: str, iterations: int = 5) -> int:
     return {"k_rowscan<2>": 2, "k_colscan": 3, "k_try_vel": iterations + 1, "k_rotate": 2}.get(kernel, 1)
 
 
+# Stages at the reference's REBVIO_TIMER tick sites -> the kernels that do that work here.
+STAGES = (
+    ("detect", "edge_detector.cpp:31,41", ("k_front_end_u8", "k_rowscan", "k_colscan", "k_dog_mag", "k_keyline_flag",
+                                           "k_keyline_emit", "k_join_edges")),
+    ("buildDistanceField", "core.cpp:34-36", ("k_df_",)),
+    # one persistent launch does minimizeVel (core.cpp:152,187), forwardMatch and extRotVel's sums (core.cpp:193,258)
+    ("minimizeVel+forwardMatch+extRotVel", "core.cpp:152,187,193,258", ("k_lm_chain", "k_try_vel", "k_ext_rot_vel", "k_rotate")),
+    ("directedMatch", "edge_map.cpp:189,216", ("k_directed_match",)),
+    ("regularize1Iter+updateInverseDepth", "edge_map.cpp:220-259, core.cpp:417-456 (untimed in the reference)",
+     ("k_regularize", "k_depth_ekf")),
+)
+
+
+def stage_us(per_frame: dict) -> dict:
+    out = {}
+    for name, site, prefixes in STAGES:
+        us = sum(v for k, v in per_frame.items() if k.startswith(prefixes))
+        out[name] = {"us_per_frame": round(us, 3), "reference_tick_site": site}
+    return out
+
+
+def percentiles_ms(stamps_s) -> dict:
+    """p50 / p99 / mean of the intervals between consecutive frame completions."""
+    d = np.diff(np.asarray(stamps_s, np.float64)) * 1e3
+    if d.size == 0:
+        return {"p50": None, "p99": None, "mean": None}
+    return {"p50": float(np.percentile(d, 50)), "p99": float(np.percentile(d, 99)), "mean": float(d.mean())}
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (rank r -> GPU r) BEFORE this process
+    makes any GPU call, pass rank 0's JSON line through, fail if any rank fails. (The driver's
+    `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE itself and never comes here.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    if any(codes):
+        print(f"bench.py --gpus {n}: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,7 +157,12 @@ def main():
     ap.add_argument("--base-frames", type=int, default=24, help="distinct rendered frames (ping-pong replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--control-plane-only", action="store_true",
+                    help="rehearsal without a GPU: rank launch, rendezvous, barrier and max-over-ranks only (value = null)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     # The contract is ONE JSON line on stdout. Native libraries write there too (gloo reports its mesh connections on
     # stdout, "[Gloo] Rank 0 is connected to ..."): everything this process prints before the result goes to stderr.
@@ -113,11 +172,25 @@ def main():
 
     from rebvio_amd import shard
     rank, local_rank, world = shard.env_ranks()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     import torch.distributed as dist
+
+    if args.control_plane_only:
+        shard.init_group("gloo", rank, world)
+        if world > 1:
+            dist.barrier()
+        tmax = shard.max_over_ranks(float(rank + 1), world, "cpu")
+        if rank == 0:
+            os.dup2(real_stdout, 1)
+            print(json.dumps({"metric": "control plane rehearsal", "value": None, "n_gpus": world, "max_over_ranks": tmax}),
+                  flush=True)
+            os.dup2(2, 1)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
@@ -164,7 +237,7 @@ def main():
     ctx = B.Context(B.default_params(H, W, **kw))
     dev = ctx.upload_frames(frames)
     npx = W * H
-    order = synth.pingpong_indices(args.base_frames, warmup + steps + 64)
+    order = synth.pingpong_indices(args.base_frames, warmup + steps + 64)  # GPU leg only; the CPU leg builds its own list
 
     def push(i):
         return ctx.push_frame_u8_device(dev + int(order[i]) * npx, i * 50000)
@@ -204,10 +277,12 @@ def main():
     ctx.profile(True, only=dominant, stride=max(8, (steps * launches_per_frame(dominant.split("<")[0])) // 200))
     statuses = []
     matches = []
+    push_done = np.zeros(steps, np.float64)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for j in range(steps):
         out, n = push(k)
+        push_done[j] = time.perf_counter()  # a push returns once the pair in flight has been completed (one host sync per frame)
         statuses.append(out.status)
         matches.append(out.klm_num)
         k += 1
@@ -248,7 +323,12 @@ def main():
             "config": {"workload": cfg["name"], "streams": world, "keylines": n_keylines,
                        "mean_matches": float(np.mean([m for m in matches if m > 0])) if any(m > 0 for m in matches) else 0.0,
                        "frames_in_hbm": args.base_frames, "parallelism": f"{world} independent streams, 1 per GPU",
-                       "rank0_numa_node": numa_node},
+                       "rank0_numa_node": numa_node,
+                       "pose_tolerance": "keyline set/order and every per-keyline output bit-exact vs the CPU restatement; pair "
+                                         "velocity within 5e-3 (rel.) of the restatement run with double-accumulated sums - the "
+                                         "sequential-fp32 restatement itself is 0.25-4.8 % from that (tests/test_parity_gpu.py)"},
+            "frame_ms": percentiles_ms(push_done),
+            "stage_us": stage_us(per_frame),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dominant),
                          "avg_launch_us": dom_us, "launches": dom[1], "algorithmic_bytes_per_launch": ab,
@@ -257,7 +337,7 @@ def main():
             "kernel_us_per_frame": {kname: round(v, 3) for kname, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(frames, cam, cfg, order, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(frames, cam, cfg, args.base_frames, args.cpu_seconds)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(result), flush=True)
@@ -266,24 +346,42 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(frames, cam, cfg, order, seconds):
-    """The CPU oracle (faithful port of the reference path: the reference itself cannot be built here) timed
-    on this host, 2 threads per stream like the reference's detect/track workers (rebvio.cpp:28-29)."""
+def cpu_baseline(frames, cam, cfg, base_frames, seconds):
+    """The CPU oracle (faithful port of the reference path: the reference itself cannot be built here) timed on this
+    host: 2 threads per stream like the reference's detect/track workers (rebvio.cpp:28-29) = `value`, plus the serial
+    1-thread figure, p50/p99 frame time and ms per stage at the reference's REBVIO_TIMER tick sites.
+    Bounded sample of the same stream: `seconds` of CPU work split 2:1 between the two legs; the index list is the
+    leg's own, and every rate is frames actually run / seconds measured."""
     from oracle import oracle_py as O
+    from rebvio_amd import synth
     try:
         path = O.build(native=True)  # -O3 -march=native for the machine the bench runs on
     except Exception:
         path = None
     kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=cfg["keylines_ref"], keylines_max=cfg["keylines_max"])
     p = O.default_params(cam.height, cam.width, **kw)
-    probe = O.Oracle(p, path).run_stream(frames, order[:24], threads=2)
-    per = probe["seconds"] / 24
-    n = int(min(max(seconds / per, 30), 1000))
-    res = O.Oracle(p, path).run_stream(frames, order[:n], threads=2)
-    return {"value": n / res["seconds"], "unit": "frames/s", "cores": 2, "kind": "port",
-            "sample": f"first {n} frames of the same {cam.width}x{cam.height} stream, detect || track on 2 threads "
-                      f"(g++ -O3 -march=native -ffp-contract=off), {os.cpu_count()} host cpus visible",
-            "keylines": int(np.median(res["keyline_counts"][20:])) if n > 20 else int(res["keyline_counts"][-1])}
+    probe_idx = synth.pingpong_indices(base_frames, 24)
+    probe = O.Oracle(p, path).run_stream(frames, probe_idx, threads=2)
+    per = probe["seconds"] / probe["frames"]
+    n2 = int(min(max(seconds * (2.0 / 3.0) / per, 30), 1000))
+    idx2 = synth.pingpong_indices(base_frames, n2)
+    res = O.Oracle(p, path).run_stream(frames, idx2, threads=2)
+    n1 = max(20, n2 // 4)  # the serial leg costs ~2x per frame: a quarter of the frames = the remaining third of the budget
+    idx1 = synth.pingpong_indices(base_frames, n1)
+    res1 = O.Oracle(p, path).run_stream(frames, idx1, threads=1)
+    skip = min(20, res["frames"] // 2)  # servo warm-up of the sample (keyline count not settled yet)
+    stage_ms = {k: v / res1["frames"] * 1e3 for k, v in res1["stage_seconds"].items()}
+    return {"value": res["frames"] / res["seconds"], "unit": "frames/s", "cores": 2, "kind": "port",
+            "sample": f"first {res['frames']} frames of the same {cam.width}x{cam.height} stream, detect || track on 2 threads "
+                      f"(g++ -O3 -march=native -ffp-contract=off), {os.cpu_count()} host cpus visible; serial leg: first "
+                      f"{res1['frames']} frames on 1 thread",
+            "frames_run": int(res["frames"]), "seconds": res["seconds"],
+            "keylines": int(np.median(res["keyline_counts"][skip:])),
+            "frame_ms": percentiles_ms(res["frame_done_s"][skip:]),
+            "one_thread": {"value": res1["frames"] / res1["seconds"], "unit": "frames/s", "cores": 1,
+                           "frames_run": int(res1["frames"]), "seconds": res1["seconds"],
+                           "frame_ms": percentiles_ms(res1["frame_done_s"][min(20, res1["frames"] // 2):]),
+                           "stage_ms_per_frame": {k: round(v, 4) for k, v in stage_ms.items()}}}
 
 
 if __name__ == "__main__":

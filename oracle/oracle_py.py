@@ -114,6 +114,8 @@ def lib(path: str | None = None):
         "orc_so3_exp": (None, [fp, fp]),
         "orc_sym6_solve": (None, [fp, fp, fp]),
         "orc_run_stream": (C.c_double, [vp, C.POINTER(C.c_uint8), ip, C.c_int, C.c_int, ip, ip, fp]),
+        "orc_run_stream_ex": (C.c_double, [vp, C.POINTER(C.c_uint8), ip, C.c_int, C.c_int, ip, ip, fp, C.POINTER(C.c_double)]),
+        "orc_stage_seconds": (None, [vp, C.POINTER(C.c_double), C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -324,7 +326,19 @@ class Oracle:
         kc = np.zeros(n, np.int32)
         mc = np.zeros(n, np.int32)
         pose = np.zeros((n, 6), np.float32)
+        done = np.zeros(n, np.float64)
         ip = C.POINTER(C.c_int)
-        secs = self.L.orc_run_stream(self.h, frames_u8.ctypes.data_as(C.POINTER(C.c_uint8)), idx.ctypes.data_as(ip), n, threads,
-                                     kc.ctypes.data_as(ip), mc.ctypes.data_as(ip), pose.ctypes.data_as(C.POINTER(C.c_float)))
-        return dict(seconds=secs, keyline_counts=kc, match_counts=mc, pose=pose)
+        self.stage_seconds(reset=True)
+        secs = self.L.orc_run_stream_ex(self.h, frames_u8.ctypes.data_as(C.POINTER(C.c_uint8)), idx.ctypes.data_as(ip), n, threads,
+                                        kc.ctypes.data_as(ip), mc.ctypes.data_as(ip), pose.ctypes.data_as(C.POINTER(C.c_float)),
+                                        done.ctypes.data_as(C.POINTER(C.c_double)))
+        return dict(seconds=secs, frames=n, keyline_counts=kc, match_counts=mc, pose=pose, frame_done_s=done,
+                    stage_seconds=self.stage_seconds())
+
+    STAGES = ("detect", "buildDistanceField", "minimizeVel", "extRotVel", "directedMatch", "other_track")
+
+    def stage_seconds(self, reset=False) -> dict:
+        """Wall seconds accumulated at the reference's REBVIO_TIMER tick sites (rebvio_oracle.h: orc_stage_seconds)."""
+        out = (C.c_double * 6)()
+        self.L.orc_stage_seconds(self.h, out, int(bool(reset)))
+        return dict(zip(self.STAGES, [float(v) for v in out]))

@@ -822,7 +822,20 @@ struct orc_ctx {
   float meanA[4][3];
   // estimateLs4Acceleration statics (core.cpp:287-293), per instance here
   float ls4_V[3], ls4_V0[3], ls4_V1[3], ls4_V2[3], ls4_V3[3], ls4_T[5], ls4_Dt[4];
+  // wall seconds accumulated at the reference's REBVIO_TIMER tick sites (orc_stage_seconds): 0 detect
+  // (edge_detector.cpp:31,41), 1 buildDistanceField (core.cpp:34-36), 2 minimizeVel (core.cpp:152,187), 3 extRotVel
+  // (core.cpp:193,258), 4 directedMatch (edge_map.cpp:189,216), 5 everything else of the pair step (untimed in the reference)
+  double stage_acc[6] = {0, 0, 0, 0, 0, 0};
 };
+
+namespace {
+struct StageTimer {
+  double* acc;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(double* a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+  ~StageTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 namespace {
 
@@ -1572,6 +1585,7 @@ int orc_filter_width(orc_ctx* c, int filter, int pass) { return c->filter[filter
 
 orc_map* orc_detect(orc_ctx* c, const float* img, uint64_t ts_us) {
   // EdgeDetector::detect (edge_detector.cpp:30-43)
+  StageTimer tick(&c->stage_acc[0]);
   orc_params& P = c->p;
   if (P.gain > 0) {
     c->det_threshold -= P.gain * float(P.keylines_ref - c->keylines_count);
@@ -1698,10 +1712,14 @@ int orc_track_pair(orc_ctx* c, orc_map* old_map, orc_map* new_map, const float* 
   // Rebvio::stateEstimationProcess body (rebvio.cpp:135-259), accelerometer/SAB branch excluded.
   const orc_params& P = c->p;
   std::memset(out, 0, sizeof(*out));
+  StageTimer tick_pair(&c->stage_acc[5]);  // whole pair step; the four timed stages are subtracted in orc_stage_seconds
   M3 P_V = m3_scale(m3_identity(), std::numeric_limits<float>::max());
   M3 R = m3_identity();
 
-  orc_build_distance_field(c, new_map);  // rebvio.cpp:142
+  {
+    StageTimer tick(&c->stage_acc[1]);
+    orc_build_distance_field(c, new_map);  // rebvio.cpp:142
+  }
 
   if (R_prior) R = m3_from(R_prior);  // rebvio.cpp:163
   {                                   // R.T() = SO3(Bg)*R.T()  (rebvio.cpp:164)
@@ -1716,11 +1734,17 @@ int orc_track_pair(orc_ctx* c, orc_map* old_map, orc_map* new_map, const float* 
 
   float Vg[3] = {0, 0, 0};
   M3 P_Vg;
-  out->F = minimize_vel(c, old_map, Vg, P_Vg, &out->lm_accept_mask, &out->sigma_rho_min);  // rebvio.cpp:169
-  forward_match(old_map, new_map);                                                            // rebvio.cpp:172
+  {
+    StageTimer tick(&c->stage_acc[2]);
+    out->F = minimize_vel(c, old_map, Vg, P_Vg, &out->lm_accept_mask, &out->sigma_rho_min);  // rebvio.cpp:169
+  }
+  forward_match(old_map, new_map);  // rebvio.cpp:172
 
   float Xv[6], W_Xv[36];
-  out->ext_ok = ext_rot_vel(c, Vg, W_Xv, Xv, nullptr);  // rebvio.cpp:177
+  {
+    StageTimer tick(&c->stage_acc[3]);
+    out->ext_ok = ext_rot_vel(c, Vg, W_Xv, Xv, nullptr);  // rebvio.cpp:177
+  }
   float Xgv[6], W_Xgv[36];
   std::memcpy(Xgv, Xv, sizeof(Xv));
   std::memcpy(W_Xgv, W_Xv, sizeof(W_Xv));
@@ -1774,7 +1798,10 @@ int orc_track_pair(orc_ctx* c, orc_map* old_map, orc_map* new_map, const float* 
     out->status = 1;
     return 1;
   }
-  out->klm_num = directed_match(c, new_map, old_map, V, P_V, Rgva, &out->kf_matches, P.search_range);  // rebvio.cpp:245
+  {
+    StageTimer tick(&c->stage_acc[4]);
+    out->klm_num = directed_match(c, new_map, old_map, V, P_V, Rgva, &out->kf_matches, P.search_range);  // rebvio.cpp:245
+  }
   if ((unsigned)out->klm_num < P.global_min_matches_threshold) {                                         // rebvio.cpp:247
     out->status = 2;
     return 2;
@@ -1826,8 +1853,20 @@ void orc_estimate_ls4_acceleration(orc_ctx* c, const float vel[3], float acc[3],
 void orc_so3_exp(const float w[3], float R[9]) { m3_to(so3_exp(w), R); }
 void orc_sym6_solve(const float A[36], const float b[6], float x[6]) { sym_pinv_solve<6>(A, b, x); }
 
+void orc_stage_seconds(orc_ctx* c, double out[6], int reset) {
+  for (int i = 0; i < 5; ++i) out[i] = c->stage_acc[i];
+  out[5] = c->stage_acc[5] - c->stage_acc[1] - c->stage_acc[2] - c->stage_acc[3] - c->stage_acc[4];
+  if (reset)
+    for (double& v : c->stage_acc) v = 0.0;
+}
+
 double orc_run_stream(orc_ctx* c, const uint8_t* frames, const int* idx, int nframes, int threads, int* keyline_counts,
                       int* match_counts, float* pose_out) {
+  return orc_run_stream_ex(c, frames, idx, nframes, threads, keyline_counts, match_counts, pose_out, nullptr);
+}
+
+double orc_run_stream_ex(orc_ctx* c, const uint8_t* frames, const int* idx, int nframes, int threads, int* keyline_counts,
+                         int* match_counts, float* pose_out, double* frame_done_s) {
   const size_t npx = (size_t)c->p.rows * c->p.cols;
   auto to_float = [&](int i, std::vector<float>& img) {
     const uint8_t* src = frames + (size_t)idx[i] * npx;
@@ -1844,6 +1883,10 @@ double orc_run_stream(orc_ctx* c, const uint8_t* frames, const int* idx, int nfr
     }
   };
   auto t0 = std::chrono::steady_clock::now();
+  // frame_done_s[i] = seconds since the start at which frame i had been detected AND tracked against its predecessor
+  auto stamp = [&](int i) {
+    if (frame_done_s) frame_done_s[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
   if (threads <= 1) {
     std::vector<float> img;
     orc_map* prev = nullptr;
@@ -1855,6 +1898,7 @@ double orc_run_stream(orc_ctx* c, const uint8_t* frames, const int* idx, int nfr
         track(prev, m, i);
         orc_map_free(prev);
       }
+      stamp(i);
       prev = m;
     }
     if (prev) orc_map_free(prev);
@@ -1895,6 +1939,7 @@ double orc_run_stream(orc_ctx* c, const uint8_t* frames, const int* idx, int nfr
         track(prev, it.second, it.first);
         orc_map_free(prev);
       }
+      stamp(it.first);
       prev = it.second;
     }
     det.join();

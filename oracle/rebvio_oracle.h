@@ -165,6 +165,13 @@ void orc_sym6_solve(const float A[36], const float b[6], float x[6]);
  * Returns wall seconds; optional per-frame keyline counts / match counts. */
 double orc_run_stream(orc_ctx* c, const uint8_t* frames, const int* idx, int nframes, int threads,
                       int* keyline_counts, int* match_counts, float* pose_out /* nframes*6: Vg,dWgv */);
+/* The same, additionally reporting when each frame was finished (seconds since the start; frame time percentiles). */
+double orc_run_stream_ex(orc_ctx* c, const uint8_t* frames, const int* idx, int nframes, int threads,
+                         int* keyline_counts, int* match_counts, float* pose_out, double* frame_done_s);
+/* Wall seconds accumulated so far at the reference's REBVIO_TIMER tick sites (util/timer.hpp:18-32): out[0] detect
+ * (edge_detector.cpp:31,41), [1] buildDistanceField (core.cpp:34-36), [2] minimizeVel (core.cpp:152,187), [3] extRotVel
+ * (core.cpp:193,258), [4] directedMatch (edge_map.cpp:189,216), [5] the rest of the pair step. reset != 0 clears them. */
+void orc_stage_seconds(orc_ctx* c, double out[6], int reset);
 
 #ifdef __cplusplus
 }
