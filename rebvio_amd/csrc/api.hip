@@ -16,9 +16,6 @@
 #include <string>
 #include <vector>
 
-#include <csetjmp>
-#include <csignal>
-
 #include "common.hpp"
 #include "hostmath.hpp"
 
@@ -279,37 +276,6 @@ namespace {
 // events of a map may only be waited on once the detect worker has recorded them
 inline void wait_enqueued(rebvio_hip_map* m) {
   while (!m->enqueued.load(std::memory_order_acquire)) std::this_thread::yield();
-}
-
-// Can this thread store into `p` (device memory mapped through the PCIe BAR)? A store to an unmapped / inaccessible
-// range raises SIGSEGV or SIGBUS: caught for the duration of the probe only, other threads' faults are passed on.
-thread_local sigjmp_buf* t_probe_jmp = nullptr;
-struct sigaction g_probe_old_segv, g_probe_old_bus;
-void probe_fault_handler(int sig) {
-  if (t_probe_jmp) siglongjmp(*t_probe_jmp, 1);
-  sigaction(sig, sig == SIGSEGV ? &g_probe_old_segv : &g_probe_old_bus, nullptr);  // not ours: previous disposition, again
-  raise(sig);
-}
-bool host_can_store(volatile unsigned* p, unsigned value) {
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  struct sigaction sa {};
-  sa.sa_handler = probe_fault_handler;
-  sigemptyset(&sa.sa_mask);
-  sigaction(SIGSEGV, &sa, &g_probe_old_segv);
-  sigaction(SIGBUS, &sa, &g_probe_old_bus);
-  sigjmp_buf jb;
-  bool ok = false;
-  t_probe_jmp = &jb;
-  if (sigsetjmp(jb, 1) == 0) {
-    *p = value;
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    ok = true;
-  }
-  t_probe_jmp = nullptr;
-  sigaction(SIGSEGV, &g_probe_old_segv, nullptr);
-  sigaction(SIGBUS, &g_probe_old_bus, nullptr);
-  return ok;
 }
 
 size_t part_call_stride(const rebvio_hip_ctx* c) { return (size_t)c->maxblocks * kPartStride; }
@@ -707,6 +673,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   const int nr = 2 * (int)p->search_range;
   if (nr < 2 || (long long)p->keylines_max * nr >= (1ll << kDfSeqBits) || (int)p->search_range > 255)
     return fail_msg("keylines_max * 2*search_range must stay below 2^23", -3);
+  if (p->keylines_max < 1 || div_up(p->keylines_max, 256) > kMaxRecBlocks)
+    return fail_msg("keylines_max must be in 1..65536 (the LM reduction stages at most 256 record groups of 256 keylines)", -3);
   if (!(p->pixel_uncertainty_match >= 0.0f) || p->search_range + 2.0f * p->pixel_uncertainty_match + 2.0f > 260.0f)
     return fail_msg("search_range + 2 * pixel_uncertainty_match must stay below 258 (probe sequence buffer)", -3);
   int ndev = 0;
@@ -840,24 +808,29 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   }
   HIPCHK(hipMalloc(&c->fscratch, 64 * sizeof(float)));
   {
-    // Where the host leaves a pair's glue for the pre-enqueued B-chain. Pinned host memory: the first kernel's read is a
-    // PCIe round trip (~1.7 us). REBVIO_HIP_GLUE=vram on a large-BAR host: fine-grained DEVICE memory that the host
-    // stores into through the BAR (posted writes) and the GPU reads locally (tools/hostvram_probe.hip).
-    // Default: device memory where the device reports a large BAR AND a probe store from this thread arrives (checked by
-    // copying it back); pinned host memory otherwise, or with REBVIO_HIP_GLUE=pinned. Measured: +1.5 % frames/s.
+    // Where the host leaves a pair's glue for the pre-enqueued B-chain. Default: pinned host memory (the first kernel's
+    // read is a PCIe round trip, ~1.7 us). REBVIO_HIP_GLUE=vram (explicit opt-in, large-BAR hosts only): fine-grained
+    // DEVICE memory that the host stores into through the BAR (posted writes) and the GPU reads locally
+    // (tools/hostvram_probe.hip; measured +1.5 % frames/s). The placement is decided from the device attribute alone:
+    // the library installs no signal handlers and never probes a mapping with a faulting store.
     const char* e = std::getenv("REBVIO_HIP_GLUE");
     hipDeviceProp_t prop{};
-    const bool want_vram = !(e && std::strcmp(e, "pinned") == 0) && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.isLargeBar;
+    const bool want_vram = e && std::strcmp(e, "vram") == 0 && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.isLargeBar;
+    if (e && std::strcmp(e, "vram") == 0 && !want_vram)
+      std::fprintf(stderr, "[rebvio_hip] REBVIO_HIP_GLUE=vram ignored: device %d does not report a large BAR\n", c->device);
     constexpr size_t kStride = 256;  // one slot per 256 bytes, flags in their own 256 bytes
     static_assert(sizeof(GlueDev) <= kStride, "slot stride");
     const size_t vram_bytes = (rebvio_hip_ctx::kSlots + 1) * kStride;
     bool vram_ok = false;
     if (want_vram && hipExtMallocWithFlags(&c->glue_vram, vram_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
-      unsigned back = 0;
-      vram_ok = hipMemset(c->glue_vram, 0, vram_bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-                host_can_store(reinterpret_cast<volatile unsigned*>((char*)c->glue_vram + vram_bytes - sizeof(unsigned)), 0xA5C3F00Du) &&
-                hipMemcpy(&back, (char*)c->glue_vram + vram_bytes - sizeof(unsigned), sizeof(back), hipMemcpyDeviceToHost) == hipSuccess &&
-                back == 0xA5C3F00Du;
+      vram_ok = hipMemset(c->glue_vram, 0, vram_bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+      if (vram_ok) {  // a large-BAR device maps its allocations into the host address space: store, copy back, compare
+        unsigned back = 0;
+        volatile unsigned* probe = reinterpret_cast<volatile unsigned*>((char*)c->glue_vram + vram_bytes - sizeof(unsigned));
+        *probe = 0xA5C3F00Du;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        vram_ok = hipMemcpy(&back, (const void*)probe, sizeof(back), hipMemcpyDeviceToHost) == hipSuccess && back == 0xA5C3F00Du;
+      }
       if (!vram_ok) {
         (void)hipFree(c->glue_vram);
         c->glue_vram = nullptr;

@@ -20,6 +20,7 @@ constexpr unsigned kDfSeqMask = (1u << kDfSeqBits) - 1u;
 constexpr int kPartStride = 16;     // floats per block record of k_try_vel
 constexpr int kXrvStride = 32;      // floats per block record of k_ext_rot_vel
 constexpr int kMaxLmCalls = 8;
+constexpr int kMaxRecBlocks = 256;   // record groups (256 keylines each) the LM reduction stages in LDS: keylines_max <= 65536
 constexpr int kDetRing = 4;         // DetState ring depth (distance-field stream may lag the detect stream)
 constexpr float kResidualCarry = -1.0f;  // marker: "|fi| carried in from an earlier block" (see try_vel)
 

@@ -465,7 +465,7 @@ __device__ __forceinline__ float auto_threshold_from(const MapState& st, float p
 __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const float4* __restrict__ stash,
                                                       const unsigned long long* __restrict__ bits,
                                                       const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
-                                                      DetState* __restrict__ det_out, const MapState* __restrict__ prev_st,
+                                                      DetState* __restrict__ det_out, const MapState* prev_st,
                                                       int clear_df) {
   const int R = p.rows, C = p.cols;
   const int r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.x * 64 + threadIdx.x;
@@ -480,6 +480,9 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
     for (int i = lane; i < R; i += 64) tp += rowcount[i];
     const int total = wave_sum(tp);
     if (lane == 0) {
+      // auto_threshold_ as left by the previous detect's tuneThreshold (its min/max are final: same stream). Read before
+      // this map's scalars are reset: the pool may hand the previous frame's map back for this one (prev_st == m.st).
+      const float prev_auto = prev_st ? auto_threshold_from(*prev_st, det_in->auto_threshold) : det_in->auto_threshold;
       const int n = min(total, p.kmax);
       m.st->n = n;
       m.st->total = total;
@@ -490,8 +493,7 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
       m.st->reg_count = 0;
       det_out->threshold = servo_threshold(p, *det_in);
       det_out->count = n;
-      // auto_threshold_ as left by the previous detect's tuneThreshold (its min/max are final: same stream)
-      det_out->auto_threshold = prev_st ? auto_threshold_from(*prev_st, det_in->auto_threshold) : det_in->auto_threshold;
+      det_out->auto_threshold = prev_auto;
     }
   }
   if (c >= C) return;

@@ -309,7 +309,6 @@ __device__ __forceinline__ void lm_step_regs(LmState& s, const float (&red)[10],
 // Shared prologue: fixed-order reduction of the previous tryVel call's block records + carry-in of the
 // "last written fi" (oracle header, H3) for this workgroup. The records are staged in LDS by one coalesced
 // pass of the whole workgroup (one memory round trip), then summed in block order from LDS.
-constexpr int kMaxRecBlocks = 256;  // keylines_max <= 65536
 
 // Stages the records of ALL launched workgroups (grid size is known without reading the keyline count, so these
 // loads are in flight together with the first own-keyline loads); records beyond the live count are never summed.

@@ -63,9 +63,21 @@ def test_create_without_gpu_fails_loudly(backend):
 
 def test_invalid_params_rejected(backend):
     # validated before any device is touched
-    for kw in (dict(rows=16), dict(cols=642), dict(quantile_num_bins=500), dict(keylines_max=200000)):
+    # keylines_max 65537: one more than the 256 record groups the LM reduction stages in LDS (search_range 20 keeps the
+    # distance-field key bound, the only other limit on it, satisfied)
+    for kw in (dict(rows=16), dict(quantile_num_bins=500), dict(keylines_max=200000),
+               dict(keylines_max=65537, search_range=20.0), dict(keylines_max=0)):
         p = backend.default_params(480, 640)
         for k, v in kw.items():
             setattr(p, k, v)
         with pytest.raises(backend.HipError):
             backend.Context(p)
+
+
+def test_library_installs_no_signal_handlers(backend):
+    """Round 1 probed a BAR mapping under a process-wide SIGSEGV/SIGBUS handler; a library inside a ROS node must not touch
+    signal dispositions. The shared object does not even import the calls."""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", backend.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for sym in ("sigaction", "signal", "siglongjmp", "__sigsetjmp"):
+        assert not re.search(rf"\b{sym}\b", und), sym

@@ -8,6 +8,8 @@ Bars:
   * tolerance (stated at each assert): the fp32 sums over ~15k keylines (tryVel: score/JtJ/JtF, extRotVel:
     JtJ/JtF) — the oracle adds sequentially in index order, the GPU uses a fixed butterfly/tree order.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -134,6 +136,28 @@ def test_detect_constant_and_empty(orc_mod, B):
     assert om.size() == 0 and gm.size() == 0
     assert (gm.mask() == -1).all()
     assert np.float32(gm.threshold) == np.float32(om.threshold)
+
+
+def test_detect_reuses_the_previous_frames_map(orc_mod, B, small_stream):
+    """Pool exhausted: every detect gets the map the previous frame has just released (prev_st aliases the map's own
+    scalars inside k_keyline_emit). The auto threshold carried into an EMPTY frame must still be the previous frame's
+    tuneThreshold value, not the reset min/max (+inf)."""
+    frames, cam = small_stream
+    kw = dict(keylines_ref=1500, keylines_max=2000, map_pool=4)
+    orc = orc_mod.Oracle(params_for(orc_mod, cam, **{k: v for k, v in kw.items() if k != "map_pool"}))
+    ctx = B.Context(params_for(B, cam, **kw))
+    held = [ctx.detect_u8(frames[i]) for i in range(3)]  # three of the four pooled maps stay in use
+    for i in range(3):
+        orc.detect_u8(frames[i])
+    blank = np.full((cam.height, cam.width), 100, np.uint8)
+    for i, f in enumerate([frames[3], frames[4], blank, frames[5], blank, blank]):
+        om, gm = orc.detect_u8(f), ctx.detect_u8(f)
+        assert om.size() == gm.size(), i
+        assert_keylines_equal(om.keylines(), gm.keylines())
+        assert np.float32(gm.threshold) == np.float32(om.threshold), (i, gm.threshold, om.threshold)
+        assert np.isfinite(gm.threshold)
+        gm.release()
+    assert len([m for m in held if m.h]) == 3
 
 
 def test_detect_small_keylines_max(orc_mod, B, small_stream):
@@ -522,10 +546,10 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
     order = synth.pingpong_indices(len(frames), 40)
     npx = cam.width * cam.height
 
-    def run(lead, slim, glue="auto"):
+    def run(lead, slim, glue="pinned"):
         monkeypatch.setenv("REBVIO_HIP_LEAD", str(lead))
         monkeypatch.setenv("REBVIO_HIP_SLIM_OPS", str(slim))
-        monkeypatch.setenv("REBVIO_HIP_GLUE", glue)  # "pinned": host memory; anything else: device memory where it works
+        monkeypatch.setenv("REBVIO_HIP_GLUE", glue)  # "pinned" (default): host memory; "vram": device memory behind a large BAR
         ctx = B.Context(params_for(B, cam, **KW_C2))
         dev = ctx.upload_frames(frames)
         rec = []
@@ -540,7 +564,7 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
 
     base = run(3, 0)
     assert len(base) >= 30
-    for lead, slim, glue in ((3, 1, "auto"), (5, 1, "auto"), (8, 1, "auto"), (5, 0, "auto"), (5, 1, "pinned")):
+    for lead, slim, glue in ((3, 1, "pinned"), (5, 1, "pinned"), (8, 1, "pinned"), (5, 0, "pinned"), (5, 1, "vram")):
         got = run(lead, slim, glue)
         assert len(got) >= len(order) - lead - 3
         assert got == base[:len(got)], (lead, slim, glue)
@@ -652,3 +676,27 @@ def test_pair_step_nan_path(orc_mod, B, small_stream):
     assert po.status == 1 and pg.status == 1
     assert po.klm_num == 0 and pg.klm_num == 0
     assert (g1.keylines()["match_id"] < 0).all() and (o1.keylines()["match_id"] < 0).all()
+
+
+def test_context_creation_leaves_signal_dispositions_untouched(B):
+    """rebvio_hip_create decides the glue placement from device attributes; SIGSEGV / SIGBUS dispositions are the
+    process's own before and after (both placements)."""
+    import ctypes
+    import signal
+    libc = ctypes.CDLL(None, use_errno=True)
+
+    def disposition(sig):
+        buf = ctypes.create_string_buffer(152)  # struct sigaction on x86-64 Linux
+        assert libc.sigaction(int(sig), None, buf) == 0
+        return buf.raw
+
+    for glue in ("pinned", "vram"):
+        os.environ["REBVIO_HIP_GLUE"] = glue
+        try:
+            before = disposition(signal.SIGSEGV), disposition(signal.SIGBUS)
+            ctx = B.Context(B.default_params(96, 128, keylines_ref=500, keylines_max=1000))
+            after = disposition(signal.SIGSEGV), disposition(signal.SIGBUS)
+            ctx.close()
+        finally:
+            os.environ.pop("REBVIO_HIP_GLUE", None)
+        assert before == after, glue
