@@ -94,10 +94,11 @@ void rebvio_hip_default_params(rebvio_hip_params* p, int rows, int cols);
 /* Replaces the constructors EdgeDetector(camera, config) (edge_detector.cpp:17-26), ScaleSpace /
  * FastGaussian (scale_space.cpp:14-41,184-190), Core(camera, config) + DistanceField (core.cpp:17-24,
  * core.hpp:22-28): allocates every device buffer once.
- * Sensor sizes: rows, cols >= 32 and cols a multiple of 4 (the row / column scans move 16-byte vectors); -3 otherwise.
+ * Sensor sizes: rows, cols >= 32, any width (the integral images get a row pitch of cols rounded up to 4 internally),
+ * cols <= 4096, rows <= 2548 (LDS-staged scan strips); -3 otherwise.
  * Also -3: search_range > 255 or search_range + 2 * pixel_uncertainty_match >= 258 (per-wave probe sequence buffer),
- * quantile_num_bins outside 1..128, keylines_max * 2 * search_range >= 2^23 (distance-field key encoding).
- * Every sensor the reference ships a camera for satisfies this (752x480, camera.hpp:25-45). */
+ * quantile_num_bins outside 1..128, keylines_max * 2 * search_range >= 2^23 (distance-field key encoding),
+ * keylines_max outside 1..65536 (the LM reduction stages at most 256 record groups of 256 keylines in LDS). */
 int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out);
 void rebvio_hip_destroy(rebvio_hip_ctx* ctx);
 

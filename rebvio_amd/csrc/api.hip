@@ -664,9 +664,9 @@ int rebvio_hip_set_gyro_state(rebvio_hip_ctx* c, const float Bg[3], const float 
 
 int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   *out = nullptr;
-  if (p->rows < 32 || p->cols < 32 || (p->cols % 4) != 0) return fail_msg("rows/cols must be >= 32 and cols % 4 == 0", -3);
+  if (p->rows < 32 || p->cols < 32) return fail_msg("rows/cols must be >= 32", -3);
   if (p->cols > 4096) return fail_msg("cols > 4096 unsupported", -3);
-  if ((size_t)(p->rows + 12) * 16 * sizeof(float) > 160 * 1024 || (size_t)(p->cols + 8) * 4 * sizeof(float) > 160 * 1024)
+  if ((size_t)(p->rows + 12) * 16 * sizeof(float) > 160 * 1024 || (size_t)(p->cols + 3 + 8) * 4 * sizeof(float) > 160 * 1024)
     return fail_msg("image too large for the LDS-staged scan strips (rows <= 2548)", -3);
   if (p->quantile_num_bins > 128 || p->quantile_num_bins < 1) return fail_msg("quantile_num_bins must be in 1..128", -3);
   if ((int)p->iterations + 2 > 15) return fail_msg("iterations too large", -3);
@@ -741,9 +741,12 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     c->s_df = c->s_key;
   c->s_cpy = c->s_df;
   const size_t Pn = (size_t)p->rows * p->cols;
+  // the integral-image buffers have a row pitch of cols rounded up to 4 floats (the scans move 16-byte vectors); every
+  // other per-pixel array is dense
+  const size_t Pp = (size_t)p->rows * ((p->cols + 3) & ~3);
   for (int f = 0; f < 2; ++f) {
-    HIPCHK(hipMalloc(&c->sb.a[f], Pn * sizeof(float)));
-    HIPCHK(hipMalloc(&c->sb.b[f], Pn * sizeof(float)));
+    HIPCHK(hipMalloc(&c->sb.a[f], Pp * sizeof(float)));
+    HIPCHK(hipMalloc(&c->sb.b[f], Pp * sizeof(float)));
   }
   HIPCHK(hipMalloc(&c->sb.dog, Pn * sizeof(float)));
   HIPCHK(hipMalloc(&c->sb.mag, Pn * sizeof(float)));

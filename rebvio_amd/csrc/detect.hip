@@ -27,7 +27,9 @@ void upload_tables(const float* recip128, const float* pinv75) {
 
 // FastGaussian::average (scale_space.cpp:69-128): the nine border/interior cases with their distinct
 // operand orders. II is the integral image, d the box width.
-__device__ __forceinline__ float box_avg(const float* __restrict__ II, int r, int c, int d, int R, int C) {
+// `ld` = row pitch of II in floats (cols rounded up to a multiple of 4: the scan kernels move 16-byte vectors; the
+// columns >= C of a row hold prefix values past the image and are never read here: every tap is clamped to C - 1).
+__device__ __forceinline__ float box_avg(const float* __restrict__ II, int r, int c, int d, int R, int C, int ld) {
   const int d2 = d >> 1;
   const bool top = r < d2 + 1, bot = r >= R - d2;
   const bool left = c < d2 + 1, right = c >= C - d2;
@@ -36,19 +38,19 @@ __device__ __forceinline__ float box_avg(const float* __restrict__ II, int r, in
   const int ny = top ? r + d2 + 1 : (bot ? R - r + d2 : d);
   const int nx = left ? c + d2 + 1 : (right ? C - c + d2 : d);
   const float div = c_recip[nx * ny];
-  const float A = II[(size_t)r1 * C + c1];
+  const float A = II[(size_t)r1 * ld + c1];
   float acc;
   if (top) {
-    acc = left ? A : A - II[(size_t)r1 * C + (c - d2 - 1)];
+    acc = left ? A : A - II[(size_t)r1 * ld + (c - d2 - 1)];
   } else {
     const int r2 = r - d2 - 1;
-    const float Cc = II[(size_t)r2 * C + c1];
+    const float Cc = II[(size_t)r2 * ld + c1];
     if (left) {
       acc = A - Cc;
     } else {
       const int c2 = c - d2 - 1;
-      const float B = II[(size_t)r1 * C + c2];
-      const float D = II[(size_t)r2 * C + c2];
+      const float B = II[(size_t)r1 * ld + c2];
+      const float D = II[(size_t)r2 * ld + c2];
       acc = bot ? (((A - Cc) - B) + D) : (((A - B) - Cc) + D);
     }
   }
@@ -58,20 +60,20 @@ __device__ __forceinline__ float box_avg(const float* __restrict__ II, int r, in
 // Straight-line form of box_avg for border pixels: four unconditional (clamped) taps, absent terms replaced by
 // +0 (x - 0 and x + 0 are exact and no -0 can arise from the differences), the operand order of the bottom rows
 // selected by swapping B and C. Same bits as box_avg, no control flow, so the taps of several pixels overlap.
-__device__ __forceinline__ float box_avg_flat(const float* __restrict__ II, int r, int c, int d, int R, int C) {
+__device__ __forceinline__ float box_avg_flat(const float* __restrict__ II, int r, int c, int d, int R, int C, int ld) {
   const int d2 = d >> 1;
   const bool top = r < d2 + 1, bot = r >= R - d2;
   const bool left = c < d2 + 1, right = c >= C - d2;
   const int r1 = (bot && !top) ? R - 1 : r + d2;
-  const int c1 = (right && !left) ? C - 1 : c + d2;
+  const int c1 = min((right && !left) ? C - 1 : c + d2, C - 1);  // (the clamp only acts in the pitch padding, c >= C)
   const int r2 = max(r - d2 - 1, 0), c2 = max(c - d2 - 1, 0);
   const int ny = top ? r + d2 + 1 : (bot ? R - r + d2 : d);
   const int nx = left ? c + d2 + 1 : (right ? C - c + d2 : d);
-  const float div = c_recip[nx * ny];
-  const float A = II[(size_t)r1 * C + c1];
-  const float Bv = II[(size_t)r1 * C + c2];
-  const float Cv = II[(size_t)r2 * C + c1];
-  const float Dv = II[(size_t)r2 * C + c2];
+  const float div = c_recip[max(nx, 0) * ny];
+  const float A = II[(size_t)r1 * ld + c1];
+  const float Bv = II[(size_t)r1 * ld + c2];
+  const float Cv = II[(size_t)r2 * ld + c1];
+  const float Dv = II[(size_t)r2 * ld + c2];
   const float B = left ? 0.0f : Bv;
   const float Cc = top ? 0.0f : Cv;
   const float D = (left || top) ? 0.0f : Dv;
@@ -92,10 +94,10 @@ constexpr int kStrip = 4;   // rows per workgroup: 120 workgroups per 480-row im
 
 // Interior fast path of box_avg for four consecutive columns: rows r1 = r+d2 and r2 = r-d2-1 are read as two
 // 4-float windows each (dword-aligned 16-byte loads) instead of 16 scalar taps. Same operand order as box_avg.
-__device__ __forceinline__ float4 box_avg4_interior(const float* __restrict__ II, int r, int c, int d, int C) {
+__device__ __forceinline__ float4 box_avg4_interior(const float* __restrict__ II, int r, int c, int d, int ld) {
   const int d2 = d >> 1;
-  const float* p1 = II + (size_t)(r + d2) * C + c;
-  const float* p2 = II + (size_t)(r - d2 - 1) * C + c;
+  const float* p1 = II + (size_t)(r + d2) * ld + c;
+  const float* p2 = II + (size_t)(r - d2 - 1) * ld + c;
   const float4 A = *reinterpret_cast<const float4*>(p1 + d2);
   const float4 B = *reinterpret_cast<const float4*>(p1 - d2 - 1);
   const float4 Cc = *reinterpret_cast<const float4*>(p2 + d2);
@@ -109,30 +111,52 @@ __device__ __forceinline__ float4 box_avg4_interior(const float* __restrict__ II
   return o;
 }
 
+// Input images (MODE 0 / 1) are dense (row stride C). Widths that are not a multiple of 4 take element loads guarded at
+// the row end (the vector forms would straddle rows and run past the last one); the columns >= C of the pitch padding
+// read 0. Integral images (MODE 2) have the padded pitch `ld`.
 template <int MODE>
-__device__ __forceinline__ float4 rowscan_fetch(const void* __restrict__ src, int r, int c4, int d, int d2, int R, int C) {
-  const int C4 = C >> 2, c = c4 * 4;
+__device__ __forceinline__ float4 rowscan_fetch(const void* __restrict__ src, int r, int c4, int d, int d2, int R, int C, int ld) {
+  const int c = c4 * 4;
   if (MODE == 0) {
-    const uchar4 u = reinterpret_cast<const uchar4*>(src)[(size_t)r * C4 + c4];
-    return make_float4((float)u.x * 3.0f, (float)u.y * 3.0f, (float)u.z * 3.0f, (float)u.w * 3.0f);
+    if ((C & 3) == 0) {
+      const uchar4 u = reinterpret_cast<const uchar4*>(src)[((size_t)r * C + c) >> 2];
+      return make_float4((float)u.x * 3.0f, (float)u.y * 3.0f, (float)u.z * 3.0f, (float)u.w * 3.0f);
+    }
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(src) + (size_t)r * C;
+    float4 v;
+    v.x = (c < C) ? (float)row[c] * 3.0f : 0.0f;
+    v.y = (c + 1 < C) ? (float)row[c + 1] * 3.0f : 0.0f;
+    v.z = (c + 2 < C) ? (float)row[c + 2] * 3.0f : 0.0f;
+    v.w = (c + 3 < C) ? (float)row[c + 3] * 3.0f : 0.0f;
+    return v;
   } else if (MODE == 1) {
-    return reinterpret_cast<const float4*>(src)[(size_t)r * C4 + c4];
+    if ((C & 3) == 0) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)r * C + c);
+    const float* row = reinterpret_cast<const float*>(src) + (size_t)r * C;
+    float4 v;
+    v.x = (c < C) ? row[c] : 0.0f;
+    v.y = (c + 1 < C) ? row[c + 1] : 0.0f;
+    v.z = (c + 2 < C) ? row[c + 2] : 0.0f;
+    v.w = (c + 3 < C) ? row[c + 3] : 0.0f;
+    return v;
   } else {
     const float* II = reinterpret_cast<const float*>(src);
-    if (r > d2 && r < R - d2 && c > d2 && c + 3 < C - d2) return box_avg4_interior(II, r, c, d, C);
+    if (r > d2 && r < R - d2 && c > d2 && c + 3 < C - d2) return box_avg4_interior(II, r, c, d, ld);
     float4 v;
-    v.x = box_avg_flat(II, r, c, d, R, C);
-    v.y = box_avg_flat(II, r, c + 1, d, R, C);
-    v.z = box_avg_flat(II, r, c + 2, d, R, C);
-    v.w = box_avg_flat(II, r, c + 3, d, R, C);
+    v.x = box_avg_flat(II, r, c, d, R, C, ld);
+    v.y = box_avg_flat(II, r, c + 1, d, R, C, ld);
+    v.z = box_avg_flat(II, r, c + 2, d, R, C, ld);
+    v.w = box_avg_flat(II, r, c + 3, d, R, C, ld);
     return v;
   }
 }
 
 template <int MODE>  // 0: u8 image * 3.0f, 1: fp32 image, 2: box average (width d) of an integral image
 __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, const void* __restrict__ src1,
-                                                 float* __restrict__ dst0, float* __restrict__ dst1, int R, int C, int d0,
+                                                 float* __restrict__ dst0, float* __restrict__ dst1, int R, int Cimg, int d0,
                                                  int d1, int ldw) {
+  // C = row pitch of the integral images = the image width rounded up to a multiple of 4; the chain also runs over the
+  // padding columns (they follow the image's columns, so the image's prefix values do not depend on them)
+  const int C = (Cimg + 3) & ~3;
   extern __shared__ float4 smem4[];
   float* tile = reinterpret_cast<float*>(smem4);
   const int f = blockIdx.y;
@@ -152,9 +176,9 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
   constexpr int kCPP = 64;   // chunks per pass
   for (int base = 0; base < C4; base += kCPP * kBatch) {
     // named registers, not an array (arrays of float4 end up in scratch with this compiler)
-    const float4 v0 = rowscan_fetch<MODE>(src, r, min(base + 0 * kCPP + cb, C4 - 1), d, d2, R, C);
-    const float4 v1 = rowscan_fetch<MODE>(src, r, min(base + 1 * kCPP + cb, C4 - 1), d, d2, R, C);
-    const float4 v2 = rowscan_fetch<MODE>(src, r, min(base + 2 * kCPP + cb, C4 - 1), d, d2, R, C);
+    const float4 v0 = rowscan_fetch<MODE>(src, r, min(base + 0 * kCPP + cb, C4 - 1), d, d2, R, Cimg, C);
+    const float4 v1 = rowscan_fetch<MODE>(src, r, min(base + 1 * kCPP + cb, C4 - 1), d, d2, R, Cimg, C);
+    const float4 v2 = rowscan_fetch<MODE>(src, r, min(base + 2 * kCPP + cb, C4 - 1), d, d2, R, Cimg, C);
     __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first LDS write
 #define RH_RS_ST(k, v)                                                                  \
     {                                                                                   \
@@ -234,7 +258,7 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
 // Narrow strips spread the staging traffic over many CUs. No global-memory latency sits on the chain.
 constexpr int kColStrip = 16;
 
-__global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
+__global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh) {
   extern __shared__ float4 smem4[];
   float* tile = reinterpret_cast<float*>(smem4);  // [kColStrip][ldh]
   float* __restrict__ buf = blockIdx.y ? buf1 : buf0;
@@ -344,20 +368,21 @@ __global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, 
                                                  int d1, float* __restrict__ dog, float* __restrict__ mag,
                                                  float* __restrict__ scale0, float* __restrict__ scale1, int R, int C,
                                                  int* __restrict__ rowcount) {
+  const int ld = (C + 3) & ~3;  // pitch of the integral images
   __shared__ float s0[6][66];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int i = tid; i < 6 * 66; i += 256) {
     const int lr = i / 66, lc = i - lr * 66;
     const int r = r0 + lr - 1, c = c0 + lc - 1;
-    s0[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? box_avg(II0, r, c, d0, R, C) : 0.0f;
+    s0[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? box_avg(II0, r, c, d0, R, C, ld) : 0.0f;
   }
   __syncthreads();
   const int r = r0 + threadIdx.y, c = c0 + threadIdx.x;
   if (r >= R || c >= C) return;
   if (c == 0) rowcount[r] = 0;  // reset for the candidate kernel of this frame
   const float v0 = s0[threadIdx.y + 1][threadIdx.x + 1];
-  const float v1 = box_avg(II1, r, c, d1, R, C);
+  const float v1 = box_avg(II1, r, c, d1, R, C, ld);
   const size_t i = (size_t)r * C + c;
   dog[i] = v1 - v0;
   float m = 0.0f;
@@ -898,7 +923,8 @@ void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, co
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
                         const int widths[2][3], int* rowcount_to_zero) {
   const int R = p.rows, C = p.cols;
-  const int ldw = lds_pitch(C);
+  const int Cp = (C + 3) & ~3;  // pitch of the scan buffers sb.a / sb.b
+  const int ldw = lds_pitch(Cp);
   const size_t shm = (size_t)kStrip * ldw * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -909,7 +935,7 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
     attr_done = true;
   }
   const dim3 g1(div_up(R, kStrip), 1), g2(div_up(R, kStrip), 2);
-  const dim3 c1(div_up(C, kColStrip), 1), c2(div_up(C, kColStrip), 2);
+  const dim3 c1(div_up(Cp, kColStrip), 1), c2(div_up(Cp, kColStrip), 2);
   const int ldh = lds_pitch(R + (4 - R % 4) % 4);
   const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
   // pass 1: both filters share the integral image of the input (scale_space.cpp:175)
@@ -917,15 +943,15 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
     RH_LAUNCH(k_rowscan<0>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
   else
     RH_LAUNCH(k_rowscan<1>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
-  RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, sb.a[0], sb.a[0], R, C, ldh);
+  RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, sb.a[0], sb.a[0], R, Cp, ldh);
   // pass 2: average(width[0]) fused into the row scan, per filter
   RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.a[0], (const void*)sb.a[0], sb.b[0], sb.b[1], R,
                      C, widths[0][0], widths[1][0], ldw);
-  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.b[0], sb.b[1], R, C, ldh);
+  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.b[0], sb.b[1], R, Cp, ldh);
   // pass 3: filter f averages its own integral image
   RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R,
                      C, widths[0][1], widths[1][1], ldw);
-  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.a[0], sb.a[1], R, C, ldh);
+  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.a[0], sb.a[1], R, Cp, ldh);
   const dim3 gt(div_up(C, 64), div_up(R, 4));
   RH_LAUNCH(k_dog_mag, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2],
                      widths[1][2], sb.dog, sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
