@@ -3,11 +3,44 @@
 // the host. Hot methods forward to the gfx950 backend through the C-ABI.
 #pragma once
 
+#include <limits>
 #include <memory>
+#include <vector>
 
 #include "rebvio/edge_map.hpp"
 
 namespace rebvio {
+
+// One cell of the distance field (reference core.hpp:15-18): the keyline whose +-search_range gradient segment passes
+// through the pixel at the smallest |r|, and that |r|.
+struct DistanceFieldElement {
+  int id = {-1};
+  int distance = {std::numeric_limits<int>::max()};
+};
+
+// rebvio::DistanceField (reference core.hpp:20-79). build() runs on the device (rebvio_hip_build_distance_field: the
+// field belongs to the map it is built from and stays in HBM, where tryVel reads it); operator[] reads a host mirror that
+// is downloaded on first use after a build. rows / cols / search_range must be those of the camera stream the map
+// belongs to (the device context is created with them); build() throws std::runtime_error otherwise.
+class DistanceField {
+ public:
+  DistanceField(int rows, int cols, types::Float search_range);
+  ~DistanceField();
+  DistanceField(const DistanceField&) = delete;
+  DistanceField& operator=(const DistanceField&) = delete;
+
+  void build(rebvio::EdgeMap::SharedPtr map);
+  DistanceFieldElement& operator[](int index);
+  rebvio::EdgeMap::SharedPtr map() { return map_; }
+
+ private:
+  void syncMirror();
+  std::vector<DistanceFieldElement> field_;
+  unsigned int rows_, cols_;
+  types::Float search_range_;
+  rebvio::EdgeMap::SharedPtr map_;
+  bool mirror_valid_ = true;
+};
 
 struct CoreConfig {
   types::Float search_range{40.0};
@@ -35,6 +68,14 @@ class Core {
 
   CoreConfig::SharedPtr config();
   void buildDistanceField(rebvio::EdgeMap::SharedPtr map);
+  // Single-keyline forms of the reference's public helpers (core.hpp:122,138,187), evaluated on the host with the
+  // kernels' arithmetic; calculatefJ reads the distance field of buildDistanceField through its host mirror.
+  static bool testfk(const rebvio::types::KeyLine& keyline1, const rebvio::types::KeyLine& keyline2,
+                     const types::Float& similarity_threshold);
+  types::Float calculatefJ(rebvio::EdgeMap::SharedPtr map, int f_inx, types::Float& df_dx, types::Float& df_dy,
+                           rebvio::types::KeyLine& keyline, const types::Float& px, const types::Float& py, int& mnum,
+                           types::Float& fi);
+  void updateInverseDepthARLU(rebvio::types::KeyLine& keyline, rebvio::types::Vector3f& vel);
   types::Float tryVel(rebvio::EdgeMap::SharedPtr map, rebvio::types::Matrix3f& JtJ, rebvio::types::Vector3f& JtF,
                       const rebvio::types::Vector3f& vel, types::Float sigma_rho_min, types::Float* residuals);
   types::Float minimizeVel(rebvio::EdgeMap::SharedPtr map, rebvio::types::Vector3f& vel, rebvio::types::Matrix3f& Rvel);
@@ -59,7 +100,7 @@ class Core {
   rebvio::CoreConfig::SharedPtr config_;
   rebvio::Camera::SharedPtr camera_;
   std::shared_ptr<backend::Session> session_;
-  rebvio::EdgeMap::SharedPtr df_map_;
+  rebvio::DistanceField distance_field_;
   // per-instance history of the two acceleration estimators (function-static in the reference, core.cpp:287-293,335-338)
   types::Vector3f ls4_V_[5];
   types::Float ls4_T_[5], ls4_Dt_[4];

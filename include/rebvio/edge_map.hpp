@@ -47,6 +47,9 @@ class EdgeMap {
   types::Float estimateQuantile(types::Float percentile, int num_bins);
   void rotateKeylines(const rebvio::types::Matrix3f& R);
   int forwardMatch(rebvio::EdgeMap::SharedPtr map);
+  // One keyline of ANOTHER map searched in this one (reference edge_map.hpp:93-94); index of the match or -1.
+  int searchMatch(const rebvio::types::KeyLine& keyline, const rebvio::types::Vector3f& vel, const rebvio::types::Matrix3f& Rvel,
+                  const rebvio::types::Matrix3f& Rback, types::Float max_radius);
   int directedMatch(rebvio::EdgeMap::SharedPtr map, const rebvio::types::Vector3f& vel, const rebvio::types::Matrix3f& Rvel,
                     const rebvio::types::Matrix3f& Rback, int& kf_matches, types::Float max_radius);
   int regularize1Iter();
@@ -54,6 +57,7 @@ class EdgeMap {
   // --- backend plumbing (not part of the reference surface) ---
   void attach(rebvio_hip_ctx* ctx, rebvio_hip_map* handle);
   rebvio_hip_map* handle() const { return handle_; }
+  rebvio_hip_ctx* ctx() const { return ctx_; }
   void invalidateMirror() { mirror_valid_ = false; mask_valid_ = false; }
 
  private:

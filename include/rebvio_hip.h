@@ -150,6 +150,21 @@ int rebvio_hip_build_distance_field(rebvio_hip_ctx* ctx, rebvio_hip_map* m);
 /* DistanceField::operator[] for all cells (core.hpp:61): ids (-1 = none) and distances (valid where id >= 0). */
 int rebvio_hip_distance_field(rebvio_hip_ctx* ctx, int* id_out, int* dist_out);
 
+/* rebvio::DistanceField::operator[] (core.hpp:61) for the field built FROM map `m` (by detect, or by
+ * rebvio_hip_build_distance_field): the field lives with its map, so it stays readable while the map is alive. */
+int rebvio_hip_map_distance_field(rebvio_hip_map* m, int* id_out, int* dist_out);
+
+/* EdgeMap::searchMatch (edge_map.hpp:93-94, edge_map.cpp:101-184): searched->searchMatch(query, vel, Rvel, Rback, max_radius),
+ * one keyline of another map against `searched`. vel / Rvel are used as given (directedMatch passes them rotated by Rback,
+ * edge_map.cpp:193-194). *idx_out = index of the match in `searched`, or -1. Synchronises. */
+int rebvio_hip_search_match(rebvio_hip_ctx* ctx, rebvio_hip_map* searched, const rebvio_hip_keyline* query, const float vel[3],
+                            const float Rvel[9], const float Rback[9], float max_radius, int* idx_out);
+
+/* FastGaussian::smooth (scale_space.hpp:31, scale_space.cpp:173-182) on a host fp32 image: three integral-image box
+ * passes of the given (odd, 3..11) widths, as FastGaussian's constructor derives them from sigma (scale_space.cpp:14-41).
+ * Test/diagnostic entry like rebvio_hip_scale_space. */
+int rebvio_hip_smooth(rebvio_hip_ctx* ctx, const float* img_host, const int widths3[3], float* out_host);
+
 /* EdgeMap::rotateKeylines (edge_map.cpp:58-71); R row-major 3x3. */
 int rebvio_hip_rotate(rebvio_hip_ctx* ctx, rebvio_hip_map* m, const float R[9]);
 /* EdgeMap::estimateQuantile (edge_map.cpp:39-56). */

@@ -113,6 +113,11 @@ def lib(path: str | None = None):
         "orc_estimate_ls4_acceleration": (None, [vp, fp, fp, fp, C.c_float]),
         "orc_so3_exp": (None, [fp, fp]),
         "orc_sym6_solve": (None, [fp, fp, fp]),
+        "orc_search_match": (C.c_int, [vp, vp, vp, fp, fp, fp, C.c_float]),
+        "orc_test_fk": (C.c_int, [vp, vp, C.c_float]),
+        "orc_calculate_fj": (C.c_float, [vp, C.c_int, fp, fp, vp, C.c_float, C.c_float, ip, fp]),
+        "orc_update_inverse_depth_arlu": (None, [vp, vp, fp]),
+        "orc_smooth": (None, [vp, fp, C.c_float, C.c_int, fp, ip]),
         "orc_run_stream": (C.c_double, [vp, C.POINTER(C.c_uint8), ip, C.c_int, C.c_int, ip, ip, fp]),
         "orc_run_stream_ex": (C.c_double, [vp, C.POINTER(C.c_uint8), ip, C.c_int, C.c_int, ip, ip, fp, C.POINTER(C.c_double)]),
         "orc_stage_seconds": (None, [vp, C.POINTER(C.c_double), C.c_int]),
@@ -287,6 +292,20 @@ class Oracle:
 
     def regularize(self, m: Map):
         return self.L.orc_regularize(m.h)
+
+    def search_match(self, searched: Map, query_keyline, vel, Rvel, Rback, max_radius=40.0) -> int:
+        q = np.ascontiguousarray(np.asarray(query_keyline, KEYLINE_DTYPE).reshape(1))
+        vel, pv = _f(vel)
+        Rvel, prv = _f(np.asarray(Rvel).reshape(9))
+        Rback, prb = _f(np.asarray(Rback).reshape(9))
+        return self.L.orc_search_match(self.h, searched.h, q.ctypes.data, pv, prv, prb, max_radius)
+
+    def smooth(self, img, sigma, n=3):
+        img, pi = _f(img)
+        out = np.empty((self.rows, self.cols), np.float32)
+        w = (C.c_int * 3)()
+        self.L.orc_smooth(self.h, pi, sigma, n, out.ctypes.data_as(C.POINTER(C.c_float)), w)
+        return out, list(w)
 
     def update_inverse_depth(self, vel):
         vel, pv = _f(vel)

@@ -1853,6 +1853,63 @@ void orc_estimate_ls4_acceleration(orc_ctx* c, const float vel[3], float acc[3],
 void orc_so3_exp(const float w[3], float R[9]) { m3_to(so3_exp(w), R); }
 void orc_sym6_solve(const float A[36], const float b[6], float x[6]) { sym_pinv_solve<6>(A, b, x); }
 
+// ---- single-keyline forms of the reference's public methods (checkers for the C++ surface) ------------------------
+int orc_search_match(orc_ctx* c, orc_map* searched, const orc_keyline* query, const float vel[3], const float Rvel[9],
+                     const float Rback[9], float max_radius) {
+  return search_match(c, searched, *query, vel, m3_from(Rvel), m3_from(Rback), max_radius);
+}
+
+int orc_test_fk(const orc_keyline* k1, const orc_keyline* k2, float similarity_threshold) {
+  // Core::testfk (core.cpp:39-44)
+  float norm_squared = k2->gradient_norm * k2->gradient_norm;
+  float dot_product = k1->gradient[0] * k2->gradient[0] + k1->gradient[1] * k2->gradient[1];
+  if (std::fabs(dot_product - norm_squared) > similarity_threshold * norm_squared) return 0;
+  return 1;
+}
+
+float orc_calculate_fj(orc_ctx* c, int f_inx, float* df_dx, float* df_dy, orc_keyline* keyline, float px, float py, int* mnum,
+                       float* fi) {
+  // Core::calculatefJ (core.cpp:46-76) on the distance field last built (orc_build_distance_field)
+  const orc_params& P = c->p;
+  const int id = c->df_id[f_inx];
+  if (id < 0) {
+    *df_dx = 0.0;
+    *df_dy = 0.0;
+    return P.search_range / keyline->sigma_rho;
+  }
+  const orc_keyline& k = c->df_map->kl[id];
+  if (!orc_test_fk(&k, keyline, P.match_treshold)) {
+    *df_dx = 0.0;
+    *df_dy = 0.0;
+    return P.search_range / keyline->sigma_rho;
+  }
+  float dx = px - k.pos[0];
+  float dy = py - k.pos[1];
+  float gnx = k.gradient[0] / k.gradient_norm;
+  float gny = k.gradient[1] / k.gradient_norm;
+  *fi = (dx * gnx + dy * gny);
+  *df_dx = gnx / keyline->sigma_rho;
+  *df_dy = gny / keyline->sigma_rho;
+  ++*mnum;
+  keyline->match_id_forward = id;
+  return *fi / keyline->sigma_rho;
+}
+
+void orc_update_inverse_depth_arlu(orc_ctx* c, orc_keyline* keyline, const float vel[3]) {
+  update_inverse_depth_arlu(c->p, *keyline, vel);
+}
+
+void orc_smooth(orc_ctx* c, const float* img, float sigma, int n, float* out, int widths_out[3]) {
+  // FastGaussian(camera, sigma, n).smooth(img) (scale_space.cpp:14-41,173-182)
+  BoxGaussian f;
+  make_filter(f, c->p.rows, c->p.cols, sigma, n);
+  std::vector<float> o;
+  smooth(c, f, img, o);
+  std::memcpy(out, o.data(), o.size() * sizeof(float));
+  if (widths_out)
+    for (int i = 0; i < 3; ++i) widths_out[i] = f.widths[i];
+}
+
 void orc_stage_seconds(orc_ctx* c, double out[6], int reset) {
   for (int i = 0; i < 5; ++i) out[i] = c->stage_acc[i];
   out[5] = c->stage_acc[5] - c->stage_acc[1] - c->stage_acc[2] - c->stage_acc[3] - c->stage_acc[4];

@@ -126,6 +126,17 @@ int orc_directed_match(orc_ctx* c, orc_map* new_map, orc_map* old_map, const flo
 int orc_regularize(orc_map* m);
 void orc_update_inverse_depth(orc_ctx* c, const float vel[3]);
 
+/* Single-keyline forms of the reference's public methods: EdgeMap::searchMatch (edge_map.cpp:101-184) on `searched`,
+ * Core::testfk (core.cpp:39-44), Core::calculatefJ (core.cpp:46-76, on the field of orc_build_distance_field),
+ * Core::updateInverseDepthARLU (core.cpp:424-456), FastGaussian(camera, sigma, n).smooth (scale_space.cpp:14-41,173-182). */
+int orc_search_match(orc_ctx* c, orc_map* searched, const orc_keyline* query, const float vel[3], const float Rvel[9],
+                     const float Rback[9], float max_radius);
+int orc_test_fk(const orc_keyline* k1, const orc_keyline* k2, float similarity_threshold);
+float orc_calculate_fj(orc_ctx* c, int f_inx, float* df_dx, float* df_dy, orc_keyline* keyline, float px, float py, int* mnum,
+                       float* fi);
+void orc_update_inverse_depth_arlu(orc_ctx* c, orc_keyline* keyline, const float vel[3]);
+void orc_smooth(orc_ctx* c, const float* img, float sigma, int n, float* out, int widths_out[3]);
+
 /* Persistent gyro-bias state of the glue (imu.hpp:180-183): reset to the reference's initial values */
 void orc_reset_state(orc_ctx* c);
 /* One frame pair: rebvio.cpp:142-259 without the accelerometer/SAB fusion (the branch taken for the

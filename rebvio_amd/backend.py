@@ -78,6 +78,9 @@ SIGNATURES = {
     "rebvio_hip_map_release": (None, [_vp]),
     "rebvio_hip_build_distance_field": (C.c_int, [_vp, _vp]),
     "rebvio_hip_distance_field": (C.c_int, [_vp, _ip, _ip]),
+    "rebvio_hip_map_distance_field": (C.c_int, [_vp, _ip, _ip]),
+    "rebvio_hip_search_match": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, C.c_float, _ip]),
+    "rebvio_hip_smooth": (C.c_int, [_vp, _fp, _ip, _fp]),
     "rebvio_hip_rotate": (C.c_int, [_vp, _vp, _fp]),
     "rebvio_hip_quantile": (C.c_int, [_vp, _vp, C.c_float, C.c_int, _fp]),
     "rebvio_hip_try_vel": (C.c_int, [_vp, _vp, _fp, C.c_float, _fp, _fp]),
@@ -197,6 +200,23 @@ class Map:
         _chk(lib().rebvio_hip_map_download(self.h, None, out.ctypes.data_as(_ip)))
         return out
 
+    def distance_field(self):
+        """The field built from THIS map (DistanceField::operator[] for all cells)."""
+        ids = np.empty((self.ctx.rows, self.ctx.cols), np.int32)
+        dist = np.empty((self.ctx.rows, self.ctx.cols), np.int32)
+        _chk(lib().rebvio_hip_map_distance_field(self.h, ids.ctypes.data_as(_ip), dist.ctypes.data_as(_ip)))
+        return ids, dist
+
+    def search_match(self, query_keyline, vel, Rvel, Rback, max_radius=40.0) -> int:
+        """EdgeMap::searchMatch: this map is searched for a match of `query_keyline` (one KEYLINE_DTYPE record)."""
+        q = np.ascontiguousarray(np.asarray(query_keyline, KEYLINE_DTYPE).reshape(1))
+        vel, pv = _f(vel)
+        Rvel, prv = _f(np.asarray(Rvel).reshape(9))
+        Rback, prb = _f(np.asarray(Rback).reshape(9))
+        out = C.c_int(-2)
+        _chk(lib().rebvio_hip_search_match(self.ctx.h, self.h, q.ctypes.data, pv, prv, prb, max_radius, C.byref(out)))
+        return out.value
+
     def upload(self, kl: np.ndarray):
         kl = np.ascontiguousarray(kl, KEYLINE_DTYPE)
         _chk(lib().rebvio_hip_map_upload(self.h, kl.ctypes.data if kl.size else None, len(kl)))
@@ -231,6 +251,13 @@ class Context:
         outs = [np.empty((self.rows, self.cols), np.float32) for _ in range(4)]
         _chk(lib().rebvio_hip_scale_space(self.h, pi, *[o.ctypes.data_as(_fp) for o in outs]))
         return dict(scale0=outs[0], scale1=outs[1], dog=outs[2], mag=outs[3])
+
+    def smooth(self, img, widths3):
+        img, pi = _f(img)
+        w = (C.c_int * 3)(*[int(v) for v in widths3])
+        out = np.empty((self.rows, self.cols), np.float32)
+        _chk(lib().rebvio_hip_smooth(self.h, pi, w, out.ctypes.data_as(_fp)))
+        return out
 
     def detect(self, img, ts_us=0) -> Map:
         img, pi = _f(img)

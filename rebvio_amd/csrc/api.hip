@@ -1156,6 +1156,61 @@ int rebvio_hip_distance_field(rebvio_hip_ctx* c, int* id_out, int* dist_out) {
   return 0;
 }
 
+int rebvio_hip_map_distance_field(rebvio_hip_map* m, int* id_out, int* dist_out) {
+  rebvio_hip_ctx* c = m->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  if (!m->df_built) return fail_msg("map_distance_field: no distance field has been built from this map", -7);
+  wait_enqueued(m);
+  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  const size_t Pn = (size_t)c->P.rows * c->P.cols;
+  launch_df_decode(c->s_trk, c->K, m->d, c->scratch_i, c->scratch_i + Pn);
+  HIPCHK(hipGetLastError());
+  if (id_out) HIPCHK(hipMemcpyAsync(id_out, c->scratch_i, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
+  if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, c->scratch_i + Pn, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  return 0;
+}
+
+int rebvio_hip_search_match(rebvio_hip_ctx* c, rebvio_hip_map* searched, const rebvio_hip_keyline* query, const float vel[3],
+                            const float Rvel[9], const float Rback[9], float max_radius, int* idx_out) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!(query->gradient_norm > 0.0f)) return fail_msg("search_match: the query keyline needs a positive gradient_norm", -3);
+  wait_enqueued(searched);
+  HIPCHK(hipStreamWaitEvent(c->s_trk, searched->ready, 0));
+  int* out_dev = reinterpret_cast<int*>(c->fscratch) + 32;
+  launch_search_match_one(c->s_trk, c->K, searched->d, *query, vel, Rvel, Rback, max_radius, out_dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_f + 32, out_dev, sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  std::memcpy(idx_out, c->h_f + 32, sizeof(int));
+  return 0;
+}
+
+int rebvio_hip_smooth(rebvio_hip_ctx* c, const float* img, const int widths3[3], float* out) {
+  HIPCHK(hipSetDevice(c->device));
+  for (int k = 0; k < 3; ++k)
+    if (widths3[k] < 3 || widths3[k] > 11 || (widths3[k] & 1) == 0) return fail_msg("smooth: box widths must be odd and in 3..11", -3);
+  const size_t nb = (size_t)c->P.rows * c->P.cols * sizeof(float);
+  if (!c->diag0) {
+    HIPCHK(hipMalloc(&c->diag0, nb));
+    HIPCHK(hipMalloc(&c->diag1, nb));
+  }
+  while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  HIPCHK(hipStreamSynchronize(c->s_key));  // the scratch DoG / gradient buffers below belong to frames in flight
+  HIPCHK(hipMemcpyAsync(c->img_dev, img, nb, hipMemcpyHostToDevice, c->s_det));
+  ScaleBufs sb = c->sb;
+  sb.scale0 = c->diag0;
+  sb.scale1 = c->diag1;
+  int w[2][3];
+  for (int f = 0; f < 2; ++f)
+    for (int k = 0; k < 3; ++k) w[f][k] = widths3[k];
+  launch_scale_space(c->s_det, c->K, c->img_dev, 0, sb, w, c->db.rowcount);  // both filter slots run the same box widths
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, c->diag0, nb, hipMemcpyDeviceToHost, c->s_det));
+  HIPCHK(hipStreamSynchronize(c->s_det));
+  return 0;
+}
+
 int rebvio_hip_rotate(rebvio_hip_ctx* c, rebvio_hip_map* m, const float R[9]) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));

@@ -205,6 +205,8 @@ void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m,
 // applies the next pair's first rotation and bins sigma_rho into hist
 void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, int* work_n_reset,
                            const float* Rnext, int* hist);
+void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& searched, const rebvio_hip_keyline& query,
+                             const float vel[3], const float Rvel[9], const float Rback[9], float max_radius, int* out_dev);
 void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate, int* work_n_reset);
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp,
                       int min_matches_gate);

@@ -1522,6 +1522,32 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
   }
 }
 
+// ---- EdgeMap::searchMatch as a public single-keyline call (edge_map.hpp:93-94, edge_map.cpp:101-184) ----------------
+// One lane walks the reference's alternating probe sequence with the same set-up / acceptance code as the directedMatch
+// kernels (vel / Rvel as given: directedMatch rotates them by Rback before it calls searchMatch, edge_map.cpp:193-194).
+__global__ void k_search_match_one(KParams p, MapDev om, float2 pi, float2 rsq, float2 gq, float gnq, Vec3 vel, Mat3 Rvel,
+                                   Mat3 Rback, float max_radius, int* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const SearchSetup S = search_setup(p, pi, rsq, gq, gnq, vel, Rvel, Rback, max_radius);
+  Mat3 I{};
+  int found = -1;
+  float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
+  for (int t_i = 0; t_i < S.t_steps && found < 0; ++t_i, tp += 1.0f, tn -= 1.0f) {
+    for (int i_idx = 0; i_idx < 2 && found < 0; ++i_idx) {
+      const float t = i_idx ? tp : tn;
+      if (i_idx ? (t > S.dq_max) : (t < S.dq_min)) continue;
+      const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
+      const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
+      if ((unsigned)row >= (unsigned)p.rows || (unsigned)col >= (unsigned)p.cols) continue;
+      const int cand = om.mask[(size_t)row * p.cols + col];
+      if (cand < 0) continue;
+      const OldKl ck = load_old(om, cand, 0, I, p.fm);
+      if (search_accept(p, S, t, ck.g, ck.gn, ck.rs, gq, gnq)) found = cand;
+    }
+  }
+  *out = found;
+}
+
 // ---- EdgeMap::regularize1Iter (edge_map.cpp:220-259): Jacobi step, results staged in rs_tmp ----------------------
 __global__ __launch_bounds__(256) void k_regularize(KParams p, MapDev m, int gate_min_matches, int* __restrict__ work_n_reset) {
   if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;  // directedMatch queue of this pair is consumed
@@ -1834,6 +1860,13 @@ void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& ne
               work_n, 1, mat3(I), g_pinned, g_dev);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
             (const int*)work, (const int*)work_n, 1, mat3(I), (const GlueDev*)g_dev);
+}
+
+void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& searched, const rebvio_hip_keyline& q, const float vel[3],
+                             const float Rvel[9], const float Rback[9], float max_radius, int* out_dev) {
+  RH_LAUNCH(k_search_match_one, dim3(1), dim3(64), 0, s, p, searched, make_float2(q.pos_img[0], q.pos_img[1]),
+            make_float2(q.rho, q.sigma_rho), make_float2(q.gradient[0], q.gradient[1]), q.gradient_norm, vec3(vel), mat3(Rvel),
+            mat3(Rback), max_radius, out_dev);
 }
 
 void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate, int* work_n_reset) {

@@ -1,5 +1,7 @@
 #include "rebvio/core.hpp"
 
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "../csrc/hostmath.hpp"
@@ -10,8 +12,46 @@ namespace rebvio {
 using backend::check;
 namespace hm = rh::hm;
 
+// ---- DistanceField (reference core.hpp:20-79) ------------------------------------------------------------------------
+DistanceField::DistanceField(int rows, int cols, types::Float search_range)
+    : rows_((unsigned)rows), cols_((unsigned)cols), search_range_(search_range) {}
+
+DistanceField::~DistanceField() {}
+
+void DistanceField::build(rebvio::EdgeMap::SharedPtr map) {
+  if (!map || !map->handle()) backend::fail("DistanceField::build: the map has no device keylines (maps come from EdgeDetector::detect)", -1);
+  check("rebvio_hip_build_distance_field", rebvio_hip_build_distance_field(map->ctx(), map->handle()));
+  map_ = map;
+  mirror_valid_ = false;
+}
+
+void DistanceField::syncMirror() {
+  if (mirror_valid_) return;
+  const size_t n = (size_t)rows_ * cols_;
+  std::vector<int> ids(n), dist(n);
+  // (a size or search range that differs from the stream's context shows up here: the ABI call sizes by the context)
+  check("rebvio_hip_map_distance_field", rebvio_hip_map_distance_field(map_->handle(), ids.data(), dist.data()));
+  field_.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    field_[i].id = ids[i];
+    field_[i].distance = dist[i];
+  }
+  mirror_valid_ = true;
+}
+
+DistanceFieldElement& DistanceField::operator[](int index) {
+  if (!map_) {  // never built: every cell empty, like the reference's freshly constructed field
+    if (field_.empty()) field_.resize((size_t)rows_ * cols_);
+    return field_[index];
+  }
+  syncMirror();
+  return field_[index];
+}
+
+// ---- Core ------------------------------------------------------------------------------------------------------------
 Core::Core(rebvio::Camera::SharedPtr camera, rebvio::CoreConfig::SharedPtr config)
-    : config_(config), camera_(camera), session_(backend::Session::forCamera(*camera)) {
+    : config_(config), camera_(camera), session_(backend::Session::forCamera(*camera)),
+      distance_field_((int)camera->rows_, (int)camera->cols_, config->search_range) {
   session_->setCoreConfig(*config_);
   for (auto& v : ls4_V_) v = TooN::Zeros;
   for (auto& v : mean_A_) v = TooN::Zeros;
@@ -24,8 +64,73 @@ Core::~Core() {}
 CoreConfig::SharedPtr Core::config() { return config_; }
 
 void Core::buildDistanceField(rebvio::EdgeMap::SharedPtr map) {
-  check("rebvio_hip_build_distance_field", rebvio_hip_build_distance_field(session_->ctx(), map->handle()));
-  df_map_ = map;
+  if (map->ctx() != session_->ctx()) backend::fail("Core::buildDistanceField: the map belongs to another camera stream", -1);
+  distance_field_.build(map);
+}
+
+// |g1.g2 - g2.g2| / (g2.g2) <= threshold (reference core.cpp:39-44)
+bool Core::testfk(const rebvio::types::KeyLine& keyline1, const rebvio::types::KeyLine& keyline2,
+                  const types::Float& similarity_threshold) {
+  const types::Float g22 = keyline2.gradient_norm * keyline2.gradient_norm;
+  const types::Float g12 = keyline1.gradient[0] * keyline2.gradient[0] + keyline1.gradient[1] * keyline2.gradient[1];
+  return !(std::fabs(g12 - g22) > similarity_threshold * g22);
+}
+
+// Distance-field lookup of one reprojected keyline (reference core.cpp:46-76): weighted residual along the matched
+// keyline's unit gradient and its two image-space derivatives; no cell / dissimilar gradients -> the range penalty with
+// zero derivatives (and `fi` untouched, which is what tryVel's carry-forward rule rests on).
+types::Float Core::calculatefJ(rebvio::EdgeMap::SharedPtr, int f_inx, types::Float& df_dx, types::Float& df_dy,
+                               rebvio::types::KeyLine& keyline, const types::Float& px, const types::Float& py, int& mnum,
+                               types::Float& fi) {
+  const int id = distance_field_[f_inx].id;
+  const types::KeyLine* target = id >= 0 ? &(*distance_field_.map())[id] : nullptr;
+  if (!target || !Core::testfk(*target, keyline, config_->match_treshold)) {
+    df_dx = 0.0;
+    df_dy = 0.0;
+    return config_->search_range / keyline.sigma_rho;
+  }
+  const types::Float ux = target->gradient[0] / target->gradient_norm;
+  const types::Float uy = target->gradient[1] / target->gradient_norm;
+  fi = (px - target->pos[0]) * ux + (py - target->pos[1]) * uy;
+  df_dx = ux / keyline.sigma_rho;
+  df_dy = uy / keyline.sigma_rho;
+  ++mnum;
+  keyline.match_id_forward = id;
+  return fi / keyline.sigma_rho;
+}
+
+// Scalar depth EKF of one matched keyline (reference core.cpp:424-456), operation for operation what k_depth_ekf /
+// k_regularize_ekf evaluate per thread (the same float / double promotions).
+void Core::updateInverseDepthARLU(rebvio::types::KeyLine& k, rebvio::types::Vector3f& vel) {
+  const float fm = camera_->fm_;
+  const float vx = vel[0], vy = vel[1], vz = vel[2];
+  float v_rho = k.sigma_rho * k.sigma_rho;
+  const float ux = k.match_gradient[0] / k.match_gradient_norm;
+  const float uy = k.match_gradient[1] / k.match_gradient_norm;
+  const float Y = ux * (k.pos_img[0] - k.match_pos_img[0]) + uy * (k.pos_img[1] - k.match_pos_img[1]);
+  const float H = ux * (vx * fm - vz * k.match_pos_img[0]) + uy * (vy * fm - vz * k.match_pos_img[1]);
+  const float rho_p = (float)(1.0 / (1.0 / (double)k.rho + (double)vz));
+  float F = (float)(1.0 / (1.0 + (double)(k.rho * vz)));
+  F *= F;
+  const float p_p = F * v_rho * F + config_->reshape_q_abs * config_->reshape_q_abs;
+  const float e = Y - H * rho_p;
+  const float S = H * p_p * H + config_->pixel_uncertainty * config_->pixel_uncertainty;
+  const float K = (float)((double)(p_p * H) * (1.0 / (double)S));
+  float rho = rho_p + K * e;
+  v_rho = (float)((1.0 - (double)(K * H)) * (double)p_p);
+  float sig = std::sqrt(v_rho);
+  if (rho < types::RHO_MIN) {
+    sig += types::RHO_MIN - rho;
+    rho = types::RHO_MIN;
+  } else if (rho > types::RHO_MAX) {
+    rho = types::RHO_MAX;
+  } else if (std::isnan(rho) || std::isnan(sig) || std::isinf(rho) || std::isinf(sig)) {
+    std::fprintf(stderr, "ERROR NaN or INF RHO in updateInverseDepthARLU()!\n");
+    rho = types::RHO_INIT;
+    sig = types::RHO_MAX;
+  }
+  k.rho = rho;
+  k.sigma_rho = sig;
 }
 
 types::Float Core::tryVel(rebvio::EdgeMap::SharedPtr map, rebvio::types::Matrix3f& JtJ, rebvio::types::Vector3f& JtF,
@@ -139,7 +244,7 @@ void Core::estimateMeanAcceleration(const rebvio::types::Vector3f sacc, rebvio::
 void Core::updateInverseDepth(rebvio::types::Vector3f& vel) {
   const float v[3] = {vel[0], vel[1], vel[2]};
   check("rebvio_hip_update_inverse_depth", rebvio_hip_update_inverse_depth(session_->ctx(), v));
-  if (df_map_) df_map_->invalidateMirror();
+  if (distance_field_.map()) distance_field_.map()->invalidateMirror();
 }
 
 }  // namespace rebvio

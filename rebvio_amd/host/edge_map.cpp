@@ -94,6 +94,20 @@ int EdgeMap::forwardMatch(rebvio::EdgeMap::SharedPtr map) {
   return 0;  // the reference's count is order dependent and unused (rebvio.cpp:172)
 }
 
+int EdgeMap::searchMatch(const rebvio::types::KeyLine& keyline, const rebvio::types::Vector3f& vel, const rebvio::types::Matrix3f& Rvel,
+                         const rebvio::types::Matrix3f& Rback, types::Float max_radius) {
+  float v[3] = {vel[0], vel[1], vel[2]}, rv[9], rb[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      rv[i * 3 + j] = Rvel(i, j);
+      rb[i * 3 + j] = Rback(i, j);
+    }
+  int idx = -1;
+  check("rebvio_hip_search_match",
+        rebvio_hip_search_match(ctx_, handle_, reinterpret_cast<const rebvio_hip_keyline*>(&keyline), v, rv, rb, max_radius, &idx));
+  return idx;
+}
+
 int EdgeMap::directedMatch(rebvio::EdgeMap::SharedPtr map, const rebvio::types::Vector3f& vel, const rebvio::types::Matrix3f& Rvel,
                            const rebvio::types::Matrix3f& Rback, int& kf_matches, types::Float max_radius) {
   float v[3] = {vel[0], vel[1], vel[2]}, rv[9], rb[9];

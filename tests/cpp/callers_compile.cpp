@@ -5,6 +5,8 @@
 #include <string>
 
 #include "rebvio/rebvio.hpp"
+#include "rebvio/scale_space.hpp"
+#include "rebvio/util/timer.hpp"
 
 namespace rebvio {
 struct RosRebvioConfigLike {
@@ -45,4 +47,32 @@ int callers(rebvio::RosRebvioConfigLike _config) {
   rebvio::types::Matrix3f R = TooN::Data(1, 8.83134e-05, -7.48149e-05, -8.831e-05, 1, 4.57494e-05, 7.4819e-05, -4.57428e-05, 1);
   core.estimateLs4Acceleration(-Vgv / dt, Av, R, dt);
   return px;
+}
+
+// The rest of the library's public surface (a user of rebvio links against these although ros_rebvio does not call them):
+// core.hpp:20-79,122,138,187; edge_map.hpp:93-94; scale_space.hpp:22-96; util/timer.hpp:18-32.
+int library_users(rebvio::Camera::SharedPtr camera, rebvio::EdgeMap::SharedPtr map, rebvio::EdgeMap::SharedPtr other) {
+  REBVIO_TIMER_TICK();
+  rebvio::DistanceField field(480, 752, 40.0);
+  field.build(map);
+  rebvio::DistanceFieldElement& e = field[0];
+  int acc = e.id + e.distance + field.map()->size();
+  rebvio::Core core(camera);
+  rebvio::types::KeyLine& k = (*map)[0];
+  rebvio::types::Float dx, dy, fi = 0;
+  int mnum = 0;
+  acc += rebvio::Core::testfk(k, (*other)[0], 0.5f) ? 1 : 0;
+  acc += (int)core.calculatefJ(map, 0, dx, dy, k, k.pos[0], k.pos[1], mnum, fi);
+  rebvio::types::Vector3f v = TooN::makeVector(0.0f, 0.0f, 0.0f);
+  core.updateInverseDepthARLU(k, v);
+  rebvio::types::Matrix3f I = TooN::Data(1, 0, 0, 0, 1, 0, 0, 0, 1);
+  acc += other->searchMatch(k, v, I, I, 40.0f);
+  rebvio::ScaleSpace space(camera);
+  cv::Mat img(480, 752, CV_32FC1);
+  space.build(img);
+  acc += space.dog().rows + space.mag().cols;
+  rebvio::FastGaussian fg(camera, 3.56359f, 3);
+  acc += fg.smooth(img).rows + fg.n_ + fg.widths_[0] + (int)fg.sigma_true_ + fg.divisors_[0].rows;
+  REBVIO_TIMER_TOCK();
+  return acc;
 }

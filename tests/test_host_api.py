@@ -78,7 +78,11 @@ def test_host_library_exports_reference_classes(host_lib):
                 "rebvio::EdgeMap::rotateKeylines", "rebvio::EdgeMap::directedMatch", "rebvio::EdgeMap::regularize1Iter",
                 "rebvio::Core::minimizeVel", "rebvio::Core::extRotVel", "rebvio::Core::updateInverseDepth",
                 "rebvio::Core::buildDistanceField", "rebvio::Core::tryVel", "rebvio::Core::estimateBias",
-                "rebvio::SABEstimator::gaussNewton", "rebvio::SABEstimator::problem"):
+                "rebvio::SABEstimator::gaussNewton", "rebvio::SABEstimator::problem",
+                "rebvio::DistanceField::build", "rebvio::DistanceField::operator[](int)", "rebvio::Core::testfk",
+                "rebvio::Core::calculatefJ", "rebvio::Core::updateInverseDepthARLU", "rebvio::EdgeMap::searchMatch",
+                "rebvio::ScaleSpace::build", "rebvio::ScaleSpace::dog() const", "rebvio::ScaleSpace::mag() const",
+                "rebvio::FastGaussian::smooth"):
         assert sym in out, sym
 
 
@@ -198,3 +202,112 @@ def test_replay_asl_folder_equals_raw_stream(host_lib, tmp_path):
     assert ex.returncode == 0
     ev = np.array([[float(x) for x in ln.split()[:7]] for ln in ex.stdout.strip().splitlines() if ln and ln[0].isdigit()])
     np.testing.assert_allclose(ev, vals, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_public_cpp_surface_matches_oracle(host_lib, tmp_path, orc_mod):
+    """The parts of the reference's public C++ surface no ros_rebvio caller reaches - rebvio::DistanceField (build ->
+    operator[]), Core::testfk / calculatefJ / updateInverseDepthARLU, EdgeMap::searchMatch, ScaleSpace, FastGaussian, the
+    timer macros - through tests/cpp/test_public_surface.cpp, every result bit-exact against the oracle's restatement."""
+    import ctypes as C
+    from rebvio_amd import synth
+    W, H = 320, 240
+    frames, cam = synth.render_stream(W, H, 2)
+    frames.tofile(tmp_path / "frames.u8")
+    exe = str(tmp_path / "public_surface")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off"] + INC + [os.path.join(ROOT, "tests", "cpp", "test_public_surface.cpp"),
+                    "-o", exe, "-L", host_lib, "-lrebvio", "-lrebvio_hip", f"-Wl,-rpath,{host_lib}", "-pthread"], check=True)
+    r = subprocess.run([exe, str(tmp_path / "frames.u8"), str(W), str(H), repr(cam.fm), repr(cam.cx), repr(cam.cy), "3000", "4000",
+                        str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "[rebvio timer]" in r.stdout and "inner" in r.stdout  # the static timers reported at exit
+
+    def load(name, dtype):
+        return np.fromfile(tmp_path / name, dtype=dtype)
+
+    O = orc_mod
+    L = O.lib()
+    orc = O.Oracle(O.default_params(H, W, fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=3000, keylines_max=4000))
+    om = [orc.detect_u8(frames[i], i * 50000) for i in range(2)]
+    ko = [m.keylines() for m in om]
+    n0, n1 = len(ko[0]), len(ko[1])
+    for i in range(2):
+        kg = load(f"kl{i}.bin", O.KEYLINE_DTYPE)
+        assert len(kg) == len(ko[i])
+        for fld in ("pos", "pos_img", "gradient", "gradient_norm", "rho", "sigma_rho", "id_prev", "id_next"):
+            assert np.array_equal(kg[fld].view(np.uint32), ko[i][fld].view(np.uint32)), (i, fld)
+
+    # DistanceField::build -> operator[]
+    orc.build_distance_field(om[1])
+    ido, dso = orc.distance_field()
+    idg, dsg = load("df_id.bin", np.int32).reshape(H, W), load("df_dist.bin", np.int32).reshape(H, W)
+    assert np.array_equal(ido, idg) and (ido >= 0).sum() > 10000
+    assert np.array_equal(dso[ido >= 0], dsg[idg >= 0])
+    assert (dsg[idg < 0] == np.iinfo(np.int32).max).all()
+
+    # Core::calculatefJ / testfk
+    K = 400
+    fj, fji = load("fj.bin", np.float32).reshape(K, 4), load("fji.bin", np.int32).reshape(K, 3)
+    f32 = np.float32
+    matched = 0
+    for k in range(K):
+        kl = ko[0][(k * 37) % n0:(k * 37) % n0 + 1].copy()
+        kl["sigma_rho"] = f32(0.5) + f32(0.01) * f32(k)
+        x, y = int(f32(kl["pos"][0, 0]) + f32(0.5)), int(f32(kl["pos"][0, 1]) + f32(0.5))
+        dx, dy, fi, mnum = C.c_float(-1), C.c_float(-1), C.c_float(123.0), C.c_int(0)
+        rr = L.orc_calculate_fj(orc.h, y * W + x, C.byref(dx), C.byref(dy), kl.ctypes.data, float(kl["pos"][0, 0]),
+                                float(kl["pos"][0, 1]), C.byref(mnum), C.byref(fi))
+        want = np.array([rr, dx.value, dy.value, fi.value], np.float32)
+        assert np.array_equal(want.view(np.uint32), fj[k].view(np.uint32)), (k, want, fj[k])
+        assert (mnum.value, int(kl["match_id_forward"][0])) == (fji[k, 0], fji[k, 1]), k
+        other = ko[1][(k * 11) % n1:(k * 11) % n1 + 1]
+        assert L.orc_test_fk(other.ctypes.data, kl.ctypes.data, 0.5) == fji[k, 2], k
+        matched += mnum.value
+    assert 50 < matched < K  # both outcomes of the lookup occur
+
+    # EdgeMap::searchMatch
+    vel = np.array([0.004, -0.002, 0.003], np.float32)
+    Rvel = np.diag([f32(1e-6) * f32(i + 1) for i in range(3)]).astype(np.float32)
+    Rback = np.eye(3, dtype=np.float32)
+    Rback[0, 2], Rback[2, 0] = 2e-3, -2e-3
+    sm, sm0 = load("sm.bin", np.int32), load("sm0.bin", np.int32)
+    want, want0 = [], []
+    for k in range(K):
+        q = ko[1][(k * 29) % n1:(k * 29) % n1 + 1].copy()
+        want0.append(orc.search_match(om[0], q, np.zeros(3), Rvel, np.eye(3)))
+        q["rho"] = f32(0.4) + f32(0.002) * f32(k)
+        q["sigma_rho"] = f32(0.05) + f32(0.01) * f32(k % 50)
+        want.append(orc.search_match(om[0], q, vel, Rvel, Rback))
+    assert np.array_equal(sm, np.array(want, np.int32)) and (sm >= 0).sum() > 20 and (sm < 0).sum() > 20
+    assert np.array_equal(sm0, np.array(want0, np.int32)) and (sm0 >= 0).sum() > 20
+
+    # Core::updateInverseDepthARLU (both clamps occur)
+    ekf = load("ekf.bin", np.float32).reshape(K, 2)
+    v = np.array([0.01, -0.004, 0.02], np.float32)
+    for k in range(K):
+        kl = ko[1][(k * 13) % n1:(k * 13) % n1 + 1].copy()
+        kl["match_pos_img"][0, 0] = kl["pos_img"][0, 0] + (f32(0.5) - f32(0.01) * f32(k % 90))
+        kl["match_pos_img"][0, 1] = kl["pos_img"][0, 1] + (f32(-0.3) + f32(0.02) * f32(k % 40))
+        kl["match_gradient"], kl["match_gradient_norm"], kl["match_id"] = kl["gradient"], kl["gradient_norm"], 1
+        kl["rho"] = f32(19.99) if k % 7 == 0 else f32(0.002) + f32(0.03) * f32(k)
+        kl["sigma_rho"] = f32(0.01) + f32(0.05) * f32(k % 100)
+        L.orc_update_inverse_depth_arlu(orc.h, kl.ctypes.data, v.ctypes.data_as(C.POINTER(C.c_float)))
+        want = np.array([kl["rho"][0], kl["sigma_rho"][0]], np.float32)
+        assert np.array_equal(want.view(np.uint32), ekf[k].view(np.uint32)), (k, want, ekf[k])
+    assert (ekf[:, 0] == np.float32(20.0)).any() and (ekf[:, 0] == np.float32(1e-3)).any()
+
+    # ScaleSpace / FastGaussian
+    img = frames[0].astype(np.float32) * np.float32(3.0)
+    so = orc.scale_space(img)
+    assert np.array_equal(so["dog"].view(np.uint32).ravel(), load("dog.bin", np.uint32))
+    assert np.array_equal(so["mag"].view(np.uint32).ravel(), load("mag.bin", np.uint32))
+    sm_o, widths = orc.smooth(img, 2.2)
+    meta = load("smooth_meta.bin", np.float32)
+    assert [int(v) for v in meta[3:6]] == widths and meta[0] == 3 and meta[1] == np.float32(2.2)
+    assert abs(meta[2] - np.sqrt((sum(w * w for w in widths) - 3) / 12.0)) < 1e-5
+    assert np.array_equal(sm_o.view(np.uint32).ravel(), load("smooth.bin", np.uint32))
+    d, h = widths[0], widths[0] // 2
+    ext = lambda i, n: np.where(i <= h, i + h + 1, np.where(i >= n - h, n - i + h, d))  # noqa: E731
+    cnt = ext(np.arange(H), H)[:, None] * ext(np.arange(W), W)[None, :]
+    assert np.array_equal((1.0 / cnt.astype(np.float32).astype(np.float64)).astype(np.float32).view(np.uint32).ravel(),
+                          load("div0.bin", np.uint32))
