@@ -4,6 +4,7 @@
 //   rebvio_stream_example frames.u8 width height n_frames [fm cx cy keylines_ref keylines_max [imu.bin [min_matches]]]
 // imu.bin: records of {int64 ts_us, float gyro[3], float acc[3]} (32 bytes); without it a still 200 Hz IMU is synthesised.
 // Each line carries, after the reference's seven columns, the scale K, gravity estimate, gyro bias and match count.
+// REBVIO_EXAMPLE_FRAME_DT_US: camera period in microseconds (default 50000 = the 20 Hz of the reference's regression data).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,6 +69,7 @@ int main(int argc, char** argv) {
     }
   }
 
+  const uint64_t frame_dt_us = std::getenv("REBVIO_EXAMPLE_FRAME_DT_US") ? std::strtoull(std::getenv("REBVIO_EXAMPLE_FRAME_DT_US"), nullptr, 10) : 50000ull;
   rebvio::Rebvio rebvio(config);
   std::mutex mu;
   int n_odo = 0, n_edge = 0, last_keylines = 0;
@@ -89,13 +91,13 @@ int main(int argc, char** argv) {
   for (int i = 0; i < N; ++i) {
     cv::Mat frame(H, W, CV_8UC1, buf.data() + (size_t)i * W * H);
     // samples up to this frame's stamp are queued before the frame, as a time-ordered bag replay delivers them
-    for (; k_imu < imu.size() && (uint64_t)imu[k_imu].ts <= (uint64_t)i * 50000ull; ++k_imu)
+    for (; k_imu < imu.size() && (uint64_t)imu[k_imu].ts <= (uint64_t)i * frame_dt_us; ++k_imu)
       rebvio.imuCallback(rebvio::types::Imu{(uint64_t)imu[k_imu].ts,
                                             TooN::makeVector(imu[k_imu].gyro[0], imu[k_imu].gyro[1], imu[k_imu].gyro[2]),
                                             TooN::makeVector(imu[k_imu].acc[0], imu[k_imu].acc[1], imu[k_imu].acc[2])});
-    rebvio.imageCallback(rebvio::types::Image{(uint64_t)i * 50000ull, frame.clone()});
-    for (int k = 0; imu.empty() && k < 10; ++k)  // 200 Hz IMU next to the 20 Hz camera: a still gyro, gravity on y
-      rebvio.imuCallback(rebvio::types::Imu{(uint64_t)i * 50000ull + (uint64_t)k * 5000ull + 1ull, TooN::makeVector(0.0f, 0.0f, 0.0f),
+    rebvio.imageCallback(rebvio::types::Image{(uint64_t)i * frame_dt_us, frame.clone()});
+    for (int k = 0; imu.empty() && k < (int)(frame_dt_us / 5000ull); ++k)  // 200 Hz IMU next to the camera: a still gyro, gravity on y
+      rebvio.imuCallback(rebvio::types::Imu{(uint64_t)i * frame_dt_us + (uint64_t)k * 5000ull + 1ull, TooN::makeVector(0.0f, 0.0f, 0.0f),
                                             TooN::makeVector(0.0f, 9.81f, 0.0f)});
   }
   rebvio.waitIdle();

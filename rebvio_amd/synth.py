@@ -202,9 +202,8 @@ def imu_samples(scene: Scene, n_frames: int, frame_dt_us: int = 50000, rate_hz: 
     Returns (ts_us[int64], gyro[n,3], acc[n,3]) in the IMU frame; sample k of frame f has f*dt < ts <= (f+1)*dt... i.e.
     timestamps in (0, (n_frames-1)*dt]."""
     R_c2i = np.eye(3) if R_c2i is None else np.asarray(R_c2i, np.float64)
-    per = rate_hz * frame_dt_us // 1000000
-    step = frame_dt_us // per
-    ts = np.arange(1, (n_frames - 1) * per + 1, dtype=np.int64) * step
+    step = 1000000 // rate_hz  # the IMU runs on its own clock: 5000 us at 200 Hz whatever the camera rate
+    ts = np.arange(1, ((n_frames - 1) * frame_dt_us) // step + 1, dtype=np.int64) * step
     yaw_rate = math.radians(scene.yaw_deg) * (1e6 / frame_dt_us)  # rad/s about camera y
     w_cam = np.array([0.0, yaw_rate, 0.0])
     f_cam = np.array([0.0, -9.81, 0.0])  # specific force = a - g with a = 0, g = +9.81 along camera y (invariant under yaw)

@@ -1,0 +1,103 @@
+// Runs the host-side fusion math on inputs read from a file of float32 and writes the results as float32,
+// so that tests/test_fusion_math.py can check them against INDEPENDENT float64 statements (finite differences of the
+// weighted cost, joint normal equations, matrix exponentials) instead of against the oracle's restatement of the same text.
+//   host_math_dump <mode> in.f32 out.f32
+//   sab   : a_v3 a_s3 G x_p7 Pp49 Rv9 Rs9 Rg X7            -> JtJ49 JtF7 Xgn7 iterations1
+//   gbc   : X6 Wx36 Wb9 Rg9 Rb9                            -> X6 Wx36 Wb9 dg3          (Core::gyroBiasCorrection + the C-ABI's hostmath form)
+//   chol6 : A36                                            -> inv36
+//   so3   : w3 a3 b3                                       -> exp(w)9 ln(exp(w))3 R(a->b)9 hostmath exp(w)9
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../rebvio_amd/csrc/hostmath.hpp"
+#include "rebvio/core.hpp"
+#include "rebvio/sab_estimator.hpp"
+
+using namespace rebvio;
+namespace hm = rh::hm;
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const std::string mode = argv[1];
+  std::ifstream f(argv[2], std::ios::binary);
+  std::vector<float> in((std::istreambuf_iterator<char>(f)), {});
+  {
+    std::ifstream g(argv[2], std::ios::binary | std::ios::ate);
+    const size_t bytes = (size_t)g.tellg();
+    g.seekg(0);
+    in.resize(bytes / sizeof(float));
+    g.read(reinterpret_cast<char*>(in.data()), (std::streamsize)bytes);
+  }
+  std::vector<float> out;
+  const float* p = in.data();
+  auto v3 = [&](const float* q) { return TooN::makeVector(q[0], q[1], q[2]); };
+  auto m3 = [&](const float* q) {
+    types::Matrix3f M;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) M(i, j) = q[i * 3 + j];
+    return M;
+  };
+  if (mode == "sab") {
+    if (in.size() != 3 + 3 + 1 + 7 + 49 + 9 + 9 + 1 + 7) return 3;
+    types::Vector7f xp, X;
+    types::Matrix7f Pp;
+    for (int i = 0; i < 7; ++i) xp[i] = p[7 + i];
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) Pp(i, j) = p[14 + i * 7 + j];
+    for (int i = 0; i < 7; ++i) X[i] = p[82 + i];
+    SABEstimator::Config cfg(v3(p), v3(p + 3), p[6], xp, m3(p + 63), m3(p + 72), p[81], Pp);
+    SABEstimator sab(cfg);
+    types::Matrix7f JtJ;
+    types::Vector7f JtF;
+    sab.problem(JtJ, JtF, X);
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) out.push_back(JtJ(i, j));
+    for (int i = 0; i < 7; ++i) out.push_back(JtF[i]);
+    types::Vector7f Xg = X;
+    const int it = sab.gaussNewton(Xg, 20);
+    for (int i = 0; i < 7; ++i) out.push_back(Xg[i]);
+    out.push_back((float)it);
+  } else if (mode == "gbc") {
+    if (in.size() != 6 + 36 + 9 + 9 + 9) return 3;
+    Core core(std::make_shared<Camera>());
+    types::Vector6f X;
+    types::Matrix6f Wx;
+    for (int i = 0; i < 6; ++i) X[i] = p[i];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) Wx(i, j) = p[6 + i * 6 + j];
+    types::Matrix3f Wb = m3(p + 42);
+    const types::Vector3f dg = core.gyroBiasCorrection(X, Wx, Wb, m3(p + 51), m3(p + 60));
+    for (int i = 0; i < 6; ++i) out.push_back(X[i]);
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) out.push_back(Wx(i, j));
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) out.push_back(Wb(i, j));
+    for (int i = 0; i < 3; ++i) out.push_back(dg[i]);
+  } else if (mode == "chol6") {
+    if (in.size() != 36) return 3;
+    float h[36];  // what the host classes and the C-ABI glue use for TooN::Cholesky<6,float>::get_inverse (rebvio.cpp:198)
+    hm::cholesky6_inverse(p, h);
+    out.insert(out.end(), h, h + 36);
+  } else if (mode == "so3") {
+    if (in.size() != 9) return 3;
+    const TooN::SO3<types::Float> E(v3(p));
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) out.push_back(E.get_matrix()(i, j));
+    const types::Vector3f l = E.ln();
+    for (int i = 0; i < 3; ++i) out.push_back(l[i]);
+    const TooN::SO3<types::Float> AB(v3(p + 3), v3(p + 6));
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) out.push_back(AB.get_matrix()(i, j));
+    const hm::M3 H = hm::so3_exp(p);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) out.push_back(H.a[i][j]);
+  } else {
+    return 2;
+  }
+  std::ofstream o(argv[3], std::ios::binary);
+  o.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)(out.size() * sizeof(float)));
+  return 0;
+}

@@ -120,15 +120,18 @@ int main(int argc, char** argv) {
 
   // --- Core::updateInverseDepthARLU on keylines with a synthetic match ---
   std::vector<float> ekf((size_t)K * 2);
-  rebvio::types::Vector3f v = TooN::makeVector(0.01f, -0.004f, 0.02f);
+  // three motions: a generic one, one that pushes rho above RHO_MAX (k % 7 == 0) and one that pushes it below RHO_MIN (== 1)
+  rebvio::types::Vector3f vs[3] = {TooN::makeVector(0.01f, -0.004f, 0.02f), TooN::makeVector(0.01f, -0.004f, -0.01f),
+                                   TooN::makeVector(0.01f, -0.004f, 200.0f)};
   for (int k = 0; k < K; ++k) {
+    rebvio::types::Vector3f& v = vs[k % 7 == 0 ? 1 : (k % 7 == 1 ? 2 : 0)];
     rebvio::types::KeyLine kl = (*maps[1])[(k * 13) % n1];
     kl.match_pos_img = kl.pos_img + TooN::makeVector(0.5f - 0.01f * (k % 90), -0.3f + 0.02f * (k % 40));
     kl.match_gradient = kl.gradient;
     kl.match_gradient_norm = kl.gradient_norm;
     kl.match_id = 1;
-    kl.rho = (k % 7 == 0) ? 19.99f : 0.002f + 0.03f * k;   // exercises both clamps
-    kl.sigma_rho = 0.01f + 0.05f * (k % 100);
+    kl.rho = (k % 7 == 0) ? 19.99f : (k % 7 == 1 ? 0.0011f : 0.002f + 0.03f * k);
+    kl.sigma_rho = (k % 7 <= 1) ? 0.001f : 0.01f + 0.05f * (k % 100);
     core.updateInverseDepthARLU(kl, v);
     ekf[k * 2] = kl.rho;
     ekf[k * 2 + 1] = kl.sigma_rho;

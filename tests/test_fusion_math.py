@@ -1,0 +1,218 @@
+"""Inertial-fusion host math pinned INDEPENDENTLY of the oracle (the host code and its
+oracle were the same text twice, so comparing them proved nothing about the fusion math).
+
+Everything here is stated in float64 numpy from the mathematical definition, not from the reference's expressions:
+  * SABEstimator::problem (sab_estimator.cpp:41-165): JtF against central finite differences of the weighted cost
+    E(X) = 1/2 F(X)^T W(a) F(X); the blocks of JtJ against the same combinations built from finite-difference Jacobians;
+  * SABEstimator::gaussNewton: the point it returns is a stationary point of that cost;
+  * Core::gyroBiasCorrection (core.cpp:264-284): against the joint 9x9 normal equations of eq. (27) of Tarrio & Pedre 2017
+    (the reference eliminates the bias with a Schur complement; here nothing is eliminated);
+  * Cholesky<6>::get_inverse, SO3 exp / ln / two-vector constructor: against numpy.linalg.inv, scipy.linalg.expm / logm
+    and the defining properties of the minimal rotation.
+Runs on the CPU (host code only)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.linalg import expm, logm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "rebvio_amd", "_build")
+
+
+@pytest.fixture(scope="module")
+def tool(tmp_path_factory):
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rebvio_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rebvio_amd", "host")], check=True)
+    exe = str(tmp_path_factory.mktemp("hostmath") / "host_math_dump")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "host_math_dump.cpp"), "-o", exe, "-L", BUILD, "-lrebvio", "-lrebvio_hip",
+                    f"-Wl,-rpath,{BUILD}", "-pthread"], check=True)
+
+    def run(mode, values, tmp=os.path.dirname(exe)):
+        fi, fo = os.path.join(tmp, "in.f32"), os.path.join(tmp, "out.f32")
+        np.asarray(values, np.float32).tofile(fi)
+        r = subprocess.run([exe, mode, fi, fo], capture_output=True, text=True)
+        assert r.returncode == 0, (mode, r.returncode, r.stderr)
+        return np.fromfile(fo, np.float32).astype(np.float64)
+    return run
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], np.float64)
+
+
+# ---- SAB measurement model, stated from the paper (eq. 40): residual vector and its weight --------------------------------
+class SabModel:
+    def __init__(self, a_v, a_s, G, x_p, Pp, Rv, Rs, Rg):
+        f = lambda v: np.asarray(np.asarray(v, np.float32), np.float64)  # the values the host sees  # noqa: E731
+        self.a_v, self.a_s, self.G, self.x_p, self.Pp, self.Rv, self.Rs, self.Rg = f(a_v), f(a_s), float(np.float32(G)), f(x_p), f(Pp), f(Rv), f(Rs), float(np.float32(Rg))
+
+    def F(self, X):
+        a, g, b = X[0], X[1:4], X[4:7]
+        r = np.zeros(11)
+        r[0:3] = (self.a_s + g) * np.cos(a) - self.a_v * np.sin(a)   # metric vs visual acceleration in polar form
+        r[3] = g @ g - self.G ** 2                                   # |g| = standard gravity
+        d = a - self.x_p[0]
+        r[4] = (d + np.pi) % (2 * np.pi) - np.pi                     # angle prior, wrapped
+        r[5:8] = expm(skew(b)) @ g - self.x_p[1:4]                   # gravity prior, rotated by the visual rotation bias
+        r[8:11] = b - self.x_p[4:7]                                  # bias prior
+        return r
+
+    def P(self, a):
+        P = np.zeros((11, 11))
+        P[0:3, 0:3] = np.sin(a) ** 2 * self.Rv + np.cos(a) ** 2 * self.Rs
+        P[3, 3] = self.Rg
+        P[4:, 4:] = self.Pp
+        return P
+
+    def W(self, a):
+        return np.linalg.inv(self.P(a))
+
+    def cost(self, X):
+        F = self.F(X)
+        return 0.5 * F @ self.W(X[0]) @ F
+
+    def pack(self, X):
+        return np.concatenate([self.a_v, self.a_s, [self.G], self.x_p, self.Pp.ravel(), self.Rv.ravel(), self.Rs.ravel(), [self.Rg], X])
+
+
+def central(f, X, i, h):
+    e = np.zeros_like(X)
+    e[i] = h
+    return (f(X + e) - f(X - e)) / (2 * h)
+
+
+def make_model(rng, b_scale, bias_var=1e-4):
+    a_s = np.array([0.3, -9.6, 0.4]) + rng.normal(0, 0.2, 3)
+    a_v = rng.normal(0, 0.5, 3)
+    x_p = np.concatenate([[0.7 + rng.normal(0, 0.05)], -a_s + rng.normal(0, 0.05, 3), rng.normal(0, b_scale, 3)])
+    A = rng.normal(0, 1, (7, 7))
+    Pp = A @ A.T * 1e-3 + np.diag([1e-2, 1e-1, 1e-1, 1e-1, 1e-4, 1e-4, 1e-4])
+    if bias_var != 1e-4:  # a tight, uncorrelated bias prior keeps the bias away from its saturation bound
+        Pp[4:, :] = Pp[:, 4:] = 0.0
+        Pp[4:, 4:] = np.eye(3) * bias_var
+    B = rng.normal(0, 1, (3, 3))
+    Rv = B @ B.T * 1e-3 + np.eye(3) * 1e-2
+    C = rng.normal(0, 1, (3, 3))
+    Rs = C @ C.T * 1e-3 + np.eye(3) * 2e-2
+    return SabModel(a_v, a_s, 9.81, x_p, Pp, Rv, Rs, 4.0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("b_scale", [0.0, 5e-3], ids=["bias0", "bias5mrad"])
+def test_sab_problem_gradient_and_gauss_newton_blocks_match_finite_differences(tool, seed, b_scale):
+    rng = np.random.default_rng(seed)
+    m = make_model(rng, b_scale)
+    X = np.asarray(np.asarray(m.x_p + np.concatenate([[0.03], rng.normal(0, 0.05, 3), rng.normal(0, b_scale, 3)]), np.float32), np.float64)
+    out = tool("sab", m.pack(X))
+    JtJ, JtF = out[:49].reshape(7, 7), out[49:56]
+
+    # gradient of the weighted cost. d(exp(b) g)/db is taken by the reference at first order in b (-[exp(b) g]_x), so the
+    # three bias entries agree to O(|b|) only; exact for b = 0. fp32 evaluation of 11x11 products: 2e-4 relative.
+    grad = np.array([central(m.cost, X, i, 1e-6) for i in range(7)])
+    scale = np.abs(grad).max()
+    tol = np.full(7, 3e-4 * scale)
+    if b_scale > 0:
+        tol[4:7] = 0.03 * scale
+    assert (np.abs(JtF - grad) <= tol).all(), (JtF, grad)
+
+    # Gauss-Newton blocks from finite-difference Jacobians of F and W (same combinations as eq. 40's normal equations)
+    J = np.stack([central(m.F, X, i, 1e-6) for i in range(7)], axis=1)       # 11 x 7
+    a = X[0]
+    dW = (m.W(a + 1e-6) - m.W(a - 1e-6)) / 2e-6
+    W, P, F = m.W(a), m.P(a), m.F(X)
+    J1, Ja = J[:, 1:], J[:, 0]
+    H11 = J1.T @ W @ J1
+    H10 = 0.5 * J1.T @ dW @ F + J1.T @ W @ Ja
+    H00 = 0.25 * F @ dW @ P @ dW @ F + Ja @ dW @ F + Ja @ W @ Ja
+    rel = 2e-3 if b_scale == 0 else 0.05
+    assert np.abs(JtJ[1:, 1:] - H11).max() <= rel * np.abs(H11).max()
+    assert np.abs(JtJ[1:, 0] - H10).max() <= rel * np.abs(H10).max() + 1e-6 * np.abs(H11).max()
+    assert np.abs(JtJ[0, 1:] - H10).max() <= rel * np.abs(H10).max() + 1e-6 * np.abs(H11).max()
+    assert abs(JtJ[0, 0] - H00) <= rel * abs(H00)
+
+
+@pytest.mark.parametrize("seed", [4, 5, 6])
+def test_sab_gauss_newton_ends_at_a_stationary_point_of_the_cost(tool, seed):
+    rng = np.random.default_rng(seed)
+    m = make_model(rng, 0.0, bias_var=1e-9)
+    X0 = np.asarray(np.asarray(m.x_p, np.float32), np.float64)
+    out = tool("sab", m.pack(X0))
+    Xg, it = out[56:63], int(out[63])
+    assert it == 20  # default tolerances are zero: all iterations run (sab_estimator.cpp:24-36)
+    # (the step is clipped per coordinate AFTER it is taken, sab_estimator.cpp:33: with a coordinate on its bound the
+    # iteration settles off the stationary point, so this case keeps the bias inside +-5e-1/25)
+    assert np.abs(Xg[4:7]).max() < 0.019
+    g0 = np.array([central(m.cost, X0, i, 1e-6) for i in range(7)])
+    g1 = np.array([central(m.cost, Xg, i, 1e-6) for i in range(7)])
+    assert m.cost(Xg) < m.cost(X0)
+    # Gauss-Newton drives ITS gradient (JtF, verified above to be the cost's gradient, in the bias entries to first order in
+    # |b|) to zero in the un-saturated directions; fp32 state: a floor of ~1e-3 of the initial gradient
+    JtF_end = tool("sab", m.pack(Xg))[49:56]
+    assert np.abs(JtF_end).max() <= 2e-3 * np.abs(g0).max(), (g0, JtF_end)
+    # and the exact gradient has collapsed with it where the reference's Jacobian is exact (scale, gravity)
+    assert np.abs(g1[:4]).max() <= 0.05 * np.abs(g0).max(), (g0, g1)
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_gyro_bias_correction_is_the_joint_minimiser(tool, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(0, 1, (6, 6))
+    Wx = (A @ A.T + np.eye(6) * 3) * 1e3
+    X = np.concatenate([rng.normal(0, 0.02, 3), rng.normal(0, 2e-3, 3)])
+    Wb = np.diag(rng.uniform(0.5, 2, 3)) * 1e4
+    Rg = np.diag(rng.uniform(0.5, 2, 3)) * 1e-5
+    Rb = np.diag(rng.uniform(0.5, 2, 3)) * 1e-7
+    f32 = lambda v: np.asarray(np.asarray(v, np.float32), np.float64)  # noqa: E731
+    Wx, X, Wb, Rg, Rb = f32(Wx), f32(X), f32(Wb), f32(Rg), f32(Rb)
+    out = tool("gbc", np.concatenate([X, Wx.ravel(), Wb.ravel(), Rg.ravel(), Rb.ravel()]))
+    X1, Wx1, Wb1, dg = out[:6], out[6:42].reshape(6, 6), out[42:51].reshape(3, 3), out[51:54]
+    # joint problem over z = (v, w, b): (z[:6] - X)' Wx (z[:6] - X) + (w - b)' Wg (w - b) + b' Wb' b, Wb' = (Wb^-1 + Rb)^-1
+    Wg, Wbp = np.linalg.inv(Rg), np.linalg.inv(np.linalg.inv(Wb) + Rb)
+    H = np.zeros((9, 9))
+    H[:6, :6] = Wx
+    H[3:6, 3:6] += Wg
+    H[3:6, 6:9] = -Wg
+    H[6:9, 3:6] = -Wg
+    H[6:9, 6:9] = Wg + Wbp
+    z = np.linalg.solve(H, np.concatenate([Wx @ X, np.zeros(3)]))
+    assert np.abs(X1 - z[:6]).max() <= 2e-4 * np.abs(z[:6]).max()
+    assert np.abs(dg - z[6:9]).max() <= 2e-4 * np.abs(z[6:9]).max() + 1e-9
+    # information bookkeeping: the bias information gains the gyro's, so does the rotation block of the state
+    assert np.abs(Wb1 - (Wg + Wbp)).max() <= 1e-5 * np.abs(Wg + Wbp).max()
+    want = Wx.copy()
+    want[3:, 3:] += Wg
+    assert np.abs(Wx1 - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("seed", [10, 11])
+def test_cholesky6_inverse_against_numpy(tool, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(0, 1, (6, 6))
+    S = np.asarray(np.asarray(A @ A.T + np.eye(6) * 0.5, np.float32), np.float64)
+    inv = tool("chol6", S.ravel()).reshape(6, 6)
+    assert np.abs(inv @ S - np.eye(6)).max() <= 5e-5 * np.linalg.cond(S)
+    assert np.abs(inv - np.linalg.inv(S)).max() <= 5e-6 * np.linalg.cond(S) * np.abs(np.linalg.inv(S)).max()
+
+
+@pytest.mark.parametrize("w", [(0.3, -0.2, 0.5), (1e-5, 2e-5, -1e-5), (4e-4, -3e-4, 2e-4), (2.0, 1.5, -1.0), (0.0, 3.0, 0.0)])
+def test_so3_exp_ln_and_two_vector_constructor(tool, w):
+    w = np.asarray(np.asarray(w, np.float32), np.float64)
+    a, b = np.array([0.2, 9.7, -0.4]), np.array([0.0, 1.0, 0.0])
+    out = tool("so3", np.concatenate([w, a, b]))
+    R, ln, Rab, Rh = out[:9].reshape(3, 3), out[9:12], out[12:21].reshape(3, 3), out[21:30].reshape(3, 3)
+    E = expm(skew(w))
+    assert np.abs(R - E).max() <= 3e-7 and np.abs(Rh - E).max() <= 3e-7        # Rodrigues == matrix exponential
+    assert np.abs(R.T @ R - np.eye(3)).max() <= 5e-7
+    assert np.abs(ln - w).max() <= 2e-6 * max(1.0, np.abs(w).max())             # ln inverts exp below pi
+    assert np.abs(np.real(logm(R)) - skew(ln)).max() <= 2e-6 * max(1.0, np.abs(w).max())
+    # SO3(a, b): rotation about a x b taking a/|a| to b/|b|
+    a, b = np.asarray(np.asarray(a, np.float32), np.float64), np.asarray(np.asarray(b, np.float32), np.float64)
+    ua, ub = a / np.linalg.norm(a), b / np.linalg.norm(b)
+    assert np.abs(Rab @ ua - ub).max() <= 5e-7
+    assert np.abs(Rab.T @ Rab - np.eye(3)).max() <= 5e-7 and np.linalg.det(Rab) > 0.999
+    axis = np.cross(ua, ub)
+    assert np.abs(Rab @ axis - axis).max() <= 5e-7                              # the axis is fixed: minimal rotation
+    assert abs(np.trace(Rab) - (1 + 2 * ua @ ub)) <= 1e-6                       # angle = angle between a and b

@@ -116,9 +116,16 @@ def _write_imu(path, ts, gyro, acc):
 EUROC_D = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]  # camera.hpp:31-35
 
 
+# (size, frame period, keyline budget, min matches): the small 20 Hz stream of round 1, and BASELINE config 5 as stated -
+# 640x480 @ 30 Hz camera + 200 Hz IMU, the bench's keyline budget, the reference's default match threshold
+VIO_SMALL = (256, 192, 50000, 2500, 3500, 100)
+VIO_CONFIG5 = (640, 480, 33333, 15000, 16000, 500)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dist", [None, EUROC_D], ids=["pinhole", "radtan"])
-def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod, dist):
+@pytest.mark.parametrize("dist,shape", [(None, VIO_SMALL), (EUROC_D, VIO_SMALL), (None, VIO_CONFIG5), (EUROC_D, VIO_CONFIG5)],
+                         ids=["pinhole", "radtan", "config5-640x480-30Hz", "config5-640x480-30Hz-radtan"])
+def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod, dist, shape):
     """BASELINE config 5 (camera + IMU, SAB scale/attitude/bias filter): rebvio::Rebvio on the device against the oracle's
     restatement of rebvio.cpp:92-293 on the same frames and IMU samples. The per-keyline work is bit-exact, the reductions
     feeding the 3x3 / 6x6 / 7x7 solves are not (REL_SUM in test_parity_gpu.py), so the fused state is compared in tolerance:
@@ -126,40 +133,42 @@ def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod, dist):
     on MI355X: <= 2e-6 everywhere, match counts identical). The "radtan" case adds the EuRoC lens model: the MONO8 frames
     then pass through the device front end (x3 + undistort) on one side and the oracle's on the other."""
     from rebvio_amd import synth
-    n, W, H = 30, 256, 192
+    W, H, dt_us, kref, kmax, min_matches = shape
+    n = 30
     frames, cam = synth.render_stream(W, H, n, dist=dist)
     scene = synth.make_scene(0)
-    ts, gyro, acc = synth.imu_samples(scene, n, noise_seed=1)
+    ts, gyro, acc = synth.imu_samples(scene, n, frame_dt_us=dt_us, noise_seed=1)
+    assert ts[1] - ts[0] == 5000  # 200 Hz
     fp, ip = tmp_path / "frames.u8", tmp_path / "imu.bin"
     frames.tofile(fp)
     _write_imu(ip, ts, gyro, acc)
     exe = os.path.join(host_lib, "rebvio_stream_example")
-    env = dict(os.environ)
+    env = dict(os.environ, REBVIO_EXAMPLE_FRAME_DT_US=str(dt_us))
     if dist is not None:
         env["REBVIO_EXAMPLE_DISTORTION"] = ",".join(repr(float(np.float32(v))) for v in dist)
-    r = subprocess.run([exe, str(fp), str(W), str(H), str(n), str(cam.fm), str(cam.cx), str(cam.cy), "2500", "3500", str(ip), "100"],
-                       capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([exe, str(fp), str(W), str(H), str(n), str(cam.fm), str(cam.cx), str(cam.cy), str(kref), str(kmax), str(ip),
+                        str(min_matches)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines() if ln and ln[0].isdigit()])
     assert got.shape == (n - 1, 15)
 
-    p = orc_mod.default_params(H, W, fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=2500, keylines_max=3500,
-                               global_min_matches_threshold=100)
+    p = orc_mod.default_params(H, W, fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=kref, keylines_max=kmax,
+                               global_min_matches_threshold=min_matches)
     orc = orc_mod.Oracle(p)
     orc.vio_reset()
     prev, k, want = None, 0, []
     for i in range(n):
         if dist is None:
-            m = orc.detect_u8(frames[i], i * 50000)
+            m = orc.detect_u8(frames[i], i * dt_us)
         else:
-            m = orc.detect(orc.front_end_u8(frames[i], cam.fm, cam.fm, cam.cx, cam.cy, dist), i * 50000)
-        while k < len(ts) and ts[k] <= i * 50000:
+            m = orc.detect(orc.front_end_u8(frames[i], cam.fm, cam.fm, cam.cx, cam.cy, dist), i * dt_us)
+        while k < len(ts) and ts[k] <= i * dt_us:
             orc.vio_add_imu(m, ts[k], gyro[k], acc[k])
             k += 1
         if prev is not None:
             o = orc.vio_step(prev, m)
             assert o.pair.status == 0
-            want.append([i * 50000] + list(o.orientation) + list(o.position) + [o.K] + list(o.g_est) + list(o.Bg) + [o.pair.klm_num])
+            want.append([i * dt_us] + list(o.orientation) + list(o.position) + [o.K] + list(o.g_est) + list(o.Bg) + [o.pair.klm_num])
         prev = m
     want = np.array(want)
     assert (got[:, 0] == want[:, 0]).all()
@@ -283,14 +292,15 @@ def test_public_cpp_surface_matches_oracle(host_lib, tmp_path, orc_mod):
 
     # Core::updateInverseDepthARLU (both clamps occur)
     ekf = load("ekf.bin", np.float32).reshape(K, 2)
-    v = np.array([0.01, -0.004, 0.02], np.float32)
+    vs = [np.array([0.01, -0.004, z], np.float32) for z in (0.02, -0.01, 200.0)]
     for k in range(K):
+        v = vs[1 if k % 7 == 0 else (2 if k % 7 == 1 else 0)]
         kl = ko[1][(k * 13) % n1:(k * 13) % n1 + 1].copy()
         kl["match_pos_img"][0, 0] = kl["pos_img"][0, 0] + (f32(0.5) - f32(0.01) * f32(k % 90))
         kl["match_pos_img"][0, 1] = kl["pos_img"][0, 1] + (f32(-0.3) + f32(0.02) * f32(k % 40))
         kl["match_gradient"], kl["match_gradient_norm"], kl["match_id"] = kl["gradient"], kl["gradient_norm"], 1
-        kl["rho"] = f32(19.99) if k % 7 == 0 else f32(0.002) + f32(0.03) * f32(k)
-        kl["sigma_rho"] = f32(0.01) + f32(0.05) * f32(k % 100)
+        kl["rho"] = f32(19.99) if k % 7 == 0 else (f32(0.0011) if k % 7 == 1 else f32(0.002) + f32(0.03) * f32(k))
+        kl["sigma_rho"] = f32(0.001) if k % 7 <= 1 else f32(0.01) + f32(0.05) * f32(k % 100)
         L.orc_update_inverse_depth_arlu(orc.h, kl.ctypes.data, v.ctypes.data_as(C.POINTER(C.c_float)))
         want = np.array([kl["rho"][0], kl["sigma_rho"][0]], np.float32)
         assert np.array_equal(want.view(np.uint32), ekf[k].view(np.uint32)), (k, want, ekf[k])
