@@ -150,6 +150,7 @@ struct rebvio_hip_map {
   bool has_done = false;
   uint64_t release_seq = 0;  // order of release (pool reuse is oldest-first)
   bool df_built = false;
+  bool raster_order = false;  // keylines + row_start as detection left them (false after map_upload)
   std::atomic<int> enqueued{1};  // 0 while the detect worker still has to record `ready` (streaming driver)
   bool pre_rotated = false;  // the next pair's first rotateKeylines (+ histogram) was already applied by the fused B-chain
   int n_host = -1;
@@ -304,6 +305,16 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipMalloc(&d.residual, M * sizeof(float)));
   HIPCHK(hipMalloc(&d.mask, Pn * sizeof(int)));
   HIPCHK(hipMalloc(&d.df, Pn * sizeof(unsigned)));
+  HIPCHK(hipMalloc(&d.unit, M * sizeof(float2)));
+  {
+    const DfGrid g = df_grid(c->P.rows, c->P.cols);
+    const size_t nt = (size_t)g.ntx * g.nty;
+    HIPCHK(hipMalloc(&d.tile_cnt, nt * sizeof(int)));
+    HIPCHK(hipMemset(d.tile_cnt, 0, nt * sizeof(int)));
+    HIPCHK(hipMalloc(&d.tile_list, nt * kDfTileCap * 2 * sizeof(float4)));
+  }
+  HIPCHK(hipMalloc(&d.row_start, ((size_t)c->P.rows + 1) * sizeof(int)));
+  HIPCHK(hipMemset(d.row_start, 0, ((size_t)c->P.rows + 1) * sizeof(int)));
   HIPCHK(hipMalloc(&d.st, sizeof(MapState)));
   HIPCHK(hipMemset(d.st, 0, sizeof(MapState)));
   HIPCHK(hipMemset(d.mask, 0xFF, Pn * sizeof(int)));
@@ -317,7 +328,7 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
 void free_map(rebvio_hip_map* m) {
   MapDev& d = m->d;
   void* ptrs[] = {d.pos, d.pos_img, d.mpos_img, d.grad, d.grad_tmp, d.mgrad, d.gnorm, d.mgnorm, d.rs, d.rs_tmp, d.id_prev, d.id_next,
-                  d.match_id, d.match_fwd, d.match_kf, d.matches, d.fwd_key, d.residual, d.mask, d.df, d.st};
+                  d.match_id, d.match_fwd, d.match_kf, d.matches, d.fwd_key, d.residual, d.mask, d.df, d.unit, d.tile_cnt, d.tile_list, d.row_start, d.st};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (m->ready) (void)hipEventDestroy(m->ready);
@@ -337,6 +348,7 @@ rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
     rebvio_hip_map* m = best;
     m->in_use = true;
     m->df_built = false;
+    m->raster_order = false;
     m->pre_rotated = false;
     m->n_host = -1;
     m->thr_host = -1.0f;
@@ -427,6 +439,7 @@ int detect_prepare(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t t
   if (!m) return fail_msg("edge-map pool exhausted (release maps or raise map_pool)", -2);
   m->ts = ts;
   m->df_built = true;
+  m->raster_order = true;
   job->m = m;
   job->img = img_dev;
   job->is_u8 = is_u8;
@@ -1116,6 +1129,7 @@ int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines,
   }
   HIPCHK(hipStreamSynchronize(c->s_cpy));
   m->df_built = false;
+  m->raster_order = false;  // arbitrary keylines: the rebuild goes through the scatter kernel
   return 0;
 }
 
@@ -1134,9 +1148,10 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
 int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
-  if (!m->df_built) {
-    HIPCHK(hipMemsetAsync(m->d.df, 0xFF, (size_t)c->P.rows * c->P.cols * sizeof(unsigned), c->s_trk));
-    launch_df_build(c->s_trk, c->K, m->d, c->det + (c->frame_index % kDetRing), false);  // keylines may have been uploaded
+  static const bool force = std::getenv("REBVIO_HIP_DF_FORCE") != nullptr;  // diagnostic: rebuild on every call (tools/df_probe.py)
+  if (!m->df_built || force) {
+    if (!m->raster_order) HIPCHK(hipMemsetAsync(m->d.df, 0xFF, (size_t)c->P.rows * c->P.cols * sizeof(unsigned), c->s_trk));
+    launch_df_build(c->s_trk, c->K, m->d, c->det + (c->frame_index % kDetRing), m->raster_order);  // keylines may have been uploaded
     HIPCHK(hipGetLastError());
     m->df_built = true;
   }

@@ -20,6 +20,9 @@ constexpr unsigned kDfSeqMask = (1u << kDfSeqBits) - 1u;
 constexpr int kPartStride = 16;     // floats per block record of k_try_vel
 constexpr int kXrvStride = 32;      // floats per block record of k_ext_rot_vel
 constexpr int kMaxLmCalls = 8;
+constexpr int kDfTile = 32;         // distance-field tile edge (pixels); 64 for sensors with more than kDfMaxTiles 32-pixel tiles
+constexpr int kDfMaxTiles = 4096;   // per-workgroup LDS counter table of the binning pass
+constexpr int kDfTileCap = 512;     // list capacity per tile (32-byte entries); a fuller tile falls back to scanning its candidate rows
 constexpr int kMaxRecBlocks = 256;   // record groups (256 keylines each) the LM reduction stages in LDS: keylines_max <= 65536
 constexpr int kDetRing = 4;         // DetState ring depth (distance-field stream may lag the detect stream)
 constexpr float kResidualCarry = -1.0f;  // marker: "|fi| carried in from an earlier block" (see try_vel)
@@ -68,6 +71,10 @@ struct MapDev {
   float* residual;              // minimizeVel's residuals[] for this (old) map
   int* mask;                    // dense image index -> keyline index
   unsigned* df;                 // distance field keys built from this map
+  float2* unit;                 // gradient / gradient_norm as DistanceField::build forms it (core.hpp:50-51), left by joinEdges
+  int* tile_cnt;                // [tiles] keylines whose +-search_range segment crosses each distance-field tile (joinEdges bins them)
+  float4* tile_list;            // [tiles][kDfTileCap][2] their entries {pos.x, pos.y, u.x, u.y} {idx, r-range, gradient_norm, -}, any order
+  int* row_start;               // [rows + 1] index of the first keyline detected in each pixel row (raster rank; [rows] = n)
   MapState* st;
 };
 
@@ -138,6 +145,25 @@ inline bool df_scatter_mode() {
   static const bool v = [] {
     const char* e = std::getenv("REBVIO_HIP_DF");
     return e && std::string(e) == "scatter";
+  }();
+  return v;
+}
+// Tile grid of the keyline-driven distance-field build (shared by the binning pass in k_join_edges and the tile kernel).
+struct DfGrid {
+  int T, ntx, nty;
+};
+inline DfGrid df_grid(int rows, int cols) {
+  DfGrid g;
+  g.T = kDfTile;
+  while (((cols + g.T - 1) / g.T) * ((rows + g.T - 1) / g.T) > kDfMaxTiles) g.T *= 2;
+  g.ntx = (cols + g.T - 1) / g.T;
+  g.nty = (rows + g.T - 1) / g.T;
+  return g;
+}
+inline bool df_tiles_mode() {  // REBVIO_HIP_DF=tiles: the mask-driven 32x32 tile kernel of round 1 (kept for A/B runs)
+  static const bool v = [] {
+    const char* e = std::getenv("REBVIO_HIP_DF");
+    return e && std::string(e) == "tiles";
   }();
   return v;
 }

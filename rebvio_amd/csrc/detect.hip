@@ -9,6 +9,7 @@
 // Bound: HBM/L2 bandwidth for the per-pixel sweeps; the two scan kernels are additionally bound by
 // their sequential fp32 add chains (cols resp. rows dependent adds) which bit-exactness requires.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include <cstring>
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
                                                       const unsigned long long* __restrict__ bits,
                                                       const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
                                                       DetState* __restrict__ det_out, const MapState* prev_st,
-                                                      int clear_df) {
+                                                      int clear_df, int ntiles) {
   const int R = p.rows, C = p.cols;
   const int r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.x * 64 + threadIdx.x;
   const int lane = threadIdx.x;
@@ -500,6 +501,12 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
   for (int i = lane; i < r; i += 64) part += rowcount[i];
   if (lane < (int)blockIdx.x) part += __popcll(bits[(size_t)r * p.nseg + lane]);
   const int offset = wave_sum(part);
+  // raster rank of the row's first keyline (segment 0: offset holds the earlier rows only), clamped like the ranks below
+  if (blockIdx.x == 0 && lane == 0) m.row_start[r] = min(offset, p.kmax);
+  {  // the distance-field tile counters of this map start at zero (k_join_edges bins into them)
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x, t = wg * 256 + threadIdx.y * 64 + threadIdx.x;
+    if (t < ntiles) m.tile_cnt[t] = 0;
+  }
   if (r == 0 && blockIdx.x == 0) {  // one wave publishes the frame's scalars
     int tp = 0;
     for (int i = lane; i < R; i += 64) tp += rowcount[i];
@@ -509,6 +516,7 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
       // this map's scalars are reset: the pool may hand the previous frame's map back for this one (prev_st == m.st).
       const float prev_auto = prev_st ? auto_threshold_from(*prev_st, det_in->auto_threshold) : det_in->auto_threshold;
       const int n = min(total, p.kmax);
+      m.row_start[R] = n;
       m.st->n = n;
       m.st->total = total;
       m.st->gmin_bits = 0x7F800000u;
@@ -554,11 +562,51 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
 }
 
 // ---- joinEdges (edge_detector.cpp:125-165) + min/max of gradient_norm for tuneThreshold (:168-174) -----
-__global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m) {
+// r-range of a keyline's probe segment (cells round(pos + u r), r in [-half, half)) that can fall into the pixel box
+// [x0, x1) x [y0, y1): conservative (one cell of slack on each side, the exact test per cell is made by whoever walks the
+// range), so the two reciprocals are the 1-ulp hardware ones. Returns false when no cell can fall into the box.
+__device__ __forceinline__ bool df_clip_range(float2 pos, float2 u, int half, int x0, int x1, int y0, int y1, int* r_lo, int* r_hi) {
+  const float fx0 = (float)x0 - 1.0f, fx1 = (float)x1, fy0 = (float)y0 - 1.0f, fy1 = (float)y1;
+  float lo = -(float)half, hi = (float)(half - 1);
+  if (fabsf(u.x) > 1e-6f) {
+    const float iv = __builtin_amdgcn_rcpf(u.x);
+    const float a = (fx0 - pos.x) * iv, b = (fx1 - pos.x) * iv;
+    lo = fmaxf(lo, fminf(a, b));
+    hi = fminf(hi, fmaxf(a, b));
+  } else if (pos.x < fx0 || pos.x > fx1) {
+    hi = lo - 1.0f;
+  }
+  if (fabsf(u.y) > 1e-6f) {
+    const float iv = __builtin_amdgcn_rcpf(u.y);
+    const float a = (fy0 - pos.y) * iv, b = (fy1 - pos.y) * iv;
+    lo = fmaxf(lo, fminf(a, b));
+    hi = fminf(hi, fmaxf(a, b));
+  } else if (pos.y < fy0 || pos.y > fy1) {
+    hi = lo - 1.0f;
+  }
+  *r_lo = max((int)floorf(lo) - 1, -half);
+  *r_hi = min((int)ceilf(hi) + 1, half - 1);
+  return hi >= lo && *r_hi >= *r_lo;
+}
+
+// joinEdges also prepares the distance field of this map (core.hpp:37-59): it leaves every keyline's unit gradient and
+// bins the keyline into the T x T tiles its +-search_range segment crosses (a segment of 80 cells crosses ~3.5 tiles of
+// 32 x 32). A workgroup's 256 keylines are neighbours in raster order, so they share tiles: counts are aggregated in an
+// LDS table, one returning global atomic per touched tile and workgroup reserves the slots, and the crossing test is
+// simply evaluated twice (count, then place) instead of keeping per-thread tile lists.
+__global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m, int T, int ntx, int nty) {
+  extern __shared__ int t_cnt[];  // [ntx * nty] count, then cursor, of this workgroup's keylines per tile
   const int n = m.st->n;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int C = p.cols;
+  const int ntiles = ntx * nty;
+  const bool live_wg = (int)blockIdx.x * 256 < n;
+  if (live_wg)
+    for (int t = threadIdx.x; t < ntiles; t += 256) t_cnt[t] = 0;
   unsigned gb = 0x7F800000u, gB = 0u;
+  float2 b_pos = make_float2(0.f, 0.f), b_u = make_float2(0.f, 0.f);
+  float b_gn = 0.f;
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;  // tile bounding box of the segment (empty for threads without a keyline)
   if (idx < n) {
     const float2 pos = m.pos[idx];
     const float2 g = m.grad[idx];
@@ -584,7 +632,48 @@ __global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m) {
       atomicMax(&m.id_prev[nxt], idx);  // sequential last-writer-wins == largest index
       m.id_next[idx] = nxt;
     }
-    gb = gB = __float_as_uint(m.gnorm[idx]);
+    const float gnv = m.gnorm[idx];
+    gb = gB = __float_as_uint(gnv);
+    // unit gradient of DistanceField::build (core.hpp:50-51: gradient / gradient_norm, IEEE division), once per keyline
+    b_u = make_float2(g.x / gnv, g.y / gnv);
+    m.unit[idx] = b_u;
+    b_pos = pos;
+    b_gn = gnv;
+    // tiles the segment's bounding box touches (end points +- one cell for the rounding)
+    const int half = p.df_nr >> 1;
+    const float ex = fabsf(b_u.x) * (float)half + 1.5f, ey = fabsf(b_u.y) * (float)half + 1.5f;
+    tx0 = max(cvtt_f32(floorf(pos.x - ex)), 0) / T;
+    tx1 = min(cvtt_f32(floorf(pos.x + ex)), C - 1) / T;
+    ty0 = max(cvtt_f32(floorf(pos.y - ey)), 0) / T;
+    ty1 = min(cvtt_f32(floorf(pos.y + ey)), p.rows - 1) / T;
+  }
+  if (live_wg) {
+    const int half = p.df_nr >> 1;
+    __syncthreads();
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        int rl, rh;
+        if (df_clip_range(b_pos, b_u, half, tx * T, min(tx * T + T, C), ty * T, min(ty * T + T, p.rows), &rl, &rh))
+          atomicAdd(&t_cnt[ty * ntx + tx], 1);
+      }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+      const int c = t_cnt[t];
+      if (c) t_cnt[t] = atomicAdd(&m.tile_cnt[t], c);  // base of this workgroup's entries in the tile's list
+    }
+    __syncthreads();
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        int rl, rh;
+        if (df_clip_range(b_pos, b_u, half, tx * T, min(tx * T + T, C), ty * T, min(ty * T + T, p.rows), &rl, &rh)) {
+          const int slot = atomicAdd(&t_cnt[ty * ntx + tx], 1);
+          if (slot < kDfTileCap) {  // the entry carries everything the tile kernel needs: no gather through the index
+            float4* e = m.tile_list + ((size_t)(ty * ntx + tx) * kDfTileCap + slot) * 2;
+            e[0] = make_float4(b_pos.x, b_pos.y, b_u.x, b_u.y);
+            e[1] = make_float4(__int_as_float(idx), __int_as_float(((rl + 256) << 16) | (rh + 256)), b_gn, 0.f);
+          }
+        }
+      }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -593,6 +682,7 @@ __global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m) {
   }
   // min / max of the gradient norm: wave -> workgroup (LDS) -> one global atomic pair per workgroup
   __shared__ unsigned b_min, b_max;
+  __syncthreads();
   if (threadIdx.x == 0) {
     b_min = 0xFFFFFFFFu;
     b_max = 0u;
@@ -807,6 +897,198 @@ __global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, co
   }
 }
 
+// ---- DistanceField::build, keyline driven (core.hpp:37-59) ----------------------------------------------------------
+// The keylines of a detected map are in raster order (their index IS the raster rank, edge_detector.cpp:109-113) and a
+// keyline detected in pixel row r only reaches field rows r-41 .. r+41 (unit gradient, 40 steps, sub-pixel offset <= 0.5).
+// A workgroup owns a strip of S field rows x W columns in LDS; the keylines that can reach it are the CONTIGUOUS index range
+// row_start[y0 - 41] .. row_start[y1 + 41] (k_keyline_emit leaves the per-row first rank with the map). No mask scan, no
+// binning pass: every candidate is read once per strip that it can reach (20 bytes of geometry), its unit gradient is
+// formed once (the two IEEE divisions of core.hpp:50-51), the r-range that can fall into the strip is clipped, and a wave
+// walks it with LDS atomicMin on the same key as k_df_build (min |r|, ties -> last visited). The finished strip is
+// written with coalesced stores, empty cells included.
+#ifdef RH_DF_PROBE  // tools/df_strips_probe.hip: phase stamps of one workgroup (100 MHz constant clock)
+unsigned long long* g_df_stamps_host = nullptr;
+#define RH_DFS_STAMP(i) do { if (stamps && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && tid == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RH_DFS_STAMP_ARG , unsigned long long* stamps
+#define RH_DFS_STAMP_PASS , g_df_stamps_host
+#define RH_DFS_STAMP_FWD , stamps
+#else
+#define RH_DFS_STAMP(i) do { } while (0)
+#define RH_DFS_STAMP_ARG
+#define RH_DFS_STAMP_PASS
+#define RH_DFS_STAMP_FWD
+#endif
+constexpr int kDfsThreads = 512;
+constexpr int kDfsList = 1024;  // candidates staged per chunk (24 KB)
+constexpr int kDfsSub = 16;     // lanes that walk one keyline's r-range (four keylines per wave)
+
+// Field cells [y0, y1) x [x0, x1) from the row range: every keyline detected in the rows that can reach the box is a
+// candidate. Used by the strip kernel (REBVIO_HIP_DF_STRIP, A/B) and by the tile kernel for a tile whose list overflowed.
+// df_smem: S * W cells, then the staging list (kDfsList entries of 24 bytes).
+__device__ __forceinline__ void df_rowrange_body(const KParams& p, const MapDev& m, float thr, int n, int S, int W, int x0, int x1, int y0,
+                                                 int y1, unsigned* df_smem, int* l_n_ptr RH_DFS_STAMP_ARG) {
+  unsigned* cell = df_smem;                                             // [S][W]
+  float4* l_geo = reinterpret_cast<float4*>(df_smem + (size_t)S * W);   // pos.x, pos.y, g.x/gn, g.y/gn   (S*W is a multiple of 4)
+  int* l_idx = reinterpret_cast<int*>(l_geo + kDfsList);
+  int* l_rr = l_idx + kDfsList;                                         // (r_lo + 256) << 16 | (r_hi + 256)
+  int& l_n = *l_n_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nr = p.df_nr, half = nr >> 1, reach = half + 1;
+  const int ia = min(m.row_start[max(y0 - reach, 0)], n), ib = min(m.row_start[min(y1 + reach, p.rows)], n);
+  for (int i = tid; i < S * W; i += kDfsThreads) cell[i] = kDfEmpty;
+  int stamp_i = 1;
+  (void)stamp_i;
+  RH_DFS_STAMP(stamp_i++);
+  for (int base = ia; base < ib; base += kDfsList) {
+    __syncthreads();  // the previous chunk's walk is finished by every wave (first chunk: the cells are initialised)
+    if (tid == 0) l_n = 0;
+    __syncthreads();
+    const int cend = min(base + kDfsList, ib);
+    for (int i0 = base; i0 < cend; i0 += kDfsThreads) {
+      const int ci = i0 + tid;
+      bool keep = false;
+      float2 pos = make_float2(0.f, 0.f), u = make_float2(0.f, 0.f);
+      int r_lo = 0, r_hi = -1, id = 0;
+      if (ci < cend) {
+        id = ci;
+        const float gn = m.gnorm[id];
+        u = m.unit[id];
+        pos = m.pos[id];
+        if (!(thr > 0.0f && gn < thr)) keep = df_clip_range(pos, u, half, x0, x1, y0, y1, &r_lo, &r_hi);
+      }
+      const unsigned long long km = __ballot(keep);
+      if (km) {
+        int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&l_n, __popcll(km));
+        slot0 = __shfl(slot0, 0);
+        if (keep) {
+          const int slot = slot0 + __popcll(km & ((1ull << lane) - 1ull));
+          l_idx[slot] = id;
+          l_geo[slot] = make_float4(pos.x, pos.y, u.x, u.y);
+          l_rr[slot] = ((r_lo + 256) << 16) | (r_hi + 256);
+        }
+      }
+    }
+    __syncthreads();
+    RH_DFS_STAMP(stamp_i++);
+    const int ln = l_n;
+    const int l16 = tid & (kDfsSub - 1);
+    for (int k = tid / kDfsSub; k < ln; k += kDfsThreads / kDfsSub) {
+      const float4 q = l_geo[k];
+      const int rr = l_rr[k];
+      const int r_hi = (rr & 0xFFFF) - 256;
+      const unsigned seq0 = (unsigned)(l_idx[k] * nr);
+      for (int r = (rr >> 16) - 256 + l16; r <= r_hi; r += kDfsSub) {
+        const float fr = q.w * float(r) + q.y;
+        const float fc = q.z * float(r) + q.x;
+        const int row = cvtt_f32(roundf(fr));
+        const int col = cvtt_f32(roundf(fc));
+        if (row < y0 || row >= y1 || col < x0 || col >= x1) continue;
+        const unsigned key = ((unsigned)abs(r) << kDfSeqBits) | (kDfSeqMask - (seq0 + (unsigned)(r + half)));
+        atomicMin(&cell[(row - y0) * W + (col - x0)], key);
+      }
+    }
+    RH_DFS_STAMP(stamp_i++);
+  }
+  __syncthreads();
+  RH_DFS_STAMP(stamp_i++);
+  const int tw = x1 - x0, th = y1 - y0;
+  if (((p.cols | x0 | tw | W) & 3) == 0) {  // 16-byte rows: vector stores
+    const int tw4 = tw >> 2;
+    for (int i = tid; i < th * tw4; i += kDfsThreads) {
+      const int ty = i / tw4, t4 = i - ty * tw4;
+      *reinterpret_cast<uint4*>(&m.df[(size_t)(y0 + ty) * p.cols + x0 + t4 * 4]) = *reinterpret_cast<const uint4*>(&cell[ty * W + t4 * 4]);
+    }
+  } else {
+    for (int i = tid; i < th * tw; i += kDfsThreads) {
+      const int ty = i / tw, tx = i - ty * tw;
+      m.df[(size_t)(y0 + ty) * p.cols + x0 + tx] = cell[ty * W + tx];
+    }
+  }
+  RH_DFS_STAMP(stamp_i++);
+}
+
+__global__ __launch_bounds__(kDfsThreads) void k_df_strips(KParams p, MapDev m, const DetState* __restrict__ det_prev, int S, int W RH_DFS_STAMP_ARG) {
+  extern __shared__ __align__(16) unsigned df_smem[];
+  __shared__ int l_n;
+  const int tid = threadIdx.x;
+  RH_DFS_STAMP(0);
+  const int n = m.st->n;
+  const float thr = auto_threshold_from(*m.st, det_prev->auto_threshold);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
+  const int y0 = blockIdx.y * S, x0 = blockIdx.x * W;
+  df_rowrange_body(p, m, thr, n, S, W, x0, min(x0 + W, p.cols), y0, min(y0 + S, p.rows), df_smem, &l_n RH_DFS_STAMP_FWD);
+}
+
+// ---- DistanceField::build, one workgroup per T x T tile fed by the tile's list (the default) --------------------------------
+// k_join_edges left, per tile, one 32-byte entry for every keyline whose segment crosses it: position, unit gradient, index,
+// the r-range that can fall into the tile, gradient norm. The workgroup reads its entries with one coalesced pass into LDS,
+// 16-lane groups walk the ranges with LDS atomicMin on the key of k_df_build (min |r|, ties -> last visited), and the
+// finished tile is stored, empty cells included (no clearing pass). A tile whose list overflowed (more than kDfTileCap
+// crossing keylines) is rebuilt from the row range instead: same cells, just slower.
+template <int T>
+__global__ __launch_bounds__(kDfsThreads) void k_df_lists(KParams p, MapDev m, const DetState* __restrict__ det_prev RH_DFS_STAMP_ARG) {
+  extern __shared__ __align__(16) unsigned df_smem[];
+  __shared__ int l_n;
+  const int tid = threadIdx.x;
+  RH_DFS_STAMP(0);
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  // every scalar this workgroup needs, and its own entry, in one round of independent loads
+  const int cnt = m.tile_cnt[tile];
+  const float4* ent = m.tile_list + (size_t)tile * kDfTileCap * 2;
+  const int slot = min(tid, kDfTileCap - 1);
+  const float4 e0 = ent[2 * slot], e1 = ent[2 * slot + 1];  // (speculative: garbage beyond cnt, never used)
+  const MapState st = *m.st;
+  const float prev_auto = det_prev->auto_threshold;
+  const int n = st.n;
+  const float thr = auto_threshold_from(st, prev_auto);
+  if (tile == 0 && tid == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
+  const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
+  const int x1 = min(x0 + T, p.cols), y1 = min(y0 + T, p.rows);
+  if (cnt > kDfTileCap) {
+    df_rowrange_body(p, m, thr, n, T, T, x0, x1, y0, y1, df_smem, &l_n RH_DFS_STAMP_FWD);
+    return;
+  }
+  // cell pitch T + 1: a group's lanes step along the segment, for a vertical one down a column - with a pitch of T words
+  // (32 or 64) those 16 cells would share two LDS banks
+  constexpr int TP = T + 1;
+  unsigned* cell = df_smem;                                                        // [T][TP]
+  float4* l_ent = reinterpret_cast<float4*>(df_smem + ((T * TP + 3) & ~3));        // [kDfTileCap][2]
+  for (int i = tid; i < T * TP; i += kDfsThreads) cell[i] = kDfEmpty;
+  static_assert(kDfTileCap <= kDfsThreads, "one entry per thread");
+  if (tid < cnt) {
+    const bool skip = thr > 0.0f && e1.z < thr;  // threshold on the gradient norm (core.hpp:47)
+    l_ent[2 * tid] = e0;
+    l_ent[2 * tid + 1] = make_float4(e1.x, skip ? __int_as_float((256 << 16) | 255) : e1.y, e1.z, 0.f);  // skip: empty r-range
+  }
+  __syncthreads();
+  RH_DFS_STAMP(1);
+  const int nr = p.df_nr, half = nr >> 1;
+  const int l16 = tid & (kDfsSub - 1);
+  const unsigned tw = (unsigned)(x1 - x0), th = (unsigned)(y1 - y0);
+  for (int k = tid / kDfsSub; k < cnt; k += kDfsThreads / kDfsSub) {
+    const float4 q = l_ent[2 * k], a = l_ent[2 * k + 1];
+    const int rr = __float_as_int(a.y);
+    const int r_hi = (rr & 0xFFFF) - 256;
+    const unsigned kbase = kDfSeqMask - (unsigned)(__float_as_int(a.x) * nr + half);  // key = |r| << 23 | (kbase - r)
+    for (int r = (rr >> 16) - 256 + l16; r <= r_hi; r += kDfsSub) {
+      const float fr = q.w * float(r) + q.y;
+      const float fc = q.z * float(r) + q.x;
+      // (the positions are finite and far inside the int range: a plain conversion equals cvtt_f32 here)
+      const unsigned ty = (unsigned)((int)roundf(fr) - y0), tx = (unsigned)((int)roundf(fc) - x0);
+      if (ty >= th || tx >= tw) continue;
+      atomicMin(&cell[ty * TP + tx], ((unsigned)abs(r) << kDfSeqBits) | (kbase - (unsigned)r));
+    }
+  }
+  __syncthreads();
+  RH_DFS_STAMP(2);
+  for (int i = tid; i < (int)(th * T); i += kDfsThreads) {  // a row of the tile = consecutive lanes = one 128/256-byte segment
+    const int ty = i / T, tx = i - ty * T;
+    if (tx < (int)tw) m.df[(size_t)(y0 + ty) * p.cols + x0 + tx] = cell[ty * TP + tx];
+  }
+  RH_DFS_STAMP(3);
+}
+
 __global__ __launch_bounds__(256) void k_df_decode(KParams p, MapDev m, int* __restrict__ id_out, int* __restrict__ dist_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.rows * p.cols) return;
@@ -960,18 +1242,55 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
                      const DetState* det_in, DetState* det_out, const MapState* prev_st) {
   const dim3 gt(div_up(p.cols, 64), div_up(p.rows, 4));
+  const DfGrid dg = df_grid(p.rows, p.cols);
   RH_LAUNCH(k_keyline_flag, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in,
                      db.stash, db.bits, db.rowcount);
   RH_LAUNCH(k_keyline_emit, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash,
-                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st, df_scatter_mode() ? 1 : 0);
-  RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m);
+                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st, df_scatter_mode() ? 1 : 0, dg.ntx * dg.nty);
+  RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, m, dg.T, dg.ntx, dg.nty);
 }
 
 void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, bool mask_is_current) {
   const long long threads = (long long)p.kmax * p.df_nr;
   // measured (MI355X, 640x480 pipeline): 16 workgroups -> 316 us/frame (the field itself becomes the bottleneck), 32 -> 172, 64..128 -> 132, 512 -> 156, 2048 -> 162: the kernel is bound by
   // the memory-side atomic rate and a larger grid only takes CUs and memory queues from the latency-critical streams
-  if (mask_is_current && !df_scatter_mode()) {  // default: LDS tiles driven by the dense keyline mask, no global atomics
+  if (mask_is_current && !df_scatter_mode() && !df_tiles_mode()) {
+    // default: one workgroup per tile of df_grid, fed by the per-tile keyline lists k_join_edges left with the map.
+    // REBVIO_HIP_DF_STRIP="S,XB" (A/B): strips of S rows x cols/XB columns fed by the raster-ordered row range instead.
+    static int envS = 0, envXB = 0;
+    static const bool parsed = [] {
+      if (const char* e = std::getenv("REBVIO_HIP_DF_STRIP")) std::sscanf(e, "%d,%d", &envS, &envXB);
+      return true;
+    }();
+    (void)parsed;
+    const DfGrid dg = df_grid(p.rows, p.cols);
+    const size_t list_bytes = (size_t)kDfsList * (sizeof(float4) + 2 * sizeof(int));  // (>= kDfTileCap entries of 32 bytes)
+    static size_t attr_shm[3] = {0, 0, 0};
+    auto want = [](const void* f, size_t shm, size_t* have) {  // (the kernels also have static LDS: ask for what is needed)
+      if (shm > *have) {
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) (void)hipGetLastError();
+        *have = shm;
+      }
+    };
+    if (envS <= 0) {
+      const size_t shm = (((size_t)dg.T * (dg.T + 1) + 3) & ~(size_t)3) * sizeof(unsigned) + list_bytes;
+      if (dg.T == 32) {
+        want(reinterpret_cast<const void*>(&k_df_lists<32>), shm, &attr_shm[0]);
+        RH_LAUNCH(k_df_lists<32>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
+      } else {  // (cols <= 4096 and rows <= 2548 keep 64-pixel tiles below kDfMaxTiles)
+        want(reinterpret_cast<const void*>(&k_df_lists<64>), shm, &attr_shm[1]);
+        RH_LAUNCH(k_df_lists<64>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
+      }
+      return;
+    }
+    int W = ((div_up(p.cols, envXB > 0 ? envXB : 1) + 3) / 4) * 4, S = envS;
+    while (S > 1 && (size_t)S * W * sizeof(unsigned) > 32 * 1024) S >>= 1;
+    const size_t shm = (size_t)S * W * sizeof(unsigned) + list_bytes;
+    want(reinterpret_cast<const void*>(&k_df_strips), shm, &attr_shm[2]);
+    RH_LAUNCH(k_df_strips, dim3(div_up(p.cols, W), div_up(p.rows, S)), dim3(kDfsThreads), shm, s, p, m, det_prev, S, W RH_DFS_STAMP_PASS);
+    return;
+  }
+  if (mask_is_current && !df_scatter_mode()) {  // REBVIO_HIP_DF=tiles: LDS tiles driven by the dense keyline mask
     static const int kTile = (std::getenv("REBVIO_HIP_DF_TILE") && std::atoi(std::getenv("REBVIO_HIP_DF_TILE")) == 64) ? 64 : 32;
     if (kTile == 64)
       RH_LAUNCH(k_df_tiles<64>, dim3(div_up(p.cols, 64), div_up(p.rows, 64)), dim3(kDfThreads), 0, s, p, m, det_prev);
