@@ -737,7 +737,9 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   // needed one frame later: lowest
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  const int prio_mid = (prio_least + prio_greatest) / 2;
+  int prio_mid = (prio_least + prio_greatest) / 2;
+  if (const char* e = std::getenv("REBVIO_HIP_PRIO"))  // "flat": every stream at the default priority (diagnostic, several contexts per GPU)
+    if (std::strcmp(e, "flat") == 0) prio_least = prio_greatest = prio_mid = 0;
   HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
   // one stream per priority class: the runtime pools hardware queues per class (GPU_MAX_HW_QUEUES each) and lets streams of
   // a class share a queue once the pool is full, so two of our streams in one class can end up serialised behind each
