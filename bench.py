@@ -157,12 +157,26 @@ def main():
     ap.add_argument("--base-frames", type=int, default=24, help="distinct rendered frames (ping-pong replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--lanes", default="4,8",
+                    help="extra runs (N=1 only, never the headline): this many camera streams per GPU advanced in lock-step by "
+                         "batched launches (rebvio_hip_batch_*); '' or 0 skips them")
+    ap.add_argument("--batched-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--child-keylines", type=int, default=15000, help=argparse.SUPPRESS)
     ap.add_argument("--control-plane-only", action="store_true",
                     help="rehearsal without a GPU: rank launch, rendezvous, barrier and max-over-ranks only (value = null)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.batched_child:
+        import torch  # noqa: F401  (same load order as the parent)
+        from rebvio_amd import synth
+        cfg = CONFIGS[args.config]
+        frames, cam = synth.render_stream(cfg["width"], cfg["height"], args.base_frames, density=cfg.get("density", 1.0))
+        kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=cfg["keylines_ref"], keylines_max=cfg["keylines_max"])
+        res = batched_run(args.batched_child, frames, cam, cfg, kw, args.base_frames, cfg["width"] * cfg["height"], args.child_keylines)
+        print(json.dumps(res), flush=True)
+        return
 
     # The contract is ONE JSON line on stdout. Native libraries write there too (gloo reports its mesh connections on
     # stdout, "[Gloo] Rank 0 is connected to ..."): everything this process prints before the result goes to stderr.
@@ -336,6 +350,24 @@ def main():
                          "frame_achieved_GBs": (112 * npx + 1740 * n_keylines) * (fps / world) / 1e9},
             "kernel_us_per_frame": {kname: round(v, 3) for kname, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
         }
+        if world == 1 and args.lanes not in ("", "0"):
+            # Each batched run gets a process of its own: the HIP runtime maps streams onto a pool of hardware queues that
+            # outlives the streams, and the batch's three streams must not end up sharing queues with this process's earlier
+            # ones (measured: the same batch ran at half its rate after the single-stream context had lived here).
+            ctx.close()
+            torch.cuda.synchronize()
+            import subprocess
+            runs = []
+            for b in [int(x) for x in args.lanes.split(",") if int(x) > 0]:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batched-child", str(b), "--config", args.config,
+                                    "--base-frames", str(args.base_frames), "--child-keylines", str(n_keylines)],
+                                   capture_output=True, text=True)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode == 0 and line:
+                    runs.append(json.loads(line[-1]))
+                else:
+                    print(f"batched run with {b} lanes failed: {r.stderr[-800:]}", file=sys.stderr)
+            result["streams_per_gpu"] = runs
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(frames, cam, cfg, args.base_frames, args.cpu_seconds)
         sys.stdout.flush()
@@ -344,6 +376,50 @@ def main():
         os.dup2(2, 1)  # process-group teardown may log again
     if world > 1:
         dist.destroy_process_group()
+
+
+def batched_run(lanes, frames0, cam, cfg, kw, base_frames, npx, n_keylines, steps=1200, warmup=800):
+    """`lanes` independent camera streams on ONE GPU advanced in lock-step (rebvio_hip_batch_*: every kernel of the frame path
+    launched once per step for all lanes). An EXTRA figure next to the single-stream headline: one 640x480 stream keeps under
+    a tenth of the chip busy (its kernels are latency chains), batching is how the rest of it is used."""
+    import torch
+    from rebvio_amd import backend as B
+    from rebvio_amd import synth
+    kwb = {k: v for k, v in kw.items() if k != "map_pool"}
+    bat = B.Batch(B.default_params(cam.height, cam.width, **kwb), lanes)
+    devs = []
+    for lane in range(lanes):  # lane l sees camera stream l (its own scene)
+        fr = frames0 if lane == 0 else synth.render_stream(cam.width, cam.height, base_frames, stream_id=lane, density=cfg.get("density", 1.0))[0]
+        devs.append(bat.lanes[lane].upload_frames(fr))
+    order = synth.pingpong_indices(base_frames, warmup + steps + 64)
+    k = 0
+    for _ in range(warmup):
+        bat.push_u8_device([d + int(order[k]) * npx for d in devs], k * 50000)
+        k += 1
+    torch.cuda.synchronize()
+    c0 = bat.lanes[0]
+    c0.profile_reset()
+    c0.profile(True, only="k_lm_chain_b<512>", stride=8)
+    bad = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        outs, _n = bat.push_u8_device([d + int(order[k]) * npx for d in devs], k * 50000)
+        bad += sum(1 for lane in range(lanes) if outs[lane].status not in (0, -1))
+        k += 1
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dom = c0.profile_read().get("k_lm_chain_b<512>", (0.0, 0))
+    c0.profile(False)
+    bat.flush()
+    bat.close()
+    ab = lanes * algorithmic_bytes("k_lm_chain", npx, n_keylines)
+    ach = ab / (dom[0] * 1e-6) / 1e9 if dom[0] > 0 else 0.0
+    fps = lanes * steps / (t1 - t0)
+    return {"lanes": lanes, "value": fps, "unit": "frames/s (all lanes)", "us_per_step": (t1 - t0) / steps * 1e6, "steps": steps,
+            "non_zero_statuses": bad,
+            "roofline": {"bound": "hbm", "kernel": "k_lm_chain_b<512>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "avg_launch_us": dom[0], "launches": dom[1], "algorithmic_bytes_per_launch": ab},
+            "frame_achieved_GBs": (112 * npx + 1740 * n_keylines) * fps / 1e9}
 
 
 def cpu_baseline(frames, cam, cfg, base_frames, seconds):

@@ -236,6 +236,25 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_de
                                     rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_flush(rebvio_hip_ctx* ctx);
 
+/* Several camera streams on ONE GPU, advanced in lock-step ("lanes" of a batch). The reference runs one rebvio::Rebvio per
+ * camera stream, each with its own detector, tracker and queues (rebvio.hpp:91-112); a batch is `lanes` such pipelines whose
+ * per-frame kernels are launched once per step for all lanes (lane = blockIdx.z). One 640x480 stream keeps well under a tenth
+ * of an MI355X busy - its kernels are short latency chains - so a batched step costs about what a single stream's step costs
+ * and the frame rate scales with the lane count until the chip fills. Every lane is a full context (own maps, servo, gyro-bias
+ * state) sharing the batch's three streams; its records are bit-identical to those of a stand-alone context fed the same
+ * frames. lanes in 1..8, keylines_max <= 32768, no lens model (the device front end is not part of the batched path).
+ * push: frames_dev[l] = this step's u8 frame of lane l in device memory (all lanes share ts_us); out[l] / keylines[l] receive
+ * lane l's most recent COMPLETE pair like rebvio_hip_push_frame_u8_device (status -1 while the pipeline fills). */
+typedef struct rebvio_hip_batch rebvio_hip_batch;
+int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_batch** out);
+void rebvio_hip_batch_destroy(rebvio_hip_batch* b);
+int rebvio_hip_batch_lanes(rebvio_hip_batch* b);
+/* The context of one lane (device_alloc / device_upload for its frames, detector_state, get/set_gyro_state, ...). Owned by the batch. */
+rebvio_hip_ctx* rebvio_hip_batch_lane(rebvio_hip_batch* b, int lane);
+int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* frames_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
+                                    int* keylines);
+int rebvio_hip_batch_flush(rebvio_hip_batch* b);
+
 /* Per-kernel device timing of the last N launches of each kernel, measured with HIP events on the
  * stream the kernel runs on. names: '\n'-separated. Used by bench.py's roofline leg. */
 int rebvio_hip_profile_enable(rebvio_hip_ctx* ctx, int on); /* 0 off, 1 every launch, N>1 every N-th launch */

@@ -98,6 +98,12 @@ SIGNATURES = {
     "rebvio_hip_track_pair_finish": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _fp, _ip, _ip, _ip, _ip]),
     "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_flush": (C.c_int, [_vp]),
+    "rebvio_hip_batch_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(_vp)]),
+    "rebvio_hip_batch_destroy": (None, [_vp]),
+    "rebvio_hip_batch_lanes": (C.c_int, [_vp]),
+    "rebvio_hip_batch_lane": (_vp, [_vp, C.c_int]),
+    "rebvio_hip_batch_push_u8_device": (C.c_int, [_vp, C.POINTER(_vp), C.c_uint64, C.POINTER(PairOut), _ip]),
+    "rebvio_hip_batch_flush": (C.c_int, [_vp]),
     "rebvio_hip_profile_enable": (C.c_int, [_vp, C.c_int]),
     "rebvio_hip_profile_select": (C.c_int, [_vp, C.c_char_p]),
     "rebvio_hip_profile_reset": (C.c_int, [_vp]),
@@ -223,11 +229,15 @@ class Map:
 
 
 class Context:
-    def __init__(self, params: Params):
+    def __init__(self, params: Params, _handle=None):
         self.p = params
         self.rows, self.cols = params.rows, params.cols
-        h = _vp()
-        _chk(lib().rebvio_hip_create(C.byref(params), C.byref(h)))
+        self._owned = _handle is None
+        if _handle is None:
+            h = _vp()
+            _chk(lib().rebvio_hip_create(C.byref(params), C.byref(h)))
+        else:
+            h = _vp(_handle)
         self.h = h
         self._dev_bufs = []
 
@@ -236,7 +246,8 @@ class Context:
             for b in self._dev_bufs:
                 lib().rebvio_hip_device_free(self.h, b)
             self._dev_bufs = []
-            lib().rebvio_hip_destroy(self.h)
+            if self._owned:
+                lib().rebvio_hip_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -410,3 +421,39 @@ class Context:
         k = lib().rebvio_hip_profile_read(self.h, names, 8192, avg, calls, cap)
         ns = names.value.decode().split("\n")
         return {ns[i]: (avg[i], calls[i]) for i in range(k)}
+
+
+class Batch:
+    """`lanes` camera streams of one GPU advanced in lock-step (rebvio_hip_batch_*)."""
+
+    def __init__(self, params: Params, lanes: int):
+        self.p, self.B = params, lanes
+        h = _vp()
+        _chk(lib().rebvio_hip_batch_create(C.byref(params), lanes, C.byref(h)))
+        self.h = h
+        self.lanes = [Context(params, _handle=lib().rebvio_hip_batch_lane(h, l)) for l in range(lanes)]
+        self._frames = (_vp * lanes)()
+        self._out = (PairOut * lanes)()
+        self._n = (C.c_int * lanes)()
+
+    def push_u8_device(self, dev_addrs, ts_us: int):
+        for l, a in enumerate(dev_addrs):
+            self._frames[l] = int(a)
+        _chk(lib().rebvio_hip_batch_push_u8_device(self.h, self._frames, ts_us, self._out, self._n))
+        return self._out, self._n
+
+    def flush(self):
+        _chk(lib().rebvio_hip_batch_flush(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.lanes:
+                c.close()  # frees the frames staged through the lane; the lane itself belongs to the batch
+            lib().rebvio_hip_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

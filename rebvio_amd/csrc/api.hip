@@ -23,6 +23,11 @@ using namespace rh;
 
 namespace {
 thread_local std::string g_err;
+// streams a context under construction adopts instead of creating its own (lanes of a batch share one set)
+struct SharedStreams {
+  hipStream_t s_det, s_key, s_trk;
+};
+thread_local const SharedStreams* t_adopt_streams = nullptr;
 
 int fail(const char* what, hipError_t e) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -156,6 +161,8 @@ struct rebvio_hip_map {
   int n_host = -1;
   float thr_host = -1.0f;
   bool trk_waited = false;  // the track stream already holds a wait on `ready` (a second one is another barrier packet)
+  int tab_idx = -1;         // entry of this map in its lane's device map table (batch driver)
+  MapDev canon{};           // ... as uploaded there (the live `d` differs from it by the ping-pong swaps only)
 };
 
 struct rebvio_hip_ctx {
@@ -270,6 +277,7 @@ struct rebvio_hip_ctx {
   double t_detect_enq = 0, t_wait = 0, t_glue = 0, t_b_enq = 0, t_a_enq = 0, t_queued = 0;
   bool dbg = false;
   uint64_t t_frames = 0;
+  bool owns_streams = true;  // false for the lanes of a batch (rebvio_hip_batch_*)
 };
 
 namespace {
@@ -740,20 +748,28 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   int prio_mid = (prio_least + prio_greatest) / 2;
   if (const char* e = std::getenv("REBVIO_HIP_PRIO"))  // "flat": every stream at the default priority (diagnostic, several contexts per GPU)
     if (std::strcmp(e, "flat") == 0) prio_least = prio_greatest = prio_mid = 0;
-  HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
-  // one stream per priority class: the runtime pools hardware queues per class (GPU_MAX_HW_QUEUES each) and lets streams of
-  // a class share a queue once the pool is full, so two of our streams in one class can end up serialised behind each
-  // other depending on what else the process created (measured with extra torch streams: 9.3k -> 7.0k frames/s)
-  HIPCHK(hipStreamCreateWithPriority(&c->s_key, hipStreamNonBlocking, prio_least));
-  HIPCHK(hipStreamCreateWithPriority(&c->s_trk, hipStreamNonBlocking, prio_greatest));
-  // Three streams per context (scans | keylines + distance field | tracking), deliberately not more: on this runtime every
-  // additional stream of the process slowed the whole pipeline (measured, same code: 3 streams 9.3k frames/s, 4 streams
-  // 9.2k, 5 streams 9.1k; creating a sixth, even unused, 2.6k). REBVIO_HIP_DF_STREAM=own restores a separate
-  // low-priority distance-field stream; the copy stream of the synchronous API is the distance-field stream.
-  if (std::getenv("REBVIO_HIP_DF_STREAM") && std::strcmp(std::getenv("REBVIO_HIP_DF_STREAM"), "own") == 0)
-    HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, prio_least));
-  else
+  if (t_adopt_streams) {
+    c->s_det = t_adopt_streams->s_det;
+    c->s_key = t_adopt_streams->s_key;
+    c->s_trk = t_adopt_streams->s_trk;
     c->s_df = c->s_key;
+    c->owns_streams = false;
+  } else {
+    HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
+    // one stream per priority class: the runtime pools hardware queues per class (GPU_MAX_HW_QUEUES each) and lets streams of
+    // a class share a queue once the pool is full, so two of our streams in one class can end up serialised behind each
+    // other depending on what else the process created (measured with extra torch streams: 9.3k -> 7.0k frames/s)
+    HIPCHK(hipStreamCreateWithPriority(&c->s_key, hipStreamNonBlocking, prio_least));
+    HIPCHK(hipStreamCreateWithPriority(&c->s_trk, hipStreamNonBlocking, prio_greatest));
+    // Three streams per context (scans | keylines + distance field | tracking), deliberately not more: on this runtime every
+    // additional stream of the process slowed the whole pipeline (measured, same code: 3 streams 9.3k frames/s, 4 streams
+    // 9.2k, 5 streams 9.1k; creating a sixth, even unused, 2.6k). REBVIO_HIP_DF_STREAM=own restores a separate
+    // low-priority distance-field stream; the copy stream of the synchronous API is the distance-field stream.
+    if (std::getenv("REBVIO_HIP_DF_STREAM") && std::strcmp(std::getenv("REBVIO_HIP_DF_STREAM"), "own") == 0)
+      HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, prio_least));
+    else
+      c->s_df = c->s_key;
+  }
   c->s_cpy = c->s_df;
   const size_t Pn = (size_t)p->rows * p->cols;
   // the integral-image buffers have a row pitch of cols rounded up to 4 floats (the scans move 16-byte vectors); every
@@ -927,10 +943,12 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   void* hptr[] = {c->h_lm, c->h_part, c->h_xrv, c->h_st, c->h_f};
   for (void* p : hptr)
     if (p) (void)hipHostFree(p);
-  if (c->s_det) (void)hipStreamDestroy(c->s_det);
-  if (c->s_trk) (void)hipStreamDestroy(c->s_trk);
-  if (c->s_df && c->s_df != c->s_key) (void)hipStreamDestroy(c->s_df);
-  if (c->s_key) (void)hipStreamDestroy(c->s_key);
+  if (c->owns_streams) {
+    if (c->s_det) (void)hipStreamDestroy(c->s_det);
+    if (c->s_trk) (void)hipStreamDestroy(c->s_trk);
+    if (c->s_df && c->s_df != c->s_key) (void)hipStreamDestroy(c->s_df);
+    if (c->s_key) (void)hipStreamDestroy(c->s_key);
+  }
   for (int i = 0; i < 2; ++i) {
     if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
     if (c->ev_flag[i]) (void)hipEventDestroy(c->ev_flag[i]);
@@ -1927,6 +1945,474 @@ int rebvio_hip_device_free(rebvio_hip_ctx* c, void* p) {
 int rebvio_hip_device_upload(rebvio_hip_ctx* c, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- batch of camera streams on one GPU (rebvio_hip_batch_*) ----------------------------------------------------------------------------------
+// B independent rebvio pipelines (B instances of rebvio::Rebvio, each with its own detector, tracker and maps: rebvio.hpp:91-112)
+// advanced in LOCK-STEP by batched launches: every kernel of the per-frame path runs once per step with lane = blockIdx.z.
+// Why not B contexts side by side: measured on MI355X (tools/multi_ctx.py), several contexts per process do not overlap -
+// with stream priorities two pipelines starve each other's low-priority stages (2 x 3.0k frames/s against 11.8k for one),
+// without them they merely share the single-stream rate, and with more hardware queues every pipeline gets slower - while a
+// single 640x480 stream keeps under a tenth of the chip busy because each of its kernels is a short latency chain. A batched
+// launch costs about the same latency as a single one, so B lanes raise the frame rate almost B-fold until the chip fills.
+// Each lane is a full rebvio_hip_ctx (its buffers, maps, glue state) that adopts the batch's three streams; per lane results
+// are bit-identical to a stand-alone context fed the same frames (same kernel bodies, same per-lane reduction order).
+struct rebvio_hip_batch {
+  int B = 0;
+  int device = 0;
+  rebvio_hip_params P{};
+  KParams K{};
+  SharedStreams st{};
+  std::vector<rebvio_hip_ctx*> lane;
+  LaneStatic* ls_dev = nullptr;
+  MapDev* maptab_dev = nullptr;
+  hipEvent_t ev_scan[2]{}, ev_flag[2]{};
+  bool ev_flag_used[2] = {false, false};
+  static constexpr int kReadyRing = 16;
+  hipEvent_t ev_ready[kReadyRing]{};  // keylines + distance fields of a step finished (keyline stream)
+  hipEvent_t slot_ev[rebvio_hip_ctx::kSlots]{};
+  uint64_t step = 0;
+  struct Frame {
+    std::vector<rebvio_hip_map*> m;  // one detected map per lane
+    uint64_t step;
+  };
+  std::deque<Frame> frames;
+  struct Pair {
+    Frame of, nf;
+    int slot = -1;
+    std::vector<hm::M3> R;
+    float frame_dt = 0.f;
+    std::vector<rebvio_hip_pair_out> out;
+  };
+  Pair cur, prev;
+  bool has_cur = false, has_prev = false;
+  uint64_t pair_seq = 0;
+  int lead = 4;
+  // detect-enqueue worker: launches the detect stage of a step while the caller thread runs the glue and launches the
+  // track stage (the reference's data-acquisition thread, rebvio.cpp:28; same split as the single-stream driver)
+  struct DetStep {
+    LaneDynB dyn;
+    int par;
+    uint64_t step;
+    hipEvent_t reuse_done;  // last consumer of the maps this step reuses (null: fresh maps)
+    std::vector<rebvio_hip_map*> maps;
+  };
+  std::thread det_thread;
+  std::mutex det_mu;
+  std::condition_variable det_cv;
+  std::deque<DetStep> det_jobs;
+  std::atomic<uint64_t> det_done_steps{0};  // steps whose detect stage has been enqueued (their events are recorded)
+  bool det_stop = false;
+  std::string det_error;
+};
+
+namespace {
+int batch_upload_map_entry(rebvio_hip_batch* b, int lane, rebvio_hip_map* m) {
+  rebvio_hip_ctx* c = b->lane[lane];
+  int idx = -1;
+  for (size_t i = 0; i < c->pool.size(); ++i)
+    if (c->pool[i] == m) idx = (int)i;
+  if (idx < 0 || idx >= kLaneMaps) return fail_msg("batch: edge-map pool of a lane outgrew the lane's map table (release maps)", -2);
+  m->tab_idx = idx;
+  m->canon = m->d;
+  HIPCHK(hipMemcpy(b->maptab_dev + (size_t)lane * kLaneMaps + idx, &m->canon, sizeof(MapDev), hipMemcpyHostToDevice));
+  return 0;
+}
+inline unsigned map_swap_bits(const rebvio_hip_map* m) { return (m->d.rs != m->canon.rs ? 1u : 0u) | (m->d.grad != m->canon.grad ? 2u : 0u); }
+
+void batch_release_map(rebvio_hip_map* m, bool record_done);
+
+// glue of the pair in flight for every lane, then its second half (batched), then the old maps go back to their pools
+int batch_finish_current(rebvio_hip_batch* b, rebvio_hip_pair_out* completed, int* completed_keylines, bool* have_completed) {
+  rebvio_hip_batch::Pair& cur = b->cur;
+  HIPCHK(hipEventSynchronize(b->slot_ev[cur.slot]));
+  LaneDynB dyn{};
+  bool any_b = false;
+  for (int l = 0; l < b->B; ++l) {
+    rebvio_hip_ctx* c = b->lane[l];
+    PairSlot* slot = c->slot[cur.slot];
+    if (*c->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
+    if (b->has_prev) {
+      rebvio_hip_pair_out& po = b->prev.out[l];
+      if (po.status != 1) {
+        po.klm_num = slot->old_st.dm_matches;
+        po.kf_matches = slot->old_st.dm_kf;
+        po.reg_num = slot->old_st.reg_count;
+        if ((unsigned)po.klm_num < c->P.global_min_matches_threshold) po.status = 2;
+      }
+      if (completed) completed[l] = po;
+      if (completed_keylines) completed_keylines[l] = slot->old_st.n;
+    }
+    rebvio_hip_map* om = cur.of.m[l];
+    rebvio_hip_map* nm = cur.nf.m[l];
+    nm->n_host = slot->new_st.n;
+    nm->thr_host = slot->new_st.threshold;
+    std::memset(&cur.out[l], 0, sizeof(cur.out[l]));
+    const GlueOut g = pair_glue(c, slot->lm, slot->xrv, nm->n_host, cur.frame_dt, cur.R[l], &cur.out[l]);
+    float RT_next[9];
+    hm::store3(hm::transpose(prior_rotation(c, nullptr)), RT_next);
+    GlueDev gl{};
+    rotate_inputs(c, g.V, g.P_V, g.Rgva, gl.vel_r, gl.Rvel_r);
+    std::memcpy(gl.Rgva, g.Rgva, sizeof(g.Rgva));
+    std::memcpy(gl.R0a, g.R0a, sizeof(g.R0a));
+    std::memcpy(gl.V, g.V, sizeof(g.V));
+    std::memcpy(gl.RT_next, RT_next, sizeof(RT_next));
+    gl.nan_v = g.nan_v ? 1 : 0;
+    gl.has_next = 1;
+    {  // plain word stores: the destination may be write-combined device memory behind the BAR (REBVIO_HIP_GLUE=vram)
+      volatile unsigned* dst = reinterpret_cast<volatile unsigned*>(c->glue_host[cur.slot]);
+      unsigned words[sizeof(GlueDev) / sizeof(unsigned)];
+      std::memcpy(words, &gl, sizeof(gl));
+      for (size_t i = 0; i < sizeof(GlueDev) / sizeof(unsigned); ++i) dst[i] = words[i];
+    }
+    if (g.nan_v) cur.out[l].status = 1;
+    any_b = true;
+    LaneDyn& d = dyn.v[l];
+    d.nm = (short)nm->tab_idx;
+    d.om = (short)om->tab_idx;
+    d.nm_swap = (unsigned char)map_swap_bits(nm);
+    d.om_swap = (unsigned char)map_swap_bits(om);
+    d.slot = (unsigned char)cur.slot;
+  }
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // the glue records are in memory before the launch that reads them is queued
+  if (b->has_prev && have_completed) *have_completed = true;
+  b->has_prev = false;
+  if (any_b) {
+    const int gate = (int)b->P.global_min_matches_threshold;
+    launch_b_chain_b(b->st.s_trk, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0);
+    HIPCHK(hipGetLastError());
+    for (int l = 0; l < b->B; ++l) {  // (a lane whose pair was skipped for a NaN velocity still had its next rotation applied)
+      rebvio_hip_map* nm = cur.nf.m[l];
+      std::swap(nm->d.rs, nm->d.rs_tmp);
+      std::swap(nm->d.grad, nm->d.grad_tmp);
+      nm->pre_rotated = true;
+      batch_release_map(cur.of.m[l], l == b->B - 1);  // stream-ordered: reusable once the second half has drained
+    }
+  }
+  b->prev = cur;
+  b->has_prev = true;
+  b->has_cur = false;
+  return 0;
+}
+
+int batch_detect_launch(rebvio_hip_batch* b, const rebvio_hip_batch::DetStep& j) {
+  const int B = b->B, par = j.par;
+  if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->st.s_det, b->ev_flag[par], 0));
+  launch_scale_space_b(b->st.s_det, b->K, B, b->ls_dev, j.dyn, b->lane[0]->widths);
+  HIPCHK(hipEventRecord(b->ev_scan[par], b->st.s_det));
+  HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan[par], 0));
+  if (j.reuse_done) HIPCHK(hipStreamWaitEvent(b->st.s_key, j.reuse_done, 0));
+  launch_keylines_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b->ev_flag[par], b->st.s_key));
+  b->ev_flag_used[par] = true;
+  launch_df_build_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b->ev_ready[j.step % rebvio_hip_batch::kReadyRing], b->st.s_key));
+  for (int l = 0; l < B; ++l) {  // the single-map entries (size, download, ...) wait on the map's own event
+    HIPCHK(hipEventRecord(j.maps[l]->ready, b->st.s_key));
+    j.maps[l]->enqueued.store(1, std::memory_order_release);
+  }
+  return 0;
+}
+
+void batch_det_worker(rebvio_hip_batch* b) {
+  (void)hipSetDevice(b->device);
+  for (;;) {
+    rebvio_hip_batch::DetStep j;
+    {
+      std::unique_lock<std::mutex> lk(b->det_mu);
+      b->det_cv.wait(lk, [&] { return b->det_stop || !b->det_jobs.empty(); });
+      if (b->det_jobs.empty()) return;
+      j = b->det_jobs.front();
+      b->det_jobs.pop_front();
+    }
+    if (batch_detect_launch(b, j) != 0) {
+      std::lock_guard<std::mutex> lk(b->det_mu);
+      b->det_error = g_err;
+      for (auto* m : j.maps) m->enqueued.store(1, std::memory_order_release);
+    }
+    b->det_done_steps.store(j.step + 1, std::memory_order_release);
+  }
+}
+
+// a map of a batch goes back to its lane's pool; only the last lane's release is marked in the stream (the releases of a
+// step sit at one point of the track stream, and the detect stage waits for that one event)
+void batch_release_map(rebvio_hip_map* m, bool record_done) {
+  if (!m || !m->in_use) return;
+  rebvio_hip_ctx* c = m->ctx;
+  wait_enqueued(m);
+  if (record_done) {
+    (void)hipEventRecord(m->done, c->s_trk);
+    m->has_done = true;
+  }
+  if (c->df_map == m) c->df_map = nullptr;
+  m->release_seq = ++c->release_counter;
+  m->in_use = false;
+}
+
+int batch_enqueue_a(rebvio_hip_batch* b, rebvio_hip_batch::Pair& pp) {
+  hipStream_t s = b->st.s_trk;
+  while (b->det_done_steps.load(std::memory_order_acquire) <= pp.nf.step) std::this_thread::yield();  // its event has been recorded
+  HIPCHK(hipStreamWaitEvent(s, b->ev_ready[pp.nf.step % rebvio_hip_batch::kReadyRing], 0));  // (the old frame's step is earlier: same stream order)
+  LaneDynB dyn{};
+  const int calls = (int)b->P.iterations + 1;
+  for (int l = 0; l < b->B; ++l) {
+    rebvio_hip_ctx* c = b->lane[l];
+    rebvio_hip_map *om = pp.of.m[l], *nm = pp.nf.m[l];
+    c->df_map = nm;
+    pp.R[l] = prior_rotation(c, nullptr);
+    if (!om->pre_rotated) {  // first pair of the lane: no second half has applied the prior rotation yet
+      float RT[9];
+      hm::store3(hm::transpose(pp.R[l]), RT);
+      launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+    }
+    LaneDyn& d = dyn.v[l];
+    d.nm = (short)nm->tab_idx;
+    d.om = (short)om->tab_idx;
+    d.nm_swap = (unsigned char)map_swap_bits(nm);
+    d.om_swap = (unsigned char)map_swap_bits(om);
+    d.slot = (unsigned char)pp.slot;
+    d.tag_base = c->lm_tag_base;
+    c->lm_tag_base += (unsigned)calls + 1u;
+    if (c->lm_tag_base > 0xFFFFFF00u) {
+      (void)hipMemsetAsync(c->lm_xch, 0, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long), s);
+      c->lm_tag_base = 0;
+    }
+  }
+  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b->slot_ev[pp.slot], s));
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->det_thread.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(b->det_mu);
+      b->det_stop = true;
+    }
+    b->det_cv.notify_all();
+    b->det_thread.join();
+  }
+  (void)hipDeviceSynchronize();
+  for (auto* c : b->lane) rebvio_hip_destroy(c);
+  if (b->ls_dev) (void)hipFree(b->ls_dev);
+  if (b->maptab_dev) (void)hipFree(b->maptab_dev);
+  for (int i = 0; i < 2; ++i) {
+    if (b->ev_scan[i]) (void)hipEventDestroy(b->ev_scan[i]);
+    if (b->ev_flag[i]) (void)hipEventDestroy(b->ev_flag[i]);
+  }
+  for (auto& e : b->ev_ready)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : b->slot_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (b->st.s_det) (void)hipStreamDestroy(b->st.s_det);
+  if (b->st.s_key) (void)hipStreamDestroy(b->st.s_key);
+  if (b->st.s_trk) (void)hipStreamDestroy(b->st.s_trk);
+  delete b;
+}
+
+int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_batch** out) {
+  *out = nullptr;
+  if (lanes < 1 || lanes > kMaxLanes) return fail_msg("batch: lanes must be in 1..8", -3);
+  if (p->keylines_max > 32768) return fail_msg("batch: keylines_max <= 32768 (the batched directedMatch head is the eight-lanes-per-keyline form)", -3);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail_msg("no HIP device present: the gfx950 backend has no CPU fallback", -4);
+  if (p->device_id < 0 || p->device_id >= ndev) return fail_msg("device_id out of range", -3);
+  HIPCHK(hipSetDevice(p->device_id));
+  rebvio_hip_batch* b = new rebvio_hip_batch;
+  struct Guard {
+    rebvio_hip_batch* b;
+    ~Guard() {
+      if (b) rebvio_hip_batch_destroy(b);
+    }
+  } guard{b};
+  b->B = lanes;
+  b->device = p->device_id;
+  b->P = *p;
+  // the three stages of a step overlap across steps like the stages of one stream do; one priority class for all
+  // (see the comment on rebvio_hip_batch: priorities are what made pipelines starve each other)
+  HIPCHK(hipStreamCreateWithFlags(&b->st.s_det, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&b->st.s_key, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&b->st.s_trk, hipStreamNonBlocking));
+  for (int l = 0; l < lanes; ++l) {
+    rebvio_hip_ctx* c = nullptr;
+    rebvio_hip_params pl = *p;
+    if (pl.map_pool <= 0) pl.map_pool = 8;
+    t_adopt_streams = &b->st;
+    const int rc = rebvio_hip_create(&pl, &c);
+    t_adopt_streams = nullptr;
+    if (rc) return rc;
+    b->lane.push_back(c);
+  }
+  b->K = b->lane[0]->K;
+  std::vector<LaneStatic> ls((size_t)lanes);
+  HIPCHK(hipMalloc(&b->maptab_dev, (size_t)lanes * kLaneMaps * sizeof(MapDev)));
+  HIPCHK(hipMemset(b->maptab_dev, 0, (size_t)lanes * kLaneMaps * sizeof(MapDev)));
+  for (int l = 0; l < lanes; ++l) {
+    rebvio_hip_ctx* c = b->lane[l];
+    LaneStatic& L = ls[l];
+    for (int f = 0; f < 2; ++f) {
+      L.sa[f] = c->sb.a[f];
+      L.sb[f] = c->sb.b[f];
+      L.dog2[f] = c->dog2[f];
+      L.mag2[f] = c->mag2[f];
+      L.rowcount2[f] = c->rowcount2[f];
+    }
+    L.stash = c->db.stash;
+    L.bits = c->db.bits;
+    L.det = c->det;
+    L.lm = c->lm;
+    L.lm_zero = c->lm_zero;
+    L.lm_xch = c->lm_xch;
+    L.lm_bar_err = c->lm_bar_err;
+    L.hist = c->hist;
+    L.dm_work = c->dm_work;
+    L.dm_work_n = c->dm_work_n;
+    for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
+      L.slot[i] = c->slot[i];
+      L.glue_host[i] = c->glue_host[i];
+    }
+    L.glue_dev = c->glue_dev;
+    for (auto* m : c->pool) {
+      const int rc = batch_upload_map_entry(b, l, m);
+      if (rc) return rc;
+    }
+  }
+  HIPCHK(hipMalloc(&b->ls_dev, ls.size() * sizeof(LaneStatic)));
+  HIPCHK(hipMemcpy(b->ls_dev, ls.data(), ls.size() * sizeof(LaneStatic), hipMemcpyHostToDevice));
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(hipEventCreateWithFlags(&b->ev_scan[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b->ev_flag[i], hipEventDisableTiming));
+  }
+  for (auto& e : b->ev_ready) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : b->slot_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (const char* e = std::getenv("REBVIO_HIP_BATCH_LEAD")) b->lead = std::min(8, std::max(3, std::atoi(e)));
+  HIPCHK(hipDeviceSynchronize());
+  guard.b = nullptr;
+  *out = b;
+  return 0;
+}
+
+int rebvio_hip_batch_lanes(rebvio_hip_batch* b) { return b->B; }
+rebvio_hip_ctx* rebvio_hip_batch_lane(rebvio_hip_batch* b, int lane) { return (lane >= 0 && lane < b->B) ? b->lane[lane] : nullptr; }
+
+int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* frames_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
+                                    int* keylines) {
+  HIPCHK(hipSetDevice(b->device));
+  const int B = b->B;
+  for (int l = 0; l < B; ++l) {
+    if (out) {
+      std::memset(&out[l], 0, sizeof(out[l]));
+      out[l].status = -1;
+    }
+    if (keylines) keylines[l] = -1;
+  }
+  // ---- detect stage of this step (detect_launch for every lane at once) ----
+  rebvio_hip_batch::Frame fr;
+  fr.step = b->step;
+  fr.m.resize((size_t)B);
+  LaneDynB dyn{};
+  const int par = (int)(b->step & 1);
+  rebvio_hip_map* last_reused = nullptr;
+  for (int l = 0; l < B; ++l) {
+    rebvio_hip_ctx* c = b->lane[l];
+    if (c->undist_map) return fail_msg("batch: the device front end (lens model) is not part of the batched path", -3);
+    rebvio_hip_ctx::DetJob job;
+    int rc = detect_prepare(c, frames_dev[l], 1, ts_us, &job);
+    if (rc) return rc;
+    rebvio_hip_map* m = job.m;
+    if (m->tab_idx < 0 || std::memcmp(&m->canon.pos, &m->d.pos, sizeof(void*)) != 0) {  // a map the pool has just grown by
+      rc = batch_upload_map_entry(b, l, m);
+      if (rc) return rc;
+    }
+    // a pooled map comes back with whatever ping-pong state its last pair left: the detector writes the canonical arrays
+    m->d = m->canon;
+    fr.m[l] = m;
+    if (l == B - 1) last_reused = m;
+    LaneDyn& d = dyn.v[l];
+    d.img = frames_dev[l];
+    d.nm = (short)m->tab_idx;
+    d.om = -1;
+    d.prev = -1;
+    if (job.prev_st)
+      for (auto* pm : c->pool)
+        if (pm->d.st == job.prev_st) d.prev = (short)pm->tab_idx;
+    d.parity = (unsigned char)par;
+    d.det_in = (unsigned char)(job.det_in - c->det);
+    d.det_out = (unsigned char)(job.det_out - c->det);
+  }
+  {
+    std::lock_guard<std::mutex> lk(b->det_mu);
+    if (!b->det_error.empty()) return fail_msg(b->det_error.c_str(), -8);
+  }
+  rebvio_hip_batch::DetStep job;
+  job.dyn = dyn;
+  job.par = par;
+  job.step = b->step;
+  // maps are released in lane order at one point of the track stream: the last lane's event covers all of them
+  job.reuse_done = (last_reused && last_reused->has_done) ? last_reused->done : nullptr;
+  job.maps = fr.m;
+  for (auto* m : fr.m) m->enqueued.store(0, std::memory_order_relaxed);
+  if (!b->det_thread.joinable()) b->det_thread = std::thread(batch_det_worker, b);
+  {
+    std::lock_guard<std::mutex> lk(b->det_mu);
+    b->det_jobs.push_back(job);
+  }
+  b->det_cv.notify_one();
+  b->frames.push_back(fr);
+  b->step++;
+
+  // ---- finish the pair in flight (glue, second half), then start the next one behind it ----
+  if (b->has_cur) {
+    bool have = false;
+    int rc = batch_finish_current(b, out, keylines, &have);
+    if (rc) return rc;
+  }
+  if ((int)b->frames.size() >= b->lead) {
+    rebvio_hip_batch::Pair pp;
+    pp.of = b->frames[0];
+    pp.nf = b->frames[1];
+    pp.slot = (int)(b->pair_seq++ % rebvio_hip_ctx::kSlots);
+    pp.R.resize((size_t)B);
+    pp.out.resize((size_t)B);
+    pp.frame_dt = (float)((double)(float)(pp.nf.m[0]->ts - pp.of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
+    int rc = batch_enqueue_a(b, pp);
+    if (rc) return rc;
+    b->frames.pop_front();
+    b->cur = pp;
+    b->has_cur = true;
+  }
+  return 0;
+}
+
+int rebvio_hip_batch_flush(rebvio_hip_batch* b) {
+  HIPCHK(hipSetDevice(b->device));
+  while (b->det_done_steps.load(std::memory_order_acquire) < b->step) std::this_thread::yield();
+  if (b->has_cur) {
+    int rc = batch_finish_current(b, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  if (b->has_prev) {
+    for (size_t l = 0; l < b->prev.nf.m.size(); ++l) batch_release_map(b->prev.nf.m[l], l + 1 == b->prev.nf.m.size());
+    b->has_prev = false;
+  }
+  for (auto& f : b->frames)
+    for (size_t l = 0; l < f.m.size(); ++l) batch_release_map(f.m[l], l + 1 == f.m.size());
+  b->frames.clear();
+  HIPCHK(hipStreamSynchronize(b->st.s_det));
+  HIPCHK(hipStreamSynchronize(b->st.s_key));
+  HIPCHK(hipStreamSynchronize(b->st.s_trk));
   return 0;
 }
 

@@ -242,6 +242,63 @@ void launch_map_unpack(hipStream_t s, const KParams& p, const MapDev& m, const r
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// ---- several camera streams ("lanes") of one GPU advanced in lock-step by batched launches (rebvio_hip_batch_*) --------
+// A batched kernel is the single-stream kernel body run for lane = blockIdx.z; what differs between lanes comes from two
+// tables: LaneStatic (device memory, fixed for the life of the lane: its scratch buffers) and the lane's map table
+// (device memory, one MapDev per pooled edge map), plus a small by-value LaneDyn per launch (which maps, which ring slots).
+constexpr int kMaxLanes = 8;
+constexpr int kLaneMaps = 24;  // map-table entries per lane (the batch driver bounds its pool by this)
+struct LaneStatic {
+  float* sa[2];   // scan buffer A per filter
+  float* sb[2];   // scan buffer B per filter
+  float* dog2[2];
+  float* mag2[2];
+  int* rowcount2[2];
+  float4* stash;
+  unsigned long long* bits;
+  DetState* det;  // ring [kDetRing + 1]
+  LmState* lm;
+  LmState* lm_zero;
+  unsigned long long* lm_xch;
+  int* lm_bar_err;
+  int* hist;
+  int* dm_work;
+  int* dm_work_n;
+  PairSlot* slot[4];
+  GlueDev* glue_host[4];
+  GlueDev* glue_dev;  // [4]
+};
+struct LaneDyn {
+  const void* img;              // u8 frame of this step (device memory)
+  short nm, om, prev;           // map-table indices: detected / new map, old map, previously detected map (-1: none)
+  unsigned char nm_swap, om_swap;  // bit 0: rs <-> rs_tmp, bit 1: grad <-> grad_tmp relative to the table entry
+  unsigned char parity, det_in, det_out, slot;
+  unsigned tag_base;
+};
+struct LaneDynB {
+  LaneDyn v[kMaxLanes];
+};
+__host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int lane, int idx, unsigned swap) {
+  MapDev m = tab[lane * kLaneMaps + idx];
+  if (swap & 1u) {
+    float2* t = m.rs;
+    m.rs = m.rs_tmp;
+    m.rs_tmp = t;
+  }
+  if (swap & 2u) {
+    float2* t = m.grad;
+    m.grad = m.grad_tmp;
+    m.grad_tmp = t;
+  }
+  return m;
+}
+void launch_scale_space_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const LaneDynB& dyn, const int widths[2][3]);
+void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
+void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
+void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls);
+void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
+                      float max_radius, int gate);
+
 // Optional per-kernel timing with HIP events recorded on the launching stream (api.hip).
 void prof_begin(hipStream_t s, const char* name);
 void prof_end(hipStream_t s);

@@ -152,7 +152,7 @@ __device__ __forceinline__ float4 rowscan_fetch(const void* __restrict__ src, in
 }
 
 template <int MODE>  // 0: u8 image * 3.0f, 1: fp32 image, 2: box average (width d) of an integral image
-__global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, const void* __restrict__ src1,
+__device__ __forceinline__ void rowscan_body(const void* __restrict__ src0, const void* __restrict__ src1,
                                                  float* __restrict__ dst0, float* __restrict__ dst1, int R, int Cimg, int d0,
                                                  int d1, int ldw) {
   // C = row pitch of the integral images = the image width rounded up to a multiple of 4; the chain also runs over the
@@ -252,6 +252,23 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, const void* __restrict__ src1, float* __restrict__ dst0,
+                                                 float* __restrict__ dst1, int R, int Cimg, int d0, int d1, int ldw) {
+  rowscan_body<MODE>(src0, src1, dst0, dst1, R, Cimg, d0, d1, ldw);
+}
+// batched form (lane = blockIdx.z). stage 0: the lane's u8 frame -> a[0]; 1: a[0] -> b[0], b[1]; 2: b[0], b[1] -> a[0], a[1]
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int stage, int R, int Cimg, int d0,
+                                                   int d1, int ldw) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const void* s0 = stage == 0 ? dyn.v[blockIdx.z].img : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[0]);
+  const void* s1 = stage == 0 ? s0 : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[1]);
+  float* o0 = stage == 1 ? L.sb[0] : L.sa[0];
+  float* o1 = stage == 0 ? L.sa[0] : (stage == 1 ? L.sb[1] : L.sa[1]);
+  rowscan_body<MODE>(s0, s1, o0, o1, R, Cimg, d0, d1, ldw);
+}
+
 // ---- column accumulation (scale_space.cpp:59-65) --------------------------------------------------------------
 // The row pass transposed: a workgroup stages a strip of kColStrip columns x all rows in LDS, TRANSPOSED
 // (tile[col][row]), so that the lane that owns a column walks down it with ds_read/write_b128 (four rows per LDS
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
 // Narrow strips spread the staging traffic over many CUs. No global-memory latency sits on the chain.
 constexpr int kColStrip = 16;
 
-__global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh) {
+__device__ __forceinline__ void colscan_body(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh) {
   extern __shared__ float4 smem4[];
   float* tile = reinterpret_cast<float*>(smem4);  // [kColStrip][ldh]
   float* __restrict__ buf = blockIdx.y ? buf1 : buf0;
@@ -364,8 +381,17 @@ __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float
   }
 }
 
+__global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
+  colscan_body(buf0, buf1, R, C, ldh);
+}
+// batched form. which 0: a[0] alone; 1: b[0], b[1]; 2: a[0], a[1]
+__global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int which, int R, int C, int ldh) {
+  const LaneStatic& L = ls[blockIdx.z];
+  colscan_body(which == 1 ? L.sb[0] : L.sa[0], which == 0 ? L.sa[0] : (which == 1 ? L.sb[1] : L.sa[1]), R, C, ldh);
+}
+
 // ---- last box pass of both filters fused with DoG and squared gradient (scale_space.cpp:210-233) ------
-__global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, const float* __restrict__ II1, int d0,
+__device__ __forceinline__ void dog_mag_body(const float* __restrict__ II0, const float* __restrict__ II1, int d0,
                                                  int d1, float* __restrict__ dog, float* __restrict__ mag,
                                                  float* __restrict__ scale0, float* __restrict__ scale1, int R, int C,
                                                  int* __restrict__ rowcount) {
@@ -397,6 +423,17 @@ __global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, 
   if (scale1) scale1[i] = v1;
 }
 
+__global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, const float* __restrict__ II1, int d0, int d1,
+                                                 float* __restrict__ dog, float* __restrict__ mag, float* __restrict__ scale0,
+                                                 float* __restrict__ scale1, int R, int C, int* __restrict__ rowcount) {
+  dog_mag_body(II0, II1, d0, d1, dog, mag, scale0, scale1, R, C, rowcount);
+}
+__global__ __launch_bounds__(256) void k_dog_mag_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int d0, int d1, int R, int C) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const int b = dyn.v[blockIdx.z].parity;
+  dog_mag_body(L.sa[0], L.sa[1], d0, d1, L.dog2[b], L.mag2[b], nullptr, nullptr, R, C, L.rowcount2[b]);
+}
+
 // Threshold servo of EdgeDetector::detect (edge_detector.cpp:33-36), evaluated identically by every thread.
 __device__ __forceinline__ float servo_threshold(const KParams& p, const DetState& d) {
   float t = d.threshold;
@@ -410,7 +447,7 @@ __device__ __forceinline__ float servo_threshold(const KParams& p, const DetStat
 // ---- candidate test + plane fit (edge_detector.cpp:73-107) ---------------------------------------------
 // Tile = 4 rows x 64 columns; each wavefront is one 64-pixel row segment, so a __ballot is exactly the
 // raster-ordered candidate set of that segment.
-__global__ __launch_bounds__(256) void k_keyline_flag(const float* __restrict__ dog, const float* __restrict__ mag,
+__device__ __forceinline__ void keyline_flag_body(const float* __restrict__ dog, const float* __restrict__ mag,
                                                       KParams p, const DetState* __restrict__ det_in,
                                                       float4* __restrict__ stash, unsigned long long* __restrict__ bits,
                                                       int* __restrict__ rowcount) {
@@ -468,6 +505,17 @@ __global__ __launch_bounds__(256) void k_keyline_flag(const float* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(256) void k_keyline_flag(const float* __restrict__ dog, const float* __restrict__ mag, KParams p,
+                                                      const DetState* __restrict__ det_in, float4* __restrict__ stash,
+                                                      unsigned long long* __restrict__ bits, int* __restrict__ rowcount) {
+  keyline_flag_body(dog, mag, p, det_in, stash, bits, rowcount);
+}
+__global__ __launch_bounds__(256) void k_keyline_flag_b(KParams p, const LaneStatic* __restrict__ ls, LaneDynB dyn) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  keyline_flag_body(L.dog2[d.parity], L.mag2[d.parity], p, L.det + d.det_in, L.stash, L.bits, L.rowcount2[d.parity]);
+}
+
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -488,7 +536,7 @@ __device__ __forceinline__ float auto_threshold_from(const MapState& st, float p
 // rank = (#candidates in earlier rows) + (#candidates in earlier segments of this row) + (#lower lanes):
 // the raster rank of the reference's sequential loop, with truncation at keylines_max. Also rewrites the
 // whole dense mask and clears this map's distance-field cells.
-__global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const float4* __restrict__ stash,
+__device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const float4* __restrict__ stash,
                                                       const unsigned long long* __restrict__ bits,
                                                       const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
                                                       DetState* __restrict__ det_out, const MapState* prev_st,
@@ -562,6 +610,21 @@ __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const
 }
 
 // ---- joinEdges (edge_detector.cpp:125-165) + min/max of gradient_norm for tuneThreshold (:168-174) -----
+__global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const float4* __restrict__ stash,
+                                                      const unsigned long long* __restrict__ bits, const int* __restrict__ rowcount,
+                                                      const DetState* __restrict__ det_in, DetState* __restrict__ det_out,
+                                                      const MapState* prev_st, int clear_df, int ntiles) {
+  keyline_emit_body(p, m, stash, bits, rowcount, det_in, det_out, prev_st, clear_df, ntiles);
+}
+__global__ __launch_bounds__(256) void k_keyline_emit_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
+                                                        LaneDynB dyn, int clear_df, int ntiles) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  const MapDev m = lane_map(maptab, blockIdx.z, d.nm, d.nm_swap);
+  const MapState* prev = d.prev >= 0 ? maptab[blockIdx.z * kLaneMaps + d.prev].st : nullptr;
+  keyline_emit_body(p, m, L.stash, L.bits, L.rowcount2[d.parity], L.det + d.det_in, L.det + d.det_out, prev, clear_df, ntiles);
+}
+
 // r-range of a keyline's probe segment (cells round(pos + u r), r in [-half, half)) that can fall into the pixel box
 // [x0, x1) x [y0, y1): conservative (one cell of slack on each side, the exact test per cell is made by whoever walks the
 // range), so the two reciprocals are the 1-ulp hardware ones. Returns false when no cell can fall into the box.
@@ -594,7 +657,7 @@ __device__ __forceinline__ bool df_clip_range(float2 pos, float2 u, int half, in
 // 32 x 32). A workgroup's 256 keylines are neighbours in raster order, so they share tiles: counts are aggregated in an
 // LDS table, one returning global atomic per touched tile and workgroup reserves the slots, and the crossing test is
 // simply evaluated twice (count, then place) instead of keeping per-thread tile lists.
-__global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m, int T, int ntx, int nty) {
+__device__ __forceinline__ void join_edges_body(KParams p, MapDev m, int T, int ntx, int nty) {
   extern __shared__ int t_cnt[];  // [ntx * nty] count, then cursor, of this workgroup's keylines per tile
   const int n = m.st->n;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -697,6 +760,12 @@ __global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m, int T, 
     atomicMin(&m.st->gmin_bits, b_min);
     atomicMax(&m.st->gmax_bits, b_max);
   }
+}
+
+__global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m, int T, int ntx, int nty) { join_edges_body(p, m, T, ntx, nty); }
+__global__ __launch_bounds__(256) void k_join_edges_b(KParams p, const MapDev* __restrict__ maptab, LaneDynB dyn, int T, int ntx, int nty) {
+  const LaneDyn d = dyn.v[blockIdx.z];
+  join_edges_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), T, ntx, nty);
 }
 
 // ---- DistanceField::build (core.hpp:37-59) ---------------------------------------------------------------
@@ -1027,7 +1096,7 @@ __global__ __launch_bounds__(kDfsThreads) void k_df_strips(KParams p, MapDev m, 
 // finished tile is stored, empty cells included (no clearing pass). A tile whose list overflowed (more than kDfTileCap
 // crossing keylines) is rebuilt from the row range instead: same cells, just slower.
 template <int T>
-__global__ __launch_bounds__(kDfsThreads) void k_df_lists(KParams p, MapDev m, const DetState* __restrict__ det_prev RH_DFS_STAMP_ARG) {
+__device__ __forceinline__ void df_lists_body(KParams p, MapDev m, const DetState* __restrict__ det_prev RH_DFS_STAMP_ARG) {
   extern __shared__ __align__(16) unsigned df_smem[];
   __shared__ int l_n;
   const int tid = threadIdx.x;
@@ -1088,6 +1157,19 @@ __global__ __launch_bounds__(kDfsThreads) void k_df_lists(KParams p, MapDev m, c
   }
   RH_DFS_STAMP(3);
 }
+
+template <int T>
+__global__ __launch_bounds__(kDfsThreads) void k_df_lists(KParams p, MapDev m, const DetState* __restrict__ det_prev RH_DFS_STAMP_ARG) {
+  df_lists_body<T>(p, m, det_prev RH_DFS_STAMP_FWD);
+}
+#ifndef RH_DF_PROBE
+template <int T>
+__global__ __launch_bounds__(kDfsThreads) void k_df_lists_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
+                                                            LaneDynB dyn) {
+  const LaneDyn d = dyn.v[blockIdx.z];
+  df_lists_body<T>(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), ls[blockIdx.z].det + d.det_out);
+}
+#endif
 
 __global__ __launch_bounds__(256) void k_df_decode(KParams p, MapDev m, int* __restrict__ id_out, int* __restrict__ dist_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1237,6 +1319,66 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
   const dim3 gt(div_up(C, 64), div_up(R, 4));
   RH_LAUNCH(k_dog_mag, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2],
                      widths[1][2], sb.dog, sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
+}
+
+// ---- batched launchers (lane = blockIdx.z): the same grids with a third dimension ------------------------------------------
+void launch_scale_space_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const LaneDynB& dyn, const int widths[2][3]) {
+  const int R = p.rows, C = p.cols;
+  const int Cp = (C + 3) & ~3;
+  const int ldw = lds_pitch(Cp);
+  const size_t shm = (size_t)kStrip * ldw * sizeof(float);
+  const int ldh = lds_pitch(R + (4 - R % 4) % 4);
+  const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan_b<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan_b<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colscan_b), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const unsigned z = (unsigned)lanes;
+  const dim3 g1(div_up(R, kStrip), 1, z), g2(div_up(R, kStrip), 2, z);
+  const dim3 c1(div_up(Cp, kColStrip), 1, z), c2(div_up(Cp, kColStrip), 2, z);
+  RH_LAUNCH(k_rowscan_b<0>, g1, dim3(256), shm, s, ls, dyn, 0, R, C, 0, 0, ldw);
+  RH_LAUNCH(k_colscan_b, c1, dim3(256), cshm, s, ls, 0, R, Cp, ldh);
+  RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, 1, R, C, widths[0][0], widths[1][0], ldw);
+  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, 1, R, Cp, ldh);
+  RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, 2, R, C, widths[0][1], widths[1][1], ldw);
+  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, 2, R, Cp, ldh);
+  RH_LAUNCH(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 4), z), dim3(64, 4), 0, s, ls, dyn, widths[0][2], widths[1][2], R, C);
+}
+
+void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn) {
+  const unsigned z = (unsigned)lanes;
+  const dim3 gt(div_up(p.cols, 64), div_up(p.rows, 4), z);
+  const DfGrid dg = df_grid(p.rows, p.cols);
+  RH_LAUNCH(k_keyline_flag_b, gt, dim3(64, 4), 0, s, p, ls, dyn);
+  RH_LAUNCH(k_keyline_emit_b, gt, dim3(64, 4), 0, s, p, ls, maptab, dyn, 0, dg.ntx * dg.nty);
+  RH_LAUNCH(k_join_edges_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, maptab, dyn, dg.T, dg.ntx,
+            dg.nty);
+}
+
+void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn) {
+  const DfGrid dg = df_grid(p.rows, p.cols);
+  const size_t list_bytes = (size_t)kDfsList * (sizeof(float4) + 2 * sizeof(int));
+  const size_t shm = (((size_t)dg.T * (dg.T + 1) + 3) & ~(size_t)3) * sizeof(unsigned) + list_bytes;
+  static size_t have[2] = {0, 0};
+  const dim3 grid(dg.ntx, dg.nty, (unsigned)lanes);
+  if (dg.T == 32) {
+    if (shm > have[0]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_df_lists_b<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        (void)hipGetLastError();
+      have[0] = shm;
+    }
+    RH_LAUNCH(k_df_lists_b<32>, grid, dim3(kDfsThreads), shm, s, p, ls, maptab, dyn);
+  } else {
+    if (shm > have[1]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_df_lists_b<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        (void)hipGetLastError();
+      have[1] = shm;
+    }
+    RH_LAUNCH(k_df_lists_b<64>, grid, dim3(kDfsThreads), shm, s, p, ls, maptab, dyn);
+  }
 }
 
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,

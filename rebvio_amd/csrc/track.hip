@@ -787,7 +787,7 @@ __device__ __forceinline__ void chain_collect_records(const unsigned long long* 
 }
 
 template <int kChainThreads>
-__global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om, MapDev nm, int calls, int do_ext,
+__device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, int calls, int do_ext,
                                                             const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
                                                             unsigned long long* __restrict__ xch, unsigned tag_base,
                                                             int* __restrict__ bar_err, const int* __restrict__ hist,
@@ -994,6 +994,28 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
   }
   RH_STAMP(2 + calls * 6);
 #undef RH_STAMP
+}
+
+template <int kChainThreads>
+__global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om, MapDev nm, int calls, int do_ext,
+                                                            const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
+                                                            unsigned long long* __restrict__ xch, unsigned tag_base,
+                                                            int* __restrict__ bar_err, const int* __restrict__ hist,
+                                                            unsigned frame_count, float* __restrict__ xrv_part,
+                                                            PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
+                                                            unsigned long long* __restrict__ stamps) {
+  lm_chain_body<kChainThreads>(p, om, nm, calls, do_ext, st_in, st_out, xch, tag_base, bar_err, hist, frame_count, xrv_part, slot,
+                               hist_to_zero, stamps);
+}
+// batched form (lane = blockIdx.z): every lane's workgroups exchange records among themselves through the lane's own words
+template <int kChainThreads>
+__global__ __launch_bounds__(kChainThreads) void k_lm_chain_b(KParams p, const LaneStatic* __restrict__ ls,
+                                                              const MapDev* __restrict__ maptab, LaneDynB dyn, int calls) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  PairSlot* slot = L.slot[d.slot];
+  lm_chain_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls, 1,
+                               L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, slot->xrv, slot, L.hist, nullptr);
 }
 
 // ---- EdgeMap::directedMatch / searchMatch (edge_map.cpp:101-218) ----------------------------------------------
@@ -1287,7 +1309,7 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
 // keyline, then ONE probe and at most ONE candidate; the first accepted slot in the reference's order is found with a
 // ballot over the eight lanes and that lane, which holds the rotated candidate, commits it. Same arithmetic per probe,
 // hence the same bits; ~1/6 of the instructions per wave on eight times the waves.
-__global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+__device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                          float max_radius, int* __restrict__ work, int* __restrict__ work_n,
                                                          int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
                                                          GlueDev* __restrict__ gd_copy) {
@@ -1372,10 +1394,26 @@ __global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, M
   }
 }
 
+__global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
+                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
+                                                         GlueDev* __restrict__ gd_copy) {
+  directed_match8_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd, gd_copy);
+}
+__global__ __launch_bounds__(256) void k_directed_match8_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
+                                                           LaneDynB dyn, float max_radius) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  const Vec3 z3{};
+  const Mat3 z9{};
+  directed_match8_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
+                       L.dm_work, L.dm_work_n, 1, z9, L.glue_host[d.slot], L.glue_dev + d.slot);
+}
+
 // Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
 // sequence; the first accepted slot in that order (lowest slot index) is the match, found with a ballot.
 // tn/tp are produced by the same repeated -1.0f / +1.0f steps as the sequential loop (not dq_rho -/+ k).
-__global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+__device__ __forceinline__ void directed_match_tail_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                              float max_radius, const int* __restrict__ work,
                                                              const int* __restrict__ work_n, int rot_, Mat3 R0_,
                                                              const GlueDev* __restrict__ gd) {
@@ -1522,6 +1560,22 @@ __global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev n
   }
 }
 
+__global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+                                                             float max_radius, const int* __restrict__ work,
+                                                             const int* __restrict__ work_n, int rot_, Mat3 R0_,
+                                                             const GlueDev* __restrict__ gd) {
+  directed_match_tail_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd);
+}
+__global__ __launch_bounds__(256) void k_directed_match_tail_b(KParams p, const LaneStatic* __restrict__ ls,
+                                                               const MapDev* __restrict__ maptab, LaneDynB dyn, float max_radius) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  const Vec3 z3{};
+  const Mat3 z9{};
+  directed_match_tail_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9,
+                           max_radius, L.dm_work, L.dm_work_n, 1, z9, L.glue_dev + d.slot);
+}
+
 // ---- EdgeMap::searchMatch as a public single-keyline call (edge_map.hpp:93-94, edge_map.cpp:101-184) ----------------
 // One lane walks the reference's alternating probe sequence with the same set-up / acceptance code as the directedMatch
 // kernels (vel / Rvel as given: directedMatch rotates them by Rback before it calls searchMatch, edge_map.cpp:193-194).
@@ -1630,7 +1684,7 @@ __global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel
 // this map. Optionally (streaming driver) the keyline is also put through the NEXT pair's first rotateKeylines
 // (rebvio.cpp:165) and binned for its estimateQuantile, which removes that pair's k_rotate launch.
 // gd != null: vel / next rotation come from *gd; gd->nan_v (rebvio.cpp:236) leaves rho untouched like the match gate.
-__global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
+__device__ __forceinline__ void regularize_ekf_body(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
                                                         int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
                                                         int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
   __shared__ int sh[128];
@@ -1741,6 +1795,21 @@ __global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec
   if (next_rot) {
     if ((int)threadIdx.x < hist_bins && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
   }
+}
+
+__global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
+                                                        int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
+                                                        int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
+  regularize_ekf_body(p, m, vel_, gate_min_matches, work_n_reset, next_rot_, Rnext_, hist, hist_bins, gd);
+}
+__global__ __launch_bounds__(256) void k_regularize_ekf_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
+                                                          LaneDynB dyn, int gate_min_matches) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  const Vec3 z3{};
+  const Mat3 z9{};
+  regularize_ekf_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), z3, gate_min_matches, L.dm_work_n, 0, z9, L.hist, p.quantile_num_bins,
+                      L.glue_dev + d.slot);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
@@ -1885,6 +1954,20 @@ void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m,
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
   RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(z), gate, work_n_reset, 0, mat3(I), hist,
             p.quantile_num_bins, g_dev);
+}
+
+void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls) {
+  // 512-thread workgroups (the single-stream default); lanes x 30 workgroups at 16k keylines must all be resident: with one
+  // workgroup per CU that holds up to 8 lanes on 256 CUs
+  RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls);
+}
+
+void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
+                      float max_radius, int gate) {
+  const unsigned z = (unsigned)lanes;
+  RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
+  RH_LAUNCH(k_directed_match_tail_b, dim3(dm_tail_blocks(p.kmax), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
+  RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
 }
 
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp, int gate) {

@@ -703,3 +703,47 @@ def test_context_creation_leaves_signal_dispositions_untouched(B):
         finally:
             os.environ.pop("REBVIO_HIP_GLUE", None)
         assert before == after, glue
+
+
+def test_batched_lanes_equal_stand_alone_streams(B, c2_stream):
+    """rebvio_hip_batch_*: three camera streams advanced in lock-step by batched launches (lane = blockIdx.z) produce, lane by
+    lane, the records of three stand-alone contexts fed the same frames - bit for bit (same kernel bodies, same per-lane
+    reduction order, same host glue), only delivered on a different schedule."""
+    from rebvio_amd import synth
+    cam = c2_stream[1]
+    L, n = 3, 36
+    streams = [c2_stream[0]] + [synth.render_stream(cam.width, cam.height, 8, stream_id=s)[0] for s in (1, 2)]
+    order = synth.pingpong_indices(8, n)
+    npx = cam.width * cam.height
+
+    def rec(out, nk):
+        return (tuple(out.Vg), tuple(out.V), tuple(out.Xgv), tuple(out.R), tuple(out.P_V), out.klm_num, out.kf_matches, out.reg_num,
+                out.lm_accept_mask, out.status, nk)
+
+    want = []
+    for s in range(L):
+        ctx = B.Context(params_for(B, cam, **KW_C2))
+        dev = ctx.upload_frames(streams[s])
+        r = []
+        for k, i in enumerate(order):
+            out, nk = ctx.push_frame_u8_device(dev + int(i) * npx, k * 50000)
+            if out.status >= 0:
+                r.append(rec(out, nk))
+        ctx.flush()
+        ctx.close()
+        want.append(r)
+    bat = B.Batch(params_for(B, cam, **KW_C2), L)
+    devs = [bat.lanes[s].upload_frames(streams[s]) for s in range(L)]
+    got = [[] for _ in range(L)]
+    for k, i in enumerate(order):
+        outs, nks = bat.push_u8_device([d + int(i) * npx for d in devs], k * 50000)
+        for s in range(L):
+            if outs[s].status >= 0:
+                got[s].append(rec(outs[s], nks[s]))
+    bat.flush()
+    bat.close()
+    for s in range(L):
+        m = min(len(got[s]), len(want[s]))
+        assert m >= n - 10, (s, len(got[s]), len(want[s]))
+        assert got[s][:m] == want[s][:m], s
+    assert got[0] != got[1]  # different scenes per lane
