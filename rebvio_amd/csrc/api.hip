@@ -1991,6 +1991,13 @@ struct rebvio_hip_batch {
   bool has_cur = false, has_prev = false;
   uint64_t pair_seq = 0;
   int lead = 4;
+  // second halves are queued BEFORE the host has the glue: parked behind a hipStreamWaitValue32 on this pinned word (one for
+  // the whole batch), released with the pair's sequence number once every lane's glue record is written (as in the
+  // single-stream driver, see enqueue_a_chain)
+  unsigned* glue_flag = nullptr;
+  bool prelaunch_b = true;
+  bool cur_b_enqueued = false;
+  unsigned cur_seq = 0;
   // detect-enqueue worker: launches the detect stage of a step while the caller thread runs the glue and launches the
   // track stage (the reference's data-acquisition thread, rebvio.cpp:28; same split as the single-stream driver)
   struct DetStep {
@@ -2025,12 +2032,61 @@ inline unsigned map_swap_bits(const rebvio_hip_map* m) { return (m->d.rs != m->c
 
 void batch_release_map(rebvio_hip_map* m, bool record_done);
 
-// glue of the pair in flight for every lane, then its second half (batched), then the old maps go back to their pools
-int batch_finish_current(rebvio_hip_batch* b, rebvio_hip_pair_out* completed, int* completed_keylines, bool* have_completed) {
+// second half of the pair in flight for every lane (batched); with `parked` it sits behind the wait on the batch's flag and
+// reads the glue records the host writes later. The old maps go back to their pools (stream-ordered).
+int batch_enqueue_b(rebvio_hip_batch* b, bool parked) {
   rebvio_hip_batch::Pair& cur = b->cur;
-  HIPCHK(hipEventSynchronize(b->slot_ev[cur.slot]));
+  hipStream_t s = b->st.s_trk;
+  if (parked) {
+    HIPCHK(hipStreamWaitValue32(s, b->glue_flag, b->cur_seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
+    b->cur_b_enqueued = true;  // from here on the flag MUST be written, whatever happens
+  }
   LaneDynB dyn{};
-  bool any_b = false;
+  for (int l = 0; l < b->B; ++l) {
+    LaneDyn& d = dyn.v[l];
+    d.nm = (short)cur.nf.m[l]->tab_idx;
+    d.om = (short)cur.of.m[l]->tab_idx;
+    d.nm_swap = (unsigned char)map_swap_bits(cur.nf.m[l]);
+    d.om_swap = (unsigned char)map_swap_bits(cur.of.m[l]);
+    d.slot = (unsigned char)cur.slot;
+  }
+  const int gate = (int)b->P.global_min_matches_threshold;
+  launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0);
+  HIPCHK(hipGetLastError());
+  for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
+    rebvio_hip_map* nm = cur.nf.m[l];
+    std::swap(nm->d.rs, nm->d.rs_tmp);
+    std::swap(nm->d.grad, nm->d.grad_tmp);
+    nm->pre_rotated = true;
+    batch_release_map(cur.of.m[l], l == b->B - 1);
+  }
+  return 0;
+}
+
+void batch_release_flag(rebvio_hip_batch* b) {
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // every lane's record before the flag
+  __atomic_store_n(b->glue_flag, b->cur_seq, __ATOMIC_RELEASE);
+}
+
+// waits for the first half of the pair in flight, runs every lane's glue (rebvio.cpp:186-233) and leaves the records where
+// the second half reads them; the counters of the PREVIOUS pair arrive with this pair's slot (its old maps)
+int batch_glue_current(rebvio_hip_batch* b, rebvio_hip_pair_out* completed, int* completed_keylines) {
+  rebvio_hip_batch::Pair& cur = b->cur;
+  struct Guard {  // never leave the stream parked behind an un-released wait
+    rebvio_hip_batch* b;
+    bool armed;
+    ~Guard() {
+      if (armed && b->cur_b_enqueued) {
+        for (int l = 0; l < b->B; ++l) {
+          GlueDev gl{};
+          gl.nan_v = 1;
+          std::memcpy(b->lane[l]->glue_host[b->cur.slot], &gl, sizeof(gl));
+        }
+        batch_release_flag(b);
+      }
+    }
+  } guard{b, true};
+  HIPCHK(hipEventSynchronize(b->slot_ev[cur.slot]));
   for (int l = 0; l < b->B; ++l) {
     rebvio_hip_ctx* c = b->lane[l];
     PairSlot* slot = c->slot[cur.slot];
@@ -2046,7 +2102,6 @@ int batch_finish_current(rebvio_hip_batch* b, rebvio_hip_pair_out* completed, in
       if (completed) completed[l] = po;
       if (completed_keylines) completed_keylines[l] = slot->old_st.n;
     }
-    rebvio_hip_map* om = cur.of.m[l];
     rebvio_hip_map* nm = cur.nf.m[l];
     nm->n_host = slot->new_st.n;
     nm->thr_host = slot->new_st.threshold;
@@ -2069,32 +2124,10 @@ int batch_finish_current(rebvio_hip_batch* b, rebvio_hip_pair_out* completed, in
       for (size_t i = 0; i < sizeof(GlueDev) / sizeof(unsigned); ++i) dst[i] = words[i];
     }
     if (g.nan_v) cur.out[l].status = 1;
-    any_b = true;
-    LaneDyn& d = dyn.v[l];
-    d.nm = (short)nm->tab_idx;
-    d.om = (short)om->tab_idx;
-    d.nm_swap = (unsigned char)map_swap_bits(nm);
-    d.om_swap = (unsigned char)map_swap_bits(om);
-    d.slot = (unsigned char)cur.slot;
   }
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // the glue records are in memory before the launch that reads them is queued
-  if (b->has_prev && have_completed) *have_completed = true;
-  b->has_prev = false;
-  if (any_b) {
-    const int gate = (int)b->P.global_min_matches_threshold;
-    launch_b_chain_b(b->st.s_trk, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0);
-    HIPCHK(hipGetLastError());
-    for (int l = 0; l < b->B; ++l) {  // (a lane whose pair was skipped for a NaN velocity still had its next rotation applied)
-      rebvio_hip_map* nm = cur.nf.m[l];
-      std::swap(nm->d.rs, nm->d.rs_tmp);
-      std::swap(nm->d.grad, nm->d.grad_tmp);
-      nm->pre_rotated = true;
-      batch_release_map(cur.of.m[l], l == b->B - 1);  // stream-ordered: reusable once the second half has drained
-    }
-  }
-  b->prev = cur;
-  b->has_prev = true;
-  b->has_cur = false;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  if (b->cur_b_enqueued) batch_release_flag(b);
+  guard.armed = false;
   return 0;
 }
 
@@ -2215,6 +2248,7 @@ void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : b->slot_ev)
     if (e) (void)hipEventDestroy(e);
+  if (b->glue_flag) (void)hipHostFree(b->glue_flag);
   if (b->st.s_det) (void)hipStreamDestroy(b->st.s_det);
   if (b->st.s_key) (void)hipStreamDestroy(b->st.s_key);
   if (b->st.s_trk) (void)hipStreamDestroy(b->st.s_trk);
@@ -2298,6 +2332,14 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   for (auto& e : b->ev_ready) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : b->slot_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_LEAD")) b->lead = std::min(8, std::max(3, std::atoi(e)));
+  HIPCHK(hipHostMalloc(&b->glue_flag, 64, hipHostMallocDefault));
+  std::memset(b->glue_flag, 0, 64);
+  {
+    int can = 0;
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, b->device);
+    const char* e = std::getenv("REBVIO_HIP_PRELAUNCH");
+    b->prelaunch_b = can != 0 && !(e && std::atoi(e) == 0);
+  }
   HIPCHK(hipDeviceSynchronize());
   guard.b = nullptr;
   *out = b;
@@ -2373,25 +2415,53 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   b->frames.push_back(fr);
   b->step++;
 
-  // ---- finish the pair in flight (glue, second half), then start the next one behind it ----
-  if (b->has_cur) {
-    bool have = false;
-    int rc = batch_finish_current(b, out, keylines, &have);
-    if (rc) return rc;
-  }
-  if ((int)b->frames.size() >= b->lead) {
-    rebvio_hip_batch::Pair pp;
+  // ---- track stage. With the second half parked behind the flag: W + B of the pair in flight, then A of the next pair, are
+  // queued BEFORE the host waits for the pair in flight; then glue for every lane, then the flag. Otherwise B follows the glue.
+  const bool start_next = (int)b->frames.size() >= b->lead;
+  int rc_pre = 0;
+  b->cur_b_enqueued = false;
+  if (b->has_cur && b->prelaunch_b) rc_pre = batch_enqueue_b(b, true);
+  rebvio_hip_batch::Pair pp;
+  bool have_next = false;
+  auto enqueue_next = [&]() -> int {
     pp.of = b->frames[0];
     pp.nf = b->frames[1];
-    pp.slot = (int)(b->pair_seq++ % rebvio_hip_ctx::kSlots);
+    pp.slot = (int)(b->pair_seq % rebvio_hip_ctx::kSlots);
+    b->pair_seq++;
     pp.R.resize((size_t)B);
     pp.out.resize((size_t)B);
     pp.frame_dt = (float)((double)(float)(pp.nf.m[0]->ts - pp.of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
     int rc = batch_enqueue_a(b, pp);
     if (rc) return rc;
     b->frames.pop_front();
+    have_next = true;
+    return 0;
+  };
+  if (rc_pre == 0 && start_next && (!b->has_cur || b->prelaunch_b)) rc_pre = enqueue_next();
+  if (b->has_cur) {
+    const bool had_prev = b->has_prev;
+    int rc = batch_glue_current(b, out, keylines);  // (releases the flag on every path once the second half is parked)
+    if (rc) return rc;
+    (void)had_prev;
+    if (!b->prelaunch_b) {
+      rc = batch_enqueue_b(b, false);
+      if (rc) return rc;
+    }
+    b->prev = b->cur;
+    b->has_prev = true;
+    b->has_cur = false;
+  }
+  if (rc_pre) return rc_pre;
+  if (!have_next && start_next && !b->prelaunch_b) {
+    int rc = enqueue_next();
+    if (rc) return rc;
+  }
+  if (have_next) {
+    for (int l = 0; l < B; ++l)
+      if (pp.of.m[l]->pre_rotated) pp.R[l] = prior_rotation(b->lane[l], nullptr);  // what the parked second half applies (bias as of now)
     b->cur = pp;
     b->has_cur = true;
+    b->cur_seq = (unsigned)b->pair_seq;  // never 0 (the idle value of the flag): pair_seq was incremented above
   }
   return 0;
 }
@@ -2400,8 +2470,18 @@ int rebvio_hip_batch_flush(rebvio_hip_batch* b) {
   HIPCHK(hipSetDevice(b->device));
   while (b->det_done_steps.load(std::memory_order_acquire) < b->step) std::this_thread::yield();
   if (b->has_cur) {
-    int rc = batch_finish_current(b, nullptr, nullptr, nullptr);
+    b->cur_b_enqueued = false;
+    int rc = b->prelaunch_b ? batch_enqueue_b(b, true) : 0;
+    const int rc2 = batch_glue_current(b, nullptr, nullptr);  // releases the wait in every case
     if (rc) return rc;
+    if (rc2) return rc2;
+    if (!b->prelaunch_b) {
+      rc = batch_enqueue_b(b, false);
+      if (rc) return rc;
+    }
+    b->prev = b->cur;
+    b->has_prev = true;
+    b->has_cur = false;
   }
   if (b->has_prev) {
     for (size_t l = 0; l < b->prev.nf.m.size(); ++l) batch_release_map(b->prev.nf.m[l], l + 1 == b->prev.nf.m.size());
