@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--lanes", default="4,8",
                     help="extra runs (N=1 only, never the headline): this many camera streams per GPU advanced in lock-step by "
                          "batched launches (rebvio_hip_batch_*); '' or 0 skips them")
+    ap.add_argument("--no-host-class", action="store_true")
     ap.add_argument("--batched-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--child-keylines", type=int, default=15000, help=argparse.SUPPRESS)
     ap.add_argument("--control-plane-only", action="store_true",
@@ -368,6 +369,14 @@ def main():
                 else:
                     print(f"batched run with {b} lanes failed: {r.stderr[-800:]}", file=sys.stderr)
             result["streams_per_gpu"] = runs
+        if world == 1 and args.config == "c2" and not args.no_host_class:
+            try:
+                result["config"]["host_class_fps"] = host_class_rate(frames, cam, cfg)
+                result["config"]["host_class_note"] = ("rebvio::Rebvio (the reference's C++ class: camera + 200 Hz IMU, gyro prior, scale / "
+                                                       "attitude / bias filter per pair) replaying the same stream through rebvio_replay; "
+                                                       "1e6 / (per-pair microseconds of its tracking worker)")
+            except Exception as e:  # the extra figure must never cost the line
+                print(f"host class rate not measured: {e}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(frames, cam, cfg, args.base_frames, args.cpu_seconds)
         sys.stdout.flush()
@@ -376,6 +385,32 @@ def main():
         os.dup2(2, 1)  # process-group teardown may log again
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_class_rate(frames, cam, cfg, n=4000):
+    """Frames/s of the drop-in C++ class rebvio::Rebvio (full camera + IMU fusion) on the bench's stream: rebvio_replay over
+    a raw file, rate taken from the tracking worker's own per-pair timers (REBVIO_HOST_TIMERS), process start excluded."""
+    import re
+    import subprocess
+    import tempfile
+    from rebvio_amd import synth
+    exe = os.path.join(ROOT, "rebvio_amd", "_build", "rebvio_replay")
+    with tempfile.TemporaryDirectory() as d:
+        order = synth.pingpong_indices(len(frames), n)
+        frames[order].tofile(os.path.join(d, "f.u8"))
+        ts, gyro, acc = synth.imu_samples(synth.make_scene(0), n, noise_seed=1)
+        rec = np.zeros(len(ts), dtype=[("ts", "<i8"), ("gyro", "<f4", 3), ("acc", "<f4", 3)])
+        rec["ts"], rec["gyro"], rec["acc"] = ts, gyro * 0, acc  # ping-pong replay: a still gyro
+        rec.tofile(os.path.join(d, "imu.bin"))
+        r = subprocess.run([exe, "--raw", os.path.join(d, "f.u8"), "--size", str(cam.width), str(cam.height), "--imu", os.path.join(d, "imu.bin"),
+                            "--camera", str(cam.fm), str(cam.cx), str(cam.cy), "--keylines", str(cfg["keylines_ref"]), str(cfg["keylines_max"]),
+                            "--out", os.path.join(d, "o.txt")], capture_output=True, text=True, env=dict(os.environ, REBVIO_HOST_TIMERS="1"),
+                           timeout=300)
+    m = re.search(r"per pair \(us\): first half on device ([0-9.]+)\s+acceleration \+ bias/scale filter ([0-9.]+)\s+second half on device "
+                  r"([0-9.]+)\s+pose \+ callbacks ([0-9.]+)", r.stderr)
+    if r.returncode != 0 or not m:
+        raise RuntimeError(r.stderr[-400:])
+    return 1e6 / sum(float(v) for v in m.groups())
 
 
 def batched_run(lanes, frames0, cam, cfg, kw, base_frames, npx, n_keylines, steps=1200, warmup=800):

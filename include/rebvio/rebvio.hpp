@@ -6,6 +6,7 @@
 #include <atomic>
 #include <functional>
 #include <mutex>
+#include <deque>
 #include <queue>
 #include <thread>
 #include <vector>
@@ -50,7 +51,7 @@ class Rebvio {
 
   rebvio::RebvioConfig config_;
   std::atomic<bool> run_;
-  std::atomic<unsigned int> num_frames_, num_detected_, num_images_;
+  std::atomic<unsigned int> num_frames_, num_detected_, num_images_, num_published_{0};
   rebvio::Camera camera_;
   rebvio::EdgeDetector edge_detector_;
   rebvio::Core core_;
@@ -61,7 +62,7 @@ class Rebvio {
   std::mutex image_buffer_mutex_;
   std::queue<rebvio::types::Imu> imu_buffer_;
   std::mutex imu_buffer_mutex_;
-  std::queue<rebvio::EdgeMap::SharedPtr> edge_map_buffer_;
+  std::deque<rebvio::EdgeMap::SharedPtr> edge_map_buffer_;  // (a deque: the tracker looks one map ahead for the next pair's gyro prior)
   std::mutex edge_map_buffer_mutex_;
   std::vector<std::function<void(cv::Mat&, rebvio::EdgeMap::SharedPtr&)>> edge_image_callbacks_;
   std::vector<std::function<void(rebvio::types::Odometry&)>> odometry_callbacks_;

@@ -43,6 +43,9 @@ class SABEstimator {
 
  private:
   SABEstimator::Config config_;
+  // inverse of the prior covariance Pp: constant over the Gauss-Newton iterations of one estimator (computed on first use)
+  rebvio::types::Matrix7f Wp_;
+  bool Wp_valid_ = false;
 };
 
 }  // namespace rebvio

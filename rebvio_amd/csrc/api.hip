@@ -161,6 +161,7 @@ struct rebvio_hip_map {
   int n_host = -1;
   float thr_host = -1.0f;
   bool trk_waited = false;  // the track stream already holds a wait on `ready` (a second one is another barrier packet)
+  hm::M3 pre_R{};           // ... with this rotation (per-pair API: checked against the prior the next _begin is given)
   int tab_idx = -1;         // entry of this map in its lane's device map table (batch driver)
   MapDev canon{};           // ... as uploaded there (the live `d` differs from it by the ping-pong swaps only)
 };
@@ -278,6 +279,16 @@ struct rebvio_hip_ctx {
   bool dbg = false;
   uint64_t t_frames = 0;
   bool owns_streams = true;  // false for the lanes of a batch (rebvio_hip_batch_*)
+  // track_pair_begin / _finish with the second half parked behind a wait on glue_flag[kSlots - 1] (see track_pair_begin)
+  bool bf_parked = false;
+  unsigned bf_seq = 0, bf_counter = 0;
+  // two result slots: the next pair's first half (and its parked second half) may be queued before the caller fetches the
+  // previous pair's counters (rebvio_hip_track_pair_finish_async / _result)
+  hipEvent_t bf_done[2]{};
+  MapState* h_bf = nullptr;  // [2] pinned
+  int bf_cur = 0;            // slot of the pair between _begin and _finish_async
+  int bf_res = -1;           // slot whose result is to be fetched (-1: none)
+  bool bf_nan[2] = {false, false};
 };
 
 namespace {
@@ -288,6 +299,26 @@ inline void wait_enqueued(rebvio_hip_map* m) {
 }
 
 size_t part_call_stride(const rebvio_hip_ctx* c) { return (size_t)c->maxblocks * kPartStride; }
+
+// Glue record, then the value a parked second half waits for. Word stores only: the destination may be write-combined device
+// memory behind the BAR (REBVIO_HIP_GLUE=vram), which must never be read and needs explicit fences to leave the CPU in order.
+void write_glue_and_flag(rebvio_hip_ctx* c, int slot, unsigned seq, const GlueDev& g) {
+  volatile unsigned* dst = reinterpret_cast<volatile unsigned*>(c->glue_host[slot]);
+  unsigned words[sizeof(GlueDev) / sizeof(unsigned)];
+  std::memcpy(words, &g, sizeof(g));
+  for (size_t i = 0; i < sizeof(GlueDev) / sizeof(unsigned); ++i) dst[i] = words[i];
+  if (c->glue_vram) __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  __atomic_store_n(c->glue_flag + slot, seq, __ATOMIC_RELEASE);
+  if (c->glue_vram) __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+// a begin without its finish (caller error, or a context torn down mid-pair): let the parked kernels fall through
+void release_parked_pair(rebvio_hip_ctx* c) {
+  if (!c->bf_parked) return;
+  GlueDev gl{};
+  gl.nan_v = 1;
+  write_glue_and_flag(c, rebvio_hip_ctx::kSlots - 1, c->bf_seq, gl);
+  c->bf_parked = false;
+}
 
 int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   // keyline arrays are padded to the launch grids (256- and 1024-thread workgroups) so kernels may load before checking n
@@ -632,7 +663,10 @@ int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, siz
   if (c->pin_used[ps]) HIPCHK(hipEventSynchronize(c->pin_ev[ps]));  // its previous copy has left the slot
   uint8_t* dst = static_cast<uint8_t*>(c->pin[ps]);
   const uint8_t* src = static_cast<const uint8_t*>(img);
-  for (int r = 0; r < c->P.rows; ++r) std::memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * pitch_bytes, row_bytes);
+  if (pitch_bytes == row_bytes)
+    std::memcpy(dst, src, (size_t)c->P.rows * row_bytes);
+  else
+    for (int r = 0; r < c->P.rows; ++r) std::memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * pitch_bytes, row_bytes);
   HIPCHK(hipMemcpyAsync(dst_dev, dst, (size_t)c->P.rows * row_bytes, hipMemcpyHostToDevice, c->s_det));
   HIPCHK(hipEventRecord(c->pin_ev[ps], c->s_det));
   c->pin_used[ps] = true;
@@ -921,6 +955,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
 void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  release_parked_pair(c);
   if (c->det_thread.joinable()) {
     {
       std::lock_guard<std::mutex> lk(c->det_mu);
@@ -978,6 +1013,9 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->glue_dev) (void)hipFree(c->glue_dev);
   if (c->lm_bar_err) (void)hipHostFree(c->lm_bar_err);
   if (c->lm_stamps) (void)hipHostFree(c->lm_stamps);
+  for (auto& e : c->bf_done)
+    if (e) (void)hipEventDestroy(e);
+  if (c->h_bf) (void)hipHostFree(c->h_bf);
   if (c->lm_zero) (void)hipFree(c->lm_zero);
   if (c->dm_work) (void)hipFree(c->dm_work);
   if (c->dm_work_n) (void)hipFree(c->dm_work_n);
@@ -1527,6 +1565,12 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   HIPCHK(hipSetDevice(c->device));
   std::memset(mid, 0, sizeof(*mid));
   hipStream_t s = c->s_trk;
+  release_parked_pair(c);  // (a previous begin that never saw its finish)
+  if (!c->h_bf) {
+    HIPCHK(hipHostMalloc(&c->h_bf, 2 * sizeof(MapState), hipHostMallocDefault));
+    for (auto& e : c->bf_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  c->bf_cur = (c->bf_res == 0) ? 1 : 0;  // the slot that does not hold an unfetched result
   wait_enqueued(om);
   wait_enqueued(nm);
   HIPCHK(hipStreamWaitEvent(s, om->ready, 0));
@@ -1534,15 +1578,44 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   int rc = rebvio_hip_build_distance_field(c, nm);
   if (rc) return rc;
   const hm::M3 R = prior_rotation(c, R_prior);
-  float RT[9];
-  hm::store3(hm::transpose(R), RT);
-  launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+  if (om->pre_rotated) {
+    // the previous pair's _finish_async applied this pair's first rotateKeylines (and binned the sigma histogram) inside its
+    // last kernel; it was told the same prior
+    if (std::memcmp(&om->pre_R, &R, sizeof(R)) != 0)
+      return fail_msg("track_pair_begin: R_prior (or the gyro state) differs from the R_prior_next the previous finish_async applied", -7);
+  } else {
+    float RT[9];
+    hm::store3(hm::transpose(R), RT);
+    launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+  }
   const float v0[3] = {0, 0, 0};
   PairSlot* slot = c->slot[0];
   rc = enqueue_pair_lm(c, om, nm, v0, slot);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipEventRecord(c->slot_ev[0], s));
+  static const bool park_pairs = std::getenv("REBVIO_HIP_PAIR_PRELAUNCH") && std::atoi(std::getenv("REBVIO_HIP_PAIR_PRELAUNCH")) != 0;
+  if (c->prelaunch_b && park_pairs) {
+    // OPT-IN (REBVIO_HIP_PAIR_PRELAUNCH=1): the second half is queued NOW, parked behind a wait on a pinned flag, and reads what
+    // the caller passes to _finish from memory at run time: no kernel launch sits between the caller's inertial fusion and the
+    // matching kernels (the streaming driver's scheme, see enqueue_a_chain). Only for hosts whose OTHER threads never
+    // synchronise with the track stream meanwhile: a thread inside hipStreamSynchronize on the parked stream (e.g. an edge-image
+    // callback reading a keyline mirror, rebvio_hip_map_download) and this thread enqueueing behind the wait block each
+    // other for good - observed with rebvio::Rebvio's two workers, which is why the default is off. What matters for the rate is
+    // _finish_async (the next pair's first half queued behind this pair's second half), which needs no parking.
+    constexpr int ks = rebvio_hip_ctx::kSlots - 1;
+    c->bf_seq = 0x80000000u | (++c->bf_counter & 0x7FFFFFFFu);
+    HIPCHK(hipStreamWaitValue32(s, c->glue_flag + ks, c->bf_seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
+    c->bf_parked = true;
+    launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_host[ks], c->glue_dev + ks, c->P.search_range, c->dm_work, c->dm_work_n);
+    const int gate = (int)c->P.global_min_matches_threshold;
+    launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + ks, gate > 0 ? gate : 0, c->dm_work_n, c->hist);
+    std::swap(nm->d.rs, nm->d.rs_tmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&c->h_bf[c->bf_cur], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->bf_done[c->bf_cur], s));
+  }
+  HIPCHK(hipEventSynchronize(c->slot_ev[0]));
   nm->n_host = slot->new_st.n;
   nm->thr_host = slot->new_st.threshold;
   lm_to_out(slot->lm, mid->Vg, mid->P_Vg, &mid->F, &mid->lm_accept_mask, &mid->sigma_rho_min);
@@ -1565,9 +1638,8 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   return 0;
 }
 
-int rebvio_hip_track_pair_finish(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float V[3], const float P_V[9],
-                                 const float Rgva[9], const float R_second[9], int* klm_num, int* kf_matches, int* reg_num,
-                                 int* status) {
+int rebvio_hip_track_pair_finish_async(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float V[3], const float P_V[9],
+                                       const float Rgva[9], const float R_second[9], const float* R_prior_next) {
   HIPCHK(hipSetDevice(c->device));
   GlueOut g;
   std::memcpy(g.V, V, sizeof(g.V));
@@ -1575,22 +1647,61 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_h
   std::memcpy(g.Rgva, Rgva, sizeof(g.Rgva));
   std::memcpy(g.R0a, R_second, sizeof(g.R0a));
   g.nan_v = std::isnan(V[0]) || std::isnan(V[1]) || std::isnan(V[2]);
+  if (!c->h_bf) return fail_msg("track_pair_finish without track_pair_begin", -7);
+  if (c->bf_res >= 0) return fail_msg("track_pair_finish_async: fetch the previous pair's result first (rebvio_hip_track_pair_result)", -7);
+  c->bf_nan[c->bf_cur] = g.nan_v;
+  c->bf_res = c->bf_cur;
+  if (c->bf_parked) {  // the second half is already queued (see _begin): hand it the fusion's results and let it go
+    GlueDev gl{};
+    rotate_inputs(c, g.V, g.P_V, g.Rgva, gl.vel_r, gl.Rvel_r);
+    std::memcpy(gl.Rgva, g.Rgva, sizeof(g.Rgva));
+    std::memcpy(gl.R0a, g.R0a, sizeof(g.R0a));
+    std::memcpy(gl.V, g.V, sizeof(g.V));
+    gl.nan_v = g.nan_v ? 1 : 0;
+    gl.has_next = 0;  // (the parked kernels were given their argument layout in _begin: no next rotation on this path)
+    write_glue_and_flag(c, rebvio_hip_ctx::kSlots - 1, c->bf_seq, gl);
+    c->bf_parked = false;
+    return 0;
+  }
+  float RT_next[9];
+  if (R_prior_next) {  // the next pair's first rotateKeylines rides in this pair's last kernel (rebvio.cpp:163-165 of that pair)
+    nm->pre_R = prior_rotation(c, R_prior_next);
+    hm::store3(hm::transpose(nm->pre_R), RT_next);
+  }
+  enqueue_b_chain(c, om, nm, g, R_prior_next ? RT_next : nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&c->h_bf[c->bf_cur], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
+  HIPCHK(hipEventRecord(c->bf_done[c->bf_cur], c->s_trk));
+  return 0;
+}
+
+int rebvio_hip_track_pair_result(rebvio_hip_ctx* c, int* klm_num, int* kf_matches, int* reg_num, int* status) {
+  HIPCHK(hipSetDevice(c->device));
   if (klm_num) *klm_num = 0;
   if (kf_matches) *kf_matches = 0;
   if (reg_num) *reg_num = 0;
-  enqueue_b_chain(c, om, nm, g, nullptr);
-  HIPCHK(hipGetLastError());
-  if (g.nan_v) {
+  if (c->bf_res < 0) return fail_msg("track_pair_result: no finished pair to report", -7);
+  const int r = c->bf_res;
+  c->bf_res = -1;
+  HIPCHK(hipEventSynchronize(c->bf_done[r]));
+  if (c->bf_nan[r]) {
     if (status) *status = 1;
     return 0;
   }
-  HIPCHK(hipMemcpyAsync(&c->h_st[1], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
-  if (klm_num) *klm_num = c->h_st[1].dm_matches;
-  if (kf_matches) *kf_matches = c->h_st[1].dm_kf;
-  if (reg_num) *reg_num = c->h_st[1].reg_count;
-  if (status) *status = ((unsigned)c->h_st[1].dm_matches < c->P.global_min_matches_threshold) ? 2 : 0;
+  const MapState& st = c->h_bf[r];
+  if (klm_num) *klm_num = st.dm_matches;
+  if (kf_matches) *kf_matches = st.dm_kf;
+  if (reg_num) *reg_num = st.reg_count;
+  if (status) *status = ((unsigned)st.dm_matches < c->P.global_min_matches_threshold) ? 2 : 0;
   return 0;
+}
+
+int rebvio_hip_track_pair_finish(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float V[3], const float P_V[9],
+                                 const float Rgva[9], const float R_second[9], int* klm_num, int* kf_matches, int* reg_num,
+                                 int* status) {
+  const int rc = rebvio_hip_track_pair_finish_async(c, om, nm, V, P_V, Rgva, R_second, nullptr);
+  if (rc) return rc;
+  return rebvio_hip_track_pair_result(c, klm_num, kf_matches, reg_num, status);
 }
 
 namespace {

@@ -2,12 +2,14 @@
 // (rebvio.cpp:17-313): the caller thread converts/undistorts and queues images; worker 1 detects edges and attaches the
 // pre-integrated IMU data; worker 2 runs one tracking step per frame pair and publishes odometry.
 //
-// The frame-pair step is TWO calls into the backend with the O(1) inertial fusion between them:
+// The frame-pair step is calls into the backend with the O(1) inertial fusion between them (and the previous pair's
+// counters fetched while this pair's first half is already queued behind that pair's second half, so that the GPU goes from
+// one pair to the next without waiting for the host):
 //   rebvio_hip_track_pair_begin  - distance field, rotate by the gyro prior, minimizeVel, forwardMatch, extRotVel,
 //                                  gyroBiasCorrection (rebvio.cpp:142-192)
 //   host                         - Ls4 / mean acceleration, Core::estimateBias + SABEstimator, second rotation
 //                                  (rebvio.cpp:195-233)
-//   rebvio_hip_track_pair_finish - rotate, directedMatch, regularize, depth EKF (rebvio.cpp:222-259)
+//   rebvio_hip_track_pair_finish_async / _result - rotate, directedMatch, regularize, depth EKF (rebvio.cpp:222-259)
 // followed by the gravity-aligned pose integration (rebvio.cpp:263-271). The reference's latent races (unlocked queue
 // peeks, plain-bool run flag) are not inherited.
 #include "rebvio/rebvio.hpp"
@@ -75,7 +77,7 @@ void Rebvio::registerOdometryCallback(std::function<void(rebvio::types::Odometry
 void Rebvio::waitIdle() {
   while (run_) {
     const unsigned imgs = num_images_;
-    if (num_detected_ >= imgs && (imgs < 2 || num_frames_ + 1 >= imgs)) return;
+    if (num_detected_ >= imgs && (imgs < 2 || num_published_ + 1 >= imgs)) return;
     std::this_thread::sleep_for(std::chrono::milliseconds(1));
   }
 }
@@ -108,7 +110,15 @@ void Rebvio::dataAcquisitionProcess() {
       if (queued < 8 || !run_) break;
       std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
+    static const bool acq_timers = std::getenv("REBVIO_HOST_TIMERS") != nullptr;
+    const auto td0 = std::chrono::steady_clock::now();
     rebvio::EdgeMap::SharedPtr edge_map = edge_detector_.detect(img);
+    if (acq_timers) {
+      static double acc_us = 0;
+      static unsigned acc_n = 0;
+      acc_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td0).count();
+      if (++acc_n % 2000 == 0) std::fprintf(stderr, "[Rebvio] EdgeDetector::detect (staging + enqueue) %.1f us per frame on the acquisition thread\n", acc_us / acc_n);
+    }
     if (!edge_image_callbacks_.empty()) {
       // callbacks see the undistorted frame, as in the reference; for a raw u8 frame of a distorting lens it is fetched
       // from the device front end (only when somebody listens)
@@ -131,7 +141,7 @@ void Rebvio::dataAcquisitionProcess() {
     }
     {
       std::lock_guard<std::mutex> guard(edge_map_buffer_mutex_);
-      edge_map_buffer_.push(edge_map);
+      edge_map_buffer_.push_back(edge_map);
     }
     ++num_detected_;
   }
@@ -186,17 +196,56 @@ void Rebvio::stateEstimationProcess() {
       for (int j = 0; j < 3; ++j) p[i * 3 + j] = m(i, j);
   };
 
+  // The odometry of a pair is complete once its second half has reported its match count (rebvio.cpp:245-252). That is
+  // fetched AFTER the next pair's first half has been queued, so the record waits here for one loop turn (or until the
+  // input runs dry). Returns false when the pair ended the run (minimization error / too few matches).
+  struct Pending {
+    bool have = false;
+    types::Odometry odometry;
+    rebvio::EdgeMap::SharedPtr old_map, new_map;
+  } pending;
+  auto complete_pending = [&]() -> bool {
+    if (!pending.have) return true;
+    pending.have = false;
+    int klm_num = 0, kf_matches = 0, reg_num = 0, status = 0;
+    backend::check("rebvio_hip_track_pair_result", rebvio_hip_track_pair_result(ctx, &klm_num, &kf_matches, &reg_num, &status));
+    pending.old_map->invalidateMirror();
+    pending.new_map->invalidateMirror();
+    bool ok = true;
+    if (status == 1) {  // rebvio.cpp:236-241
+      P_Kp = FMAX;
+      std::cerr << "Minimization Error occured!\n";
+      run_ = false;
+      ok = false;
+    } else if (status == 2) {  // rebvio.cpp:247-252
+      P_Kp = FMAX;
+      std::cerr << "Insufficient number of keylines matches!\n";
+      run_ = false;
+      ok = false;
+    }
+    pending.odometry.klm_num = klm_num;
+    for (auto& cb : odometry_callbacks_) cb(pending.odometry);
+    pending.old_map.reset();
+    pending.new_map.reset();
+    ++num_published_;
+    return ok;
+  };
+
   while (run_) {
     rebvio::EdgeMap::SharedPtr new_edge_map, old_edge_map;
     {
       std::lock_guard<std::mutex> guard(edge_map_buffer_mutex_);
       if (edge_map_buffer_.size() >= 2) {
         old_edge_map = edge_map_buffer_.front();
-        edge_map_buffer_.pop();
+        edge_map_buffer_.pop_front();
         new_edge_map = edge_map_buffer_.front();
       }
     }
     if (!new_edge_map) {
+      if (pending.have) {  // nothing to overlap with: finish the last pair now
+        complete_pending();
+        continue;
+      }
       std::this_thread::sleep_for(std::chrono::microseconds(200));
       continue;
     }
@@ -235,6 +284,14 @@ void Rebvio::stateEstimationProcess() {
     timers.start();
     backend::check("rebvio_hip_track_pair_begin",
                    rebvio_hip_track_pair_begin(ctx, old_edge_map->handle(), new_edge_map->handle(), Rp, frame_dt, &mid));
+    // this pair's first half (and its parked second half) are queued behind the previous pair's second half: now that pair's
+    // counters can be fetched without leaving the GPU idle
+    if (!complete_pending()) {
+      const float nanv[3] = {std::numeric_limits<float>::quiet_NaN(), 0.f, 0.f}, I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      int st = 0;  // the run has ended: let this pair's parked second half fall through
+      (void)rebvio_hip_track_pair_finish(ctx, old_edge_map->handle(), new_edge_map->handle(), nanv, I9, I9, I9, nullptr, nullptr, nullptr, &st);
+      break;
+    }
     {
       float bg[3], wb[9];
       rebvio_hip_get_gyro_state(ctx, bg, wb);
@@ -303,22 +360,23 @@ void Rebvio::stateEstimationProcess() {
     store3(P_V, pv);
     store3(Rgva, rg);
     store3(R_second, r2);
-    int klm_num = 0, kf_matches = 0, reg_num = 0, status = 0;
     timers.lap(1);
-    backend::check("rebvio_hip_track_pair_finish", rebvio_hip_track_pair_finish(ctx, old_edge_map->handle(), new_edge_map->handle(), V,
-                                                                                pv, rg, r2, &klm_num, &kf_matches, &reg_num, &status));
-    timers.lap(2);
-    old_edge_map->invalidateMirror();
-    new_edge_map->invalidateMirror();
-    if (status == 1) {  // rebvio.cpp:236-241
-      P_Kp = FMAX;
-      std::cerr << "Minimization Error occured!\n";
-      run_ = false;
-    } else if (status == 2) {  // rebvio.cpp:247-252
-      P_Kp = FMAX;
-      std::cerr << "Insufficient number of keylines matches!\n";
-      run_ = false;
+    // If the following frame is already queued, its gyro pre-integration (complete before the map was queued) is the next
+    // pair's prior: that pair's first rotateKeylines then rides in this pair's last kernel. Only once the gyro bias is
+    // initialised (until then the bias still changes between pairs, rebvio.cpp:146-160).
+    float Rnext[9];
+    bool have_next = false;
+    if (imu_state_.initialized) {
+      std::lock_guard<std::mutex> guard(edge_map_buffer_mutex_);
+      if (edge_map_buffer_.size() >= 2) {
+        store3(edge_map_buffer_[1]->imu().R(), Rnext);
+        have_next = true;
+      }
     }
+    backend::check("rebvio_hip_track_pair_finish_async",
+                   rebvio_hip_track_pair_finish_async(ctx, old_edge_map->handle(), new_edge_map->handle(), V, pv, rg, r2,
+                                                      have_next ? Rnext : nullptr));
+    timers.lap(2);
 
     // gravity-aligned pose integration (rebvio.cpp:263-271)
     if (num_frames_ > 4u + (unsigned)config_.imu_state.init_bias_frame_num) {
@@ -338,12 +396,15 @@ void Rebvio::stateEstimationProcess() {
     odometry.scale = K;
     odometry.gravity = sab_state_.g_est;
     odometry.gyro_bias = imu_state_.Bg;
-    odometry.klm_num = klm_num;
-    for (auto& cb : odometry_callbacks_) cb(odometry);
+    pending.have = true;  // published by complete_pending() once the match count is in
+    pending.odometry = odometry;
+    pending.old_map = old_edge_map;
+    pending.new_map = new_edge_map;
     timers.lap(3);
     timers.n++;
     ++num_frames_;
   }
+  complete_pending();
 }
 
 }  // namespace rebvio

@@ -155,6 +155,42 @@ void sym_pinv_solve_d(const double* A_, const double* b_, double* x_) {
     for (int i = 0; i < N; ++i) x_[i] += V[i][k] * proj;
   }
 }
+// h = pinv(A) b as SVD<7>::backsub gives it (sab_estimator.cpp:31-32). For a well-conditioned symmetric positive definite A
+// the pseudo-inverse is the inverse: LDL^T in double (~200 flops); when a pivot falls below the 1e9 condition cut relative
+// to the largest diagonal entry, the Jacobi pseudo-inverse (minimum-norm solution, like the SVD) takes over.
+template <int N>
+void sym_solve_d(const double* A_, const double* b_, double* x_) {
+  double L[N][N], d[N], dmax = 0;
+  bool ok = true;
+  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(A_[i * N + i]));
+  for (int j = 0; j < N && ok; ++j) {
+    double v = A_[j * N + j];
+    for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * d[k];
+    if (!(v * 1e7 > dmax)) ok = false;
+    d[j] = v;
+    for (int i = j + 1; i < N && ok; ++i) {
+      double s = 0.5 * (A_[i * N + j] + A_[j * N + i]);
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k] * d[k];
+      L[i][j] = s / v;
+    }
+  }
+  if (!ok) {
+    sym_pinv_solve_d<N>(A_, b_, x_);
+    return;
+  }
+  double y[N];
+  for (int i = 0; i < N; ++i) {
+    double s = b_[i];
+    for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+    y[i] = s;
+  }
+  for (int i = 0; i < N; ++i) y[i] /= d[i];
+  for (int i = N - 1; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < N; ++k) s -= L[k][i] * x_[k];
+    x_[i] = s;
+  }
+}
 inline float saturate(float t, float limit) { return (t > limit) ? limit : ((t < -limit) ? -limit : t); }
 }  // namespace
 
@@ -222,9 +258,14 @@ bool SABEstimator::problem(rebvio::types::Matrix7f& JtJ_, rebvio::types::Vector7
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) W.a[i][j] = Wz.a[i][j];
   W.a[3][3] = 1.0 / cfg.Rg;
-  const Mx<7, 7> Wp = chol_inverse<7>(Pp);
+  if (!Wp_valid_) {  // Cholesky<7>(Pp).get_inverse() does not depend on X: once per estimator, not once per iteration
+    const Mx<7, 7> Wp = chol_inverse<7>(Pp);
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) Wp_(i, j) = Wp.a[i][j];
+    Wp_valid_ = true;
+  }
   for (int i = 0; i < 7; ++i)
-    for (int j = 0; j < 7; ++j) W.a[4 + i][4 + j] = Wp.a[i][j];
+    for (int j = 0; j < 7; ++j) W.a[4 + i][4 + j] = Wp_(i, j);
   // dP/da is non-zero in the 3x3 measurement block only, so dW/da = -W dP/da W and dW/da P dW/da live there too: the
   // products are formed on the 3x3 blocks (the dense 11x11 products add exact zeros to the same terms)
   Mx<3, 3> dPz;
@@ -279,10 +320,22 @@ int SABEstimator::gaussNewton(rebvio::types::Vector7f& X, int iter_max, types::F
       b[r] = -(double)JtF[r];
       for (int c = 0; c < 7; ++c) A[r * 7 + c] = (double)JtJ(r, c);
     }
-    sym_pinv_solve_d<7>(A, b, h);
-    for (int r = 0; r < 7; ++r) X[r] = (float)((double)X[r] + h[r]);
-    X[0] = std::atan2(std::sin(X[0]), std::cos(X[0]));
-    for (int r = 4; r < 7; ++r) X[r] = saturate(X[r], 5e-1 / 25);
+    sym_solve_d<7>(A, b, h);
+    float Xn[7];
+    for (int r = 0; r < 7; ++r) Xn[r] = (float)((double)X[r] + h[r]);
+    Xn[0] = std::atan2(std::sin(Xn[0]), std::cos(Xn[0]));
+    for (int r = 4; r < 7; ++r) Xn[r] = saturate(Xn[r], 5e-1 / 25);
+    bool moved = false;
+    for (int r = 0; r < 7; ++r) {
+      moved = moved || !(Xn[r] == X[r]);
+      X[r] = Xn[r];
+    }
+    if (!moved && a_tol <= 0 && r_tol <= 0) {
+      // fixed point in fp32: every further iteration would evaluate the same problem at the same X and leave it where it is,
+      // so running them (the reference does: its default tolerances are zero) cannot change the result
+      i = iter_max;
+      break;
+    }
     double nh = 0;
     for (int r = 0; r < 7; ++r) nh += h[r] * h[r];
     nh = std::sqrt(nh);
