@@ -2082,6 +2082,11 @@ struct rebvio_hip_batch {
   MapDev* maptab_dev = nullptr;
   hipEvent_t ev_scan[2]{}, ev_flag[2]{};
   bool ev_flag_used[2] = {false, false};
+  // second scan stream: with >= 4 lanes the scale space of the upper half of the lanes runs beside that of the lower half
+  // (a lane's seven scan kernels depend on each other only; two half-sized chains overlap where one full-sized chain cannot)
+  hipStream_t s_det2{};
+  hipEvent_t ev_scan2[2]{};
+  int split = 0;  // lanes on the first scan stream (0: one stream)
   static constexpr int kReadyRing = 16;
   hipEvent_t ev_ready[kReadyRing]{};  // keylines + distance fields of a step finished (keyline stream)
   hipEvent_t slot_ev[rebvio_hip_ctx::kSlots]{};
@@ -2245,9 +2250,16 @@ int batch_glue_current(rebvio_hip_batch* b, rebvio_hip_pair_out* completed, int*
 int batch_detect_launch(rebvio_hip_batch* b, const rebvio_hip_batch::DetStep& j) {
   const int B = b->B, par = j.par;
   if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->st.s_det, b->ev_flag[par], 0));
-  launch_scale_space_b(b->st.s_det, b->K, B, b->ls_dev, j.dyn, b->lane[0]->widths);
+  const int n0 = b->split > 0 ? b->split : B;
+  launch_scale_space_b(b->st.s_det, b->K, 0, n0, b->ls_dev, j.dyn, b->lane[0]->widths);
   HIPCHK(hipEventRecord(b->ev_scan[par], b->st.s_det));
   HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan[par], 0));
+  if (n0 < B) {
+    if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->s_det2, b->ev_flag[par], 0));
+    launch_scale_space_b(b->s_det2, b->K, n0, B - n0, b->ls_dev, j.dyn, b->lane[0]->widths);
+    HIPCHK(hipEventRecord(b->ev_scan2[par], b->s_det2));
+    HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan2[par], 0));
+  }
   if (j.reuse_done) HIPCHK(hipStreamWaitEvent(b->st.s_key, j.reuse_done, 0));
   launch_keylines_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
   HIPCHK(hipGetLastError());
@@ -2360,6 +2372,9 @@ void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
   for (auto& e : b->slot_ev)
     if (e) (void)hipEventDestroy(e);
   if (b->glue_flag) (void)hipHostFree(b->glue_flag);
+  for (auto& ev : b->ev_scan2)
+    if (ev) (void)hipEventDestroy(ev);
+  if (b->s_det2) (void)hipStreamDestroy(b->s_det2);
   if (b->st.s_det) (void)hipStreamDestroy(b->st.s_det);
   if (b->st.s_key) (void)hipStreamDestroy(b->st.s_key);
   if (b->st.s_trk) (void)hipStreamDestroy(b->st.s_trk);
@@ -2442,6 +2457,15 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   }
   for (auto& e : b->ev_ready) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : b->slot_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  {
+    const char* e = std::getenv("REBVIO_HIP_BATCH_SPLIT");  // 1: two scan streams (lower / upper half of the lanes); default one
+    const bool want = e ? std::atoi(e) != 0 : false;  // measured at 4 and 8 lanes: no gain (the chip, not the chain, is the limit there)
+    if (want && lanes >= 2) {
+      b->split = (lanes + 1) / 2;
+      HIPCHK(hipStreamCreateWithFlags(&b->s_det2, hipStreamNonBlocking));
+      for (auto& ev : b->ev_scan2) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+  }
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_LEAD")) b->lead = std::min(8, std::max(3, std::atoi(e)));
   HIPCHK(hipHostMalloc(&b->glue_flag, 64, hipHostMallocDefault));
   std::memset(b->glue_flag, 0, 64);
@@ -2602,6 +2626,7 @@ int rebvio_hip_batch_flush(rebvio_hip_batch* b) {
     for (size_t l = 0; l < f.m.size(); ++l) batch_release_map(f.m[l], l + 1 == f.m.size());
   b->frames.clear();
   HIPCHK(hipStreamSynchronize(b->st.s_det));
+  if (b->s_det2) HIPCHK(hipStreamSynchronize(b->s_det2));
   HIPCHK(hipStreamSynchronize(b->st.s_key));
   HIPCHK(hipStreamSynchronize(b->st.s_trk));
   return 0;

@@ -292,7 +292,8 @@ __host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int l
   }
   return m;
 }
-void launch_scale_space_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const LaneDynB& dyn, const int widths[2][3]);
+void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
+                          const int widths[2][3]);
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls);

@@ -259,10 +259,11 @@ __global__ __launch_bounds__(256) void k_rowscan(const void* __restrict__ src0, 
 }
 // batched form (lane = blockIdx.z). stage 0: the lane's u8 frame -> a[0]; 1: a[0] -> b[0], b[1]; 2: b[0], b[1] -> a[0], a[1]
 template <int MODE>
-__global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int stage, int R, int Cimg, int d0,
-                                                   int d1, int ldw) {
-  const LaneStatic& L = ls[blockIdx.z];
-  const void* s0 = stage == 0 ? dyn.v[blockIdx.z].img : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[0]);
+__global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int lane0, int stage, int R, int Cimg,
+                                                   int d0, int d1, int ldw) {
+  const int lane = lane0 + blockIdx.z;
+  const LaneStatic& L = ls[lane];
+  const void* s0 = stage == 0 ? dyn.v[lane].img : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[0]);
   const void* s1 = stage == 0 ? s0 : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[1]);
   float* o0 = stage == 1 ? L.sb[0] : L.sa[0];
   float* o1 = stage == 0 ? L.sa[0] : (stage == 1 ? L.sb[1] : L.sa[1]);
@@ -385,8 +386,8 @@ __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float
   colscan_body(buf0, buf1, R, C, ldh);
 }
 // batched form. which 0: a[0] alone; 1: b[0], b[1]; 2: a[0], a[1]
-__global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int which, int R, int C, int ldh) {
-  const LaneStatic& L = ls[blockIdx.z];
+__global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh) {
+  const LaneStatic& L = ls[lane0 + blockIdx.z];
   colscan_body(which == 1 ? L.sb[0] : L.sa[0], which == 0 ? L.sa[0] : (which == 1 ? L.sb[1] : L.sa[1]), R, C, ldh);
 }
 
@@ -428,9 +429,9 @@ __global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, 
                                                  float* __restrict__ scale1, int R, int C, int* __restrict__ rowcount) {
   dog_mag_body(II0, II1, d0, d1, dog, mag, scale0, scale1, R, C, rowcount);
 }
-__global__ __launch_bounds__(256) void k_dog_mag_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int d0, int d1, int R, int C) {
-  const LaneStatic& L = ls[blockIdx.z];
-  const int b = dyn.v[blockIdx.z].parity;
+__global__ __launch_bounds__(256) void k_dog_mag_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int lane0, int d0, int d1, int R, int C) {
+  const LaneStatic& L = ls[lane0 + blockIdx.z];
+  const int b = dyn.v[lane0 + blockIdx.z].parity;
   dog_mag_body(L.sa[0], L.sa[1], d0, d1, L.dog2[b], L.mag2[b], nullptr, nullptr, R, C, L.rowcount2[b]);
 }
 
@@ -1322,7 +1323,8 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
 }
 
 // ---- batched launchers (lane = blockIdx.z): the same grids with a third dimension ------------------------------------------
-void launch_scale_space_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const LaneDynB& dyn, const int widths[2][3]) {
+void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
+                          const int widths[2][3]) {
   const int R = p.rows, C = p.cols;
   const int Cp = (C + 3) & ~3;
   const int ldw = lds_pitch(Cp);
@@ -1339,13 +1341,13 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lanes, const Lane
   const unsigned z = (unsigned)lanes;
   const dim3 g1(div_up(R, kStrip), 1, z), g2(div_up(R, kStrip), 2, z);
   const dim3 c1(div_up(Cp, kColStrip), 1, z), c2(div_up(Cp, kColStrip), 2, z);
-  RH_LAUNCH(k_rowscan_b<0>, g1, dim3(256), shm, s, ls, dyn, 0, R, C, 0, 0, ldw);
-  RH_LAUNCH(k_colscan_b, c1, dim3(256), cshm, s, ls, 0, R, Cp, ldh);
-  RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, 1, R, C, widths[0][0], widths[1][0], ldw);
-  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, 1, R, Cp, ldh);
-  RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, 2, R, C, widths[0][1], widths[1][1], ldw);
-  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, 2, R, Cp, ldh);
-  RH_LAUNCH(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 4), z), dim3(64, 4), 0, s, ls, dyn, widths[0][2], widths[1][2], R, C);
+  RH_LAUNCH(k_rowscan_b<0>, g1, dim3(256), shm, s, ls, dyn, lane0, 0, R, C, 0, 0, ldw);
+  RH_LAUNCH(k_colscan_b, c1, dim3(256), cshm, s, ls, lane0, 0, R, Cp, ldh);
+  RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 1, R, C, widths[0][0], widths[1][0], ldw);
+  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, lane0, 1, R, Cp, ldh);
+  RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 2, R, C, widths[0][1], widths[1][1], ldw);
+  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, lane0, 2, R, Cp, ldh);
+  RH_LAUNCH(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 4), z), dim3(64, 4), 0, s, ls, dyn, lane0, widths[0][2], widths[1][2], R, C);
 }
 
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn) {

@@ -10,6 +10,7 @@
 // no dense contraction exists on this path (largest product is 6x6), so MFMA does not apply.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace rh {
@@ -750,11 +751,16 @@ __device__ __forceinline__ void xch_publish(unsigned long long* w, unsigned tag,
   __hip_atomic_store(w, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float xch_wait(const unsigned long long* w, unsigned tag, int* err) {
+// g_poll_sleep_long (set per launch through a kernel argument copied to a register): batched launches run several lanes'
+// workgroups at once and every polling thread is an L2 request per poll - they back off longer between polls.
+__device__ __forceinline__ float xch_wait(const unsigned long long* w, unsigned tag, int* err, int slow = 0) {
   unsigned spins = 0;
   unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while ((unsigned)(v >> 32) != tag) {
-    __builtin_amdgcn_s_sleep(1);
+    if (slow)
+      __builtin_amdgcn_s_sleep(12);
+    else
+      __builtin_amdgcn_s_sleep(1);
     if (++spins > kXchSpinLimit) {
       // err[0] = flag, err[1..7] = diagnostics of the first waiter that gave up (host-visible pinned memory)
       if (__hip_atomic_exchange(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
@@ -776,11 +782,11 @@ __device__ __forceinline__ float xch_wait(const unsigned long long* w, unsigned 
 // Wait for the records every live group published for evaluation `tag`, stage them in LDS and reduce them.
 template <int kChainThreads>
 __device__ __forceinline__ void chain_collect_records(const unsigned long long* __restrict__ slot_words, unsigned tag, int nblocks,
-                                                      float* rec, float* red, float* carry_in, int* err) {
+                                                      float* rec, float* red, float* carry_in, int* err, int slow = 0) {
   constexpr int kChainGroups = kChainThreads / 256;
   const int total = min(nblocks, kMaxRecBlocks) * kPartStride;
   for (int i = threadIdx.x; i < total; i += kChainThreads)
-    if ((i & (kPartStride - 1)) < 12) rec[i] = xch_wait(slot_words + i, tag, err);
+    if ((i & (kPartStride - 1)) < 12) rec[i] = xch_wait(slot_words + i, tag, err, slow);
   __syncthreads();
   reduce_staged_records(rec, nblocks, red, carry_in, (int)blockIdx.x * kChainGroups, kChainGroups);
   __syncthreads();
@@ -793,7 +799,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
                                                             int* __restrict__ bar_err, const int* __restrict__ hist,
                                                             unsigned frame_count, float* __restrict__ xrv_part,
                                                             PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
-                                                            unsigned long long* __restrict__ stamps) {
+                                                            unsigned long long* __restrict__ stamps, int slow_poll = 0) {
   constexpr int kChainGroups = kChainThreads / 256;
   // optional phase stamps of workgroup 0 (REBVIO_HIP_LM_STAMPS diagnostic): 100 MHz constant clock
 #define RH_STAMP(i) \
@@ -850,7 +856,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
     RH_STAMP(1 + call * 6 + 0);
     if (call >= 1) {
       chain_collect_records<kChainThreads>(xch + (size_t)((call - 1) & 1) * nrec_launched * kPartStride, tag_base + (unsigned)call, nblocks,
-                                           rec, red, carry_in, bar_err);
+                                           rec, red, carry_in, bar_err, slow_poll);
       RH_STAMP(1 + call * 6 + 1);
       if (tid == 0) lm_step(s, red, call, false);
       __syncthreads();
@@ -939,7 +945,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   // final accept / reject of minimizeVel (core.cpp:166-185 for the last evaluation)
   if (lm_live && calls > 0) {
     chain_collect_records<kChainThreads>(xch + (size_t)((calls - 1) & 1) * nrec_launched * kPartStride, tag_base + (unsigned)calls, nblocks,
-                                         rec, red, carry_in, bar_err);
+                                         rec, red, carry_in, bar_err, slow_poll);
     if (tid == 0) lm_step(s, red, calls, true);
     __syncthreads();
   }
@@ -1010,12 +1016,13 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
 // batched form (lane = blockIdx.z): every lane's workgroups exchange records among themselves through the lane's own words
 template <int kChainThreads>
 __global__ __launch_bounds__(kChainThreads) void k_lm_chain_b(KParams p, const LaneStatic* __restrict__ ls,
-                                                              const MapDev* __restrict__ maptab, LaneDynB dyn, int calls) {
+                                                              const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
   PairSlot* slot = L.slot[d.slot];
   lm_chain_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls, 1,
-                               L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, slot->xrv, slot, L.hist, nullptr);
+                               L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, slot->xrv, slot, L.hist, nullptr,
+                               slow_poll);
 }
 
 // ---- EdgeMap::directedMatch / searchMatch (edge_map.cpp:101-218) ----------------------------------------------
@@ -1959,7 +1966,9 @@ void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m,
 void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls) {
   // 512-thread workgroups (the single-stream default); lanes x 30 workgroups at 16k keylines must all be resident: with one
   // workgroup per CU that holds up to 8 lanes on 256 CUs
-  RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls);
+  static const int slow = std::getenv("REBVIO_HIP_BATCH_POLL") ? std::atoi(std::getenv("REBVIO_HIP_BATCH_POLL")) : -1;
+  const int slow_poll = slow >= 0 ? slow : (lanes >= 3 ? 1 : 0);
+  RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll);
 }
 
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
