@@ -69,9 +69,10 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_keyline_emit": 4 * P + 116 * N,  # dense mask + SoA keylines (the tiled distance field needs no clearing pass)
         "k_front_end_u8": 13 * P,           # u8 gather + 8-byte map in, fp32 frame out
         "k_regularize_ekf": 108 * N,
-        "k_join_edges": 40 * N,
+        "k_join_edges": 40 * N + 8 * N + 130 * N,  # chaining + unit gradient + ~4.07 tile-list entries of 32 B per keyline
         "k_df_build": 340 * N,            # scatter variant: 80 cells x 4 B atomics + 20 B keyline
-        "k_df_tiles": 8 * P + 20 * N,     # tiled variant: mask read once + field written once + keyline geometry
+        "k_df_tiles": 8 * P + 20 * N,     # mask-driven variant (REBVIO_HIP_DF=tiles): mask read once + field written once + geometry
+        "k_df_lists": 4 * P + 130 * N,    # keyline-driven default: field written once + ~4.07 list entries of 32 B per keyline
         "k_rotate": 52 * N,
         "k_try_vel": 68 * N,
         # persistent minimizeVel + forwardMatch + extRotVel: the traffic of the launches it replaces
@@ -84,7 +85,7 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_regularize": 60 * N,
         "k_depth_ekf": 48 * N,
     }
-    base = kernel.split("<")[0] if kernel.startswith(("k_lm_chain", "k_df_tiles")) else kernel
+    base = kernel.split("<")[0] if kernel.startswith(("k_lm_chain", "k_df_tiles", "k_df_lists")) else kernel
     return float(table.get(base, 0))
 
 
