@@ -1204,7 +1204,7 @@ __device__ __forceinline__ DmArgs dm_args(const GlueDev* __restrict__ gd, const 
   return a;
 }
 
-__global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+__device__ __forceinline__ void directed_match_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
                                                         GlueDev* __restrict__ gd_copy) {
@@ -1307,6 +1307,22 @@ __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, Ma
     if (b_found) atomicAdd(&nm.st->dm_matches, b_found);
     if (b_kf) atomicAdd(&nm.st->dm_kf, b_kf);
   }
+}
+
+__global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+                                                        float max_radius, int* __restrict__ work, int* __restrict__ work_n,
+                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
+                                                        GlueDev* __restrict__ gd_copy) {
+  directed_match_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd, gd_copy);
+}
+__global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
+                                                          LaneDynB dyn, float max_radius) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  const Vec3 z3{};
+  const Mat3 z9{};
+  directed_match_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
+                      L.dm_work, L.dm_work_n, 1, z9, L.glue_host[d.slot], L.glue_dev + d.slot);
 }
 
 // Pass 1, wide form: EIGHT lanes per keyline of the NEW map, one per probe slot of the head (2 * kHeadSteps == 8). The
@@ -1974,7 +1990,17 @@ void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneSta
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
                       float max_radius, int gate) {
   const unsigned z = (unsigned)lanes;
-  RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
+  // head form: eight lanes per keyline is the low-latency form while the chip is mostly idle; from a few lanes on the chip is
+  // full and the thread-per-keyline form (an eighth of the waves) is the cheaper one (REBVIO_HIP_BATCH_DM_HEAD=wide|thread)
+  static const int env = [] {
+    const char* e = std::getenv("REBVIO_HIP_BATCH_DM_HEAD");
+    return (e && std::strcmp(e, "thread") == 0) ? 1 : ((e && std::strcmp(e, "wide") == 0) ? 2 : 0);
+  }();
+  const bool wide = env ? env == 2 : lanes < 4;
+  if (wide)
+    RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
+  else
+    RH_LAUNCH(k_directed_match_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   RH_LAUNCH(k_directed_match_tail_b, dim3(dm_tail_blocks(p.kmax), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
 }
