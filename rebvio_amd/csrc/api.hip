@@ -212,10 +212,12 @@ struct rebvio_hip_ctx {
   // persistent LM kernel: record exchange words, tags consumed so far, sticky time-out flag
   unsigned long long* lm_xch = nullptr;
   unsigned lm_tag_base = 0;
+  bool lm_spec = true;
   int* lm_bar_err = nullptr;  // pinned, zero-copy
   unsigned long long* lm_stamps = nullptr;  // pinned; REBVIO_HIP_LM_STAMPS diagnostic (phase stamps of workgroup 0)
   double lm_stamp_acc[64]{};
   uint64_t lm_stamp_n = 0;
+  bool lm_stamp_spec = false;
   bool lm_persistent = true;
   rebvio_hip_map* df_map = nullptr;
   // pinned host staging
@@ -628,21 +630,24 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
   if (c->lm_stamps && c->lm_stamps[0]) {  // stamps of the previous launch (the caller has synchronised on its slot since)
     // the buffer may be half rewritten by a launch that is already running (streaming driver): take a snapshot and use it
     // only if it is monotonic and spans less than a millisecond
-    const int ns = 3 + calls * 6;
+    const bool spec = c->lm_stamps[0] == 1ull;  // k_lm_chain_spec: stamps 1..9, [0] is a marker
+    const int i0 = spec ? 1 : 0;
+    const int ns = spec ? 10 : 3 + calls * 6;
     unsigned long long snap[64];
     for (int i = 0; i < ns; ++i) snap[i] = c->lm_stamps[i];
-    bool sane = snap[ns - 1] > snap[0] && snap[ns - 1] - snap[0] < 100000ull;
-    for (int i = 1; i < ns && sane; ++i) sane = snap[i] >= snap[i - 1];
+    bool sane = snap[ns - 1] > snap[i0] && snap[ns - 1] - snap[i0] < 100000ull;
+    for (int i = i0 + 1; i < ns && sane; ++i) sane = snap[i] >= snap[i - 1];
     if (sane) {
-      for (int i = 1; i < ns; ++i) c->lm_stamp_acc[i] += (double)(snap[i] - snap[i - 1]) * 0.01;
+      for (int i = i0 + 1; i < ns; ++i) c->lm_stamp_acc[i] += (double)(snap[i] - snap[i - 1]) * 0.01;
       c->lm_stamp_n++;
+      c->lm_stamp_spec = spec;
     }
   }
-  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
+  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, c->lm_spec ? 2 : 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
                   slot->xrv, slot, c->hist, c->lm_stamps);
-  c->lm_tag_base += (unsigned)calls + 1u;
+  c->lm_tag_base += 2u * ((unsigned)calls + 1u);  // (the speculative kernel numbers repeated evaluations in a second range)
   if (c->lm_tag_base > 0xFFFFFF00u) {  // tags must stay unique and non-zero: restart the sequence on clean exchange words
-    (void)hipMemsetAsync(c->lm_xch, 0, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long), c->s_trk);
+    (void)hipMemsetAsync(c->lm_xch, 0, lm_xch_words(c->maxblocks) * sizeof(unsigned long long), c->s_trk);
     c->lm_tag_base = 0;
   }
   return 0;
@@ -846,15 +851,20 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
 
   c->maxblocks = div_up(p->keylines_max, 1024) * 4;  // record groups of 256 keylines, padded to whole 1024-thread workgroups
   // [2 parity slots][record groups][kPartStride] + the final-velocity broadcast words
-  HIPCHK(hipMalloc(&c->lm_xch, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(c->lm_xch, 0, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long)));  // tag 0 = never published
+  HIPCHK(hipMalloc(&c->lm_xch, lm_xch_words(c->maxblocks) * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(c->lm_xch, 0, lm_xch_words(c->maxblocks) * sizeof(unsigned long long)));  // tag 0 = never published
   HIPCHK(hipHostMalloc(&c->lm_bar_err, 8 * sizeof(int), hipHostMallocDefault));
   std::memset(c->lm_bar_err, 0, 8 * sizeof(int));
   if (std::getenv("REBVIO_HIP_LM_STAMPS")) {
     HIPCHK(hipHostMalloc(&c->lm_stamps, 64 * sizeof(unsigned long long), hipHostMallocDefault));
     std::memset(c->lm_stamps, 0, 64 * sizeof(unsigned long long));
   }
-  if (const char* e = std::getenv("REBVIO_HIP_LM")) c->lm_persistent = std::strcmp(e, "percall") != 0;
+  // REBVIO_HIP_LM = percall (one kernel per evaluation) | seq (persistent kernel, one evaluation per exchange round) |
+  // anything else / unset: persistent kernel with the speculative reject chain (track.hip, k_lm_chain_spec)
+  if (const char* e = std::getenv("REBVIO_HIP_LM")) {
+    c->lm_persistent = std::strcmp(e, "percall") != 0;
+    c->lm_spec = std::strcmp(e, "seq") != 0;
+  }
   HIPCHK(hipMalloc(&c->lm, 16 * sizeof(LmState)));
   HIPCHK(hipMemset(c->lm, 0, 16 * sizeof(LmState)));
   HIPCHK(hipMalloc(&c->part, (size_t)(kMaxLmCalls + 1) * part_call_stride(c) * sizeof(float)));
@@ -1949,7 +1959,14 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
 
 int rebvio_hip_flush(rebvio_hip_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
-  if (c->lm_stamps && c->lm_stamp_n) {
+  if (c->lm_stamps && c->lm_stamp_n && c->lm_stamp_spec) {
+    const double* a = c->lm_stamp_acc;
+    const double n = (double)c->lm_stamp_n;
+    std::fprintf(stderr,
+                 "[rebvio_hip] k_lm_chain_spec workgroup 0, mean us over %llu launches: eval0 %.2f  eval1 %.2f  collect+states %.2f  "
+                 "speculative evals %.2f  collect all %.2f  check %.2f  finish %.2f  forwardMatch+extRotVel %.2f\n",
+                 (unsigned long long)c->lm_stamp_n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, a[8] / n, a[9] / n);
+  } else if (c->lm_stamps && c->lm_stamp_n) {
     const int calls = (int)c->P.iterations + 1;
     std::fprintf(stderr, "[rebvio_hip] k_lm_chain workgroup 0, mean us per segment over %llu launches\n", (unsigned long long)c->lm_stamp_n);
     std::fprintf(stderr, "  prologue %.2f\n", c->lm_stamp_acc[1] / c->lm_stamp_n);
@@ -2333,13 +2350,13 @@ int batch_enqueue_a(rebvio_hip_batch* b, rebvio_hip_batch::Pair& pp) {
     d.om_swap = (unsigned char)map_swap_bits(om);
     d.slot = (unsigned char)pp.slot;
     d.tag_base = c->lm_tag_base;
-    c->lm_tag_base += (unsigned)calls + 1u;
+    c->lm_tag_base += 2u * ((unsigned)calls + 1u);
     if (c->lm_tag_base > 0xFFFFFF00u) {
-      (void)hipMemsetAsync(c->lm_xch, 0, (2 * (size_t)c->maxblocks + 1) * kPartStride * sizeof(unsigned long long), s);
+      (void)hipMemsetAsync(c->lm_xch, 0, lm_xch_words(c->maxblocks) * sizeof(unsigned long long), s);
       c->lm_tag_base = 0;
     }
   }
-  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls);
+  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, b->lane[0]->lm_spec ? 1 : 0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->slot_ev[pp.slot], s));
   return 0;

@@ -20,6 +20,9 @@ constexpr unsigned kDfSeqMask = (1u << kDfSeqBits) - 1u;
 constexpr int kPartStride = 16;     // floats per block record of k_try_vel
 constexpr int kXrvStride = 32;      // floats per block record of k_ext_rot_vel
 constexpr int kMaxLmCalls = 8;
+// 64-bit exchange words of the persistent LM kernels for `groups` record groups of 256 keylines (track.hip: record sets per
+// evaluation, the final velocity, neighbour carry words and barrier words of the speculative form)
+constexpr size_t lm_xch_words(size_t groups) { return ((size_t)kMaxLmCalls * groups + 1) * 16 + (2 * (size_t)kMaxLmCalls + 1) * groups; }
 constexpr int kDfTile = 32;         // distance-field tile edge (pixels); 64 for sensors with more than kDfMaxTiles 32-pixel tiles
 constexpr int kDfMaxTiles = 4096;   // per-workgroup LDS counter table of the binning pass
 constexpr int kDfTileCap = 512;     // list capacity per tile (32-byte entries); a fuller tile falls back to scanning its candidate rows
@@ -296,7 +299,8 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
                           const int widths[2][3]);
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
-void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls);
+void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
+                       int spec);
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
                       float max_radius, int gate);
 

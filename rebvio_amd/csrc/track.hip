@@ -345,6 +345,21 @@ __device__ __forceinline__ void reduce_staged_records(const float* rec, int nblo
   }
 }
 
+// The ten sums of one staged record set by the 160 threads t0 .. t0 + 159 (same order as reduce_staged_records).
+__device__ __forceinline__ void reduce_staged_sums(const float* rec, int nblocks, float* red /*shared[16]*/, int t0) {
+  const int t = (int)threadIdx.x - t0;
+  if (t >= 0 && t < 160) {
+    const int k = t >> 4, j = t & 15;
+    float acc = 0.f;
+    for (int b = j; b < nblocks; b += 16) acc += rec[b * kPartStride + k];
+    acc = dpp_add_f<0x111, 0xF>(acc);
+    acc = dpp_add_f<0x112, 0xF>(acc);
+    acc = dpp_add_f<0x114, 0xF>(acc);
+    acc = dpp_add_f<0x118, 0xF>(acc);
+    if (j == 15) red[k] = acc;
+  }
+}
+
 // Per-keyline body of Core::tryVel / calculatefJ / testfk (core.cpp:39-148), shared by the per-call kernel and the
 // persistent LM kernel.
 struct TvIn {
@@ -1000,6 +1015,412 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   }
   RH_STAMP(2 + calls * 6);
 #undef RH_STAMP
+}
+
+// ---- persistent minimizeVel with SPECULATIVE evaluation of the reject chain ------------------------------------------------
+// Observation (tools/mask_hist.py, profiles/r02_divergence_report.txt): on every tested stream minimizeVel accepts its first
+// step and rejects the other four (accept mask 00001). After a rejection the next trial point depends on nothing the rejected
+// evaluation produced: u *= v, v *= 2, h = -(JtJ + uI)^-1 JtF with the OLD JtJ / JtF (core.cpp:180-183). So once the result of
+// evaluation 1 is in, the points of evaluations 2, 3, .., calls-1 under the hypothesis "all rejected" are known, and they are
+// evaluated back to back in ONE pass - three exchange rounds per launch instead of six. Then the hypothesis is checked with
+// the real scores (the gain test of core.cpp:172, same expression); if an evaluation turns out accepted, the launch continues
+// from there with ordinary one-evaluation passes (nothing speculative is kept: state and residuals are rolled back to that
+// evaluation, the forwardMatch keys the speculative last evaluation published are cleared behind a grid barrier). Either way
+// the results are those of the sequential algorithm, bit for bit (test_persistent_lm_kernel_equals_per_call_kernels).
+// What consecutive evaluations of one pass need from OTHER workgroups is only the carry-forward of the last written fi
+// (oracle header, H3) for keylines in front of their group's first match: each workgroup hands the fi of its last matched
+// keyline to its right neighbour through one tagged word per evaluation, published right after the evaluation and polled
+// after the workgroup's own reduction (the hop hides behind it).
+// Exchange words: [kMaxLmCalls][record groups][kPartStride] record sets (one per evaluation index: no slot is reused within a
+// launch), kPartStride words for the final velocity, [kMaxLmCalls][workgroups][2] carry words, [workgroups] barrier words.
+// Tags: tag_base + phase * (calls + 1) + evaluation + 1, phase 1 = evaluations repeated after a failed hypothesis; the caller
+// advances tag_base by 2 * (calls + 1) per launch.
+constexpr int kSpecMax = 6;  // speculative evaluations per launch (iterations <= 7)
+
+template <int kChainThreads>
+__device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev nm, int calls, const LmState* __restrict__ st_in,
+                                                   LmState* __restrict__ st_out, unsigned long long* __restrict__ xch, unsigned tag_base,
+                                                   int* __restrict__ bar_err, const int* __restrict__ hist, unsigned frame_count,
+                                                   float* __restrict__ xrv_part, PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
+                                                   unsigned long long* __restrict__ stamps, int slow_poll) {
+  constexpr int kChainGroups = kChainThreads / 256;
+  constexpr int kWaves = kChainThreads / 64;
+  // REBVIO_HIP_LM_STAMPS: 1 start, 2/3 evaluations 0/1 published, 4 hypothesis states ready, 5 speculative evaluations published,
+  // 6 all record sets staged and reduced, 7 hypothesis checked, 8 LM done, 9 extRotVel rows out (stamps[0] = 1 marks the layout)
+#define RH_STAMP(i) \
+  do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  extern __shared__ float recm[];  // [nspec][cap * kPartStride] staged record sets (set 0 doubles as the ordinary collect's staging)
+  __shared__ LmState s;
+  __shared__ LmState stc[kSpecMax + 1];  // state before evaluation 2 + k's result is processed (k = 0 .. nspec), under the hypothesis
+  __shared__ float red[16];
+  __shared__ float redm[kSpecMax][16];
+  __shared__ float carry_in[kChainGroups];
+  __shared__ float wsum[kWaves][28];
+  __shared__ float wlast[kWaves];
+  __shared__ int whas[kWaves];
+  __shared__ int shist[128];
+  __shared__ int first_accept;
+
+  const int tid = threadIdx.x;
+  const int idx = blockIdx.x * kChainThreads + tid;
+  const int lane = tid & 63, wid = tid >> 6, grp = tid >> 8, wig = wid & 3;
+  const int nwg = gridDim.x;
+  const int nrec_launched = nwg * kChainGroups;
+  const TvIn in = make_tvin(p, om.gnorm[idx], om.rs[idx], om.pos_img[idx], om.grad[idx], om.matches[idx]);
+  float res = om.residual[idx];
+  XrvIn xk{};
+  xk.mid = nm.match_id[idx];
+  xk.rs = nm.rs[idx];
+  xk.mpi = nm.mpos_img[idx];
+  xk.g = nm.grad[idx];
+  xk.gn = nm.gnorm[idx];
+  xk.q = nm.pos_img[idx];
+  const int n = om.st->n;
+  const float thr = om.st->threshold;
+  const int n_new = nm.st->n;
+  const int nblocks = (n + 255) / 256;
+  const int cap = min(nblocks, kMaxRecBlocks) * kPartStride;  // words staged per record set
+  if (tid < 128) shist[tid] = (tid < p.quantile_num_bins) ? hist[tid] : 0;
+  if (tid == 0) s = *st_in;
+  if (tid < kChainGroups) carry_in[tid] = 0.f;
+  __syncthreads();
+  if (tid == 0) {
+    s.sigma_rho_min = quantile_from_hist(shist, p.quantile_num_bins, p.quantile_cutoff, n);
+    for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
+  }
+  __syncthreads();
+  const unsigned min_matches = min(p.min_match_threshold, frame_count);
+  const float srm = s.sigma_rho_min;
+  const bool lm_live = blockIdx.x == 0 || (int)blockIdx.x * kChainGroups < nblocks;
+  const int live_wgs = max(1, (nblocks + kChainGroups - 1) / kChainGroups);
+  unsigned long long* xch_final = xch + (size_t)kMaxLmCalls * nrec_launched * kPartStride;
+  unsigned long long* xch_carry = xch_final + kPartStride;                  // [kMaxLmCalls][nwg][2]
+  unsigned long long* xch_sync = xch_carry + (size_t)kMaxLmCalls * nwg * 2;  // [nwg]
+  const unsigned tag_final = tag_base + 2u * ((unsigned)calls + 1u);
+  auto tag_of = [&](int call, int phase) { return tag_base + (unsigned)phase * ((unsigned)calls + 1u) + (unsigned)call + 1u; };
+  int fa = -1;  // index of the first speculative evaluation that turned out accepted (-1: none / not known yet)
+  auto set_words = [&](int call) { return xch + (size_t)call * nrec_launched * kPartStride; };
+
+  // One evaluation at (vx, vy, vz): tryVel body, carry-forward, wave / workgroup sums, records published under `tag`.
+  // handoff: the NEXT evaluation follows in this pass without an exchange - resolve its carry-in through the neighbour words.
+  auto do_eval = [&](int call, unsigned tag, float vx, float vy, float vz, bool last, bool handoff) {
+    const float cin = carry_in[grp];
+    TvOut e{};
+    e.mfwd = -1;
+    if (idx < n) {
+      e = try_vel_eval(p, nm, in, res, cin, vx, vy, vz, srm, thr, min_matches);
+      if (e.wrote_res) res = e.res_out;
+      if (last) {
+        if (e.matched) {
+          const unsigned long long key = ((unsigned long long)order_key(in.rs.x) << 32) | (unsigned)idx;
+          atomicMax(&nm.fwd_key[e.mfwd], key);
+        }
+        om.match_fwd[idx] = e.mfwd;
+      }
+    }
+    const unsigned long long mm = __ballot(e.matched);
+    const unsigned long long below = mm & ((1ull << lane) - 1ull);
+    const int src = below ? (63 - __clzll((long long)below)) : 0;
+    const float fi_prev = __shfl(e.fi, src);
+    const int wl = mm ? (63 - __clzll((long long)mm)) : 0;
+    const float fi_wlast = __shfl(e.fi, wl);
+    if (lane == 0) {
+      whas[wid] = mm ? 1 : 0;
+      wlast[wid] = fi_wlast;
+    }
+    const float sc = e.contrib ? e.f * e.f : 0.f;
+    float v[10] = {sc, e.jx * e.jx, e.jy * e.jy, e.jz * e.jz, e.jx * e.jy, e.jx * e.jz, e.jy * e.jz, e.jx * e.f, e.jy * e.f, e.jz * e.f};
+    wave_total63_fN(v);
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) wsum[wid][k] = v[k];
+    }
+    __syncthreads();
+    if (e.need_carry) {
+      float r;
+      if (below) {
+        r = fabsf(fi_prev);
+      } else {
+        r = kResidualCarry;
+        for (int w = wig - 1; w >= 0; --w)
+          if (whas[grp * 4 + w]) {
+            r = fabsf(wlast[grp * 4 + w]);
+            break;
+          }
+      }
+      res = r;
+    }
+    // this workgroup's own last written fi (if any): out to the right neighbour at once when the next evaluation needs it
+    int own_has = 0;
+    float own_last = 0.f;
+    if (handoff && tid == kChainThreads - 1) {  // (a thread that publishes no record words below)
+      for (int w = kWaves - 1; w >= 0; --w)
+        if (whas[w]) {
+          own_has = 1;
+          own_last = wlast[w];
+          break;
+        }
+      if (own_has && (int)blockIdx.x + 1 < live_wgs) {
+        unsigned long long* cw = xch_carry + ((size_t)call * nwg + blockIdx.x) * 2;
+        xch_publish(cw, tag, 1.0f);
+        xch_publish(cw + 1, tag, own_last);
+      }
+    }
+    if (tid < kChainGroups * 16) {
+      if (last) __atomic_thread_fence(__ATOMIC_RELEASE);  // the forwardMatch keys issued before the __syncthreads above
+      const int g = tid >> 4, k = tid & 15;
+      unsigned long long* out = set_words(call) + ((size_t)blockIdx.x * kChainGroups + g) * kPartStride;
+      if (k < 10) {
+        float acc = 0.f;
+        for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
+        xch_publish(out + k, tag, acc);
+      } else if (k == 10 || k == 11) {
+        float hv = 0.f, lv = 0.f;
+        for (int w = 3; w >= 0; --w)
+          if (whas[g * 4 + w]) {
+            hv = 1.f;
+            lv = wlast[g * 4 + w];
+            break;
+          }
+        xch_publish(out + k, tag, k == 10 ? hv : lv);
+      }
+    }
+    if (handoff && tid == kChainThreads - 1) {
+      // carry-in of this workgroup for the evaluation that follows: the left neighbour's word (workgroup 0: nothing before it)
+      float in_has = 0.f, in_fi = 0.f;
+      if (blockIdx.x > 0) {
+        const unsigned long long* cw = xch_carry + ((size_t)call * nwg + (blockIdx.x - 1)) * 2;
+        in_has = xch_wait(cw, tag, bar_err, slow_poll);
+        in_fi = xch_wait(cw + 1, tag, bar_err, slow_poll);
+      }
+      if (!own_has && (int)blockIdx.x + 1 < live_wgs) {  // nothing written here: what came in goes on to the right
+        unsigned long long* cw = xch_carry + ((size_t)call * nwg + blockIdx.x) * 2;
+        xch_publish(cw, tag, in_has);
+        xch_publish(cw + 1, tag, in_fi);
+      }
+      float c = (in_has != 0.f) ? fabsf(in_fi) : 0.f;
+      for (int g = 0; g < kChainGroups; ++g) {  // as reduce_staged_records derives it from the records: nearest earlier group with a match
+        carry_in[g] = c;
+        for (int w = 3; w >= 0; --w)
+          if (whas[g * 4 + w]) {
+            c = fabsf(wlast[g * 4 + w]);
+            break;
+          }
+      }
+    }
+    __syncthreads();  // wsum / whas / wlast are rewritten by the next evaluation; carry_in is set
+  };
+
+  // ordinary collect of one record set (+ carry-in per group) into recm[0 .. cap) / red
+  auto collect = [&](int call_of_set, unsigned tag) {
+    for (int i = tid; i < cap; i += kChainThreads)
+      if ((i & (kPartStride - 1)) < 12) recm[i] = xch_wait(set_words(call_of_set) + i, tag, bar_err, slow_poll);
+    __syncthreads();
+    reduce_staged_records(recm, nblocks, red, carry_in, (int)blockIdx.x * kChainGroups, kChainGroups);
+    __syncthreads();
+  };
+  auto normal_pass = [&](int call, int phase) {
+    if (call >= 1) {
+      collect(call - 1, tag_of(call - 1, (phase == 1 && call - 1 >= fa + 3) ? 1 : 0));
+      if (tid == 0) lm_step(s, red, call, false);
+      __syncthreads();
+    }
+    do_eval(call, tag_of(call, phase), s.Vnew[0], s.Vnew[1], s.Vnew[2], call == calls - 1, false);
+  };
+
+  const int nspec = calls - 2;  // evaluations 2 .. calls - 1 (the launcher guarantees 2 <= nspec <= kSpecMax)
+  RH_STAMP(1);
+  if (lm_live) {
+    normal_pass(0, 0);
+    RH_STAMP(2);
+    normal_pass(1, 0);
+    RH_STAMP(3);
+    collect(1, tag_of(1, 0));
+    if (tid == 0) {
+      lm_step(s, red, 2, false);
+      stc[0] = s;
+    }
+    __syncthreads();
+    // states under the hypothesis: thread j applies j rejections' (u, v) updates and then one lm_step whose score is NaN (the
+    // gain test fails for any denominator): exactly the reject branch of core.cpp:180-183 plus the next trial point
+    if (tid < nspec - 1) {
+      LmState t = s;
+      for (int j = 0; j < tid; ++j) {
+        t.u *= t.v;
+        t.v = (float)((double)t.v * 2.0);
+      }
+      float fake[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) fake[i] = __uint_as_float(0x7FC00000u);
+      lm_step_regs(t, fake, 3 + tid, false);
+      stc[tid + 1] = t;
+    }
+    __syncthreads();
+    RH_STAMP(4);
+    float res_hist[kSpecMax];
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k) {
+      if (k < nspec) {
+        const int c = 2 + k;
+        do_eval(c, tag_of(c, 0), stc[k].Vnew[0], stc[k].Vnew[1], stc[k].Vnew[2], c == calls - 1, k + 1 < nspec);
+        res_hist[k] = res;
+      }
+    }
+    RH_STAMP(5);
+    // all nspec record sets at once: every thread first issues its loads together, then waits for the stragglers
+    {
+      const int total = nspec * cap;
+      for (int i0 = 0; i0 < total; i0 += kChainThreads * 8) {
+        unsigned long long w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = i0 + j * kChainThreads + tid;
+          w8[j] = 0ull;
+          if (i < total && ((i % cap) & (kPartStride - 1)) < 12) {
+            const int set = i / cap, w = i - set * cap;
+            w8[j] = __hip_atomic_load(set_words(2 + set) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = i0 + j * kChainThreads + tid;
+          if (i < total && ((i % cap) & (kPartStride - 1)) < 12) {
+            const int set = i / cap, w = i - set * cap;
+            const unsigned tag = tag_of(2 + set, 0);
+            recm[i] = ((unsigned)(w8[j] >> 32) == tag) ? __uint_as_float((unsigned)w8[j])
+                                                        : xch_wait(set_words(2 + set) + w, tag, bar_err, slow_poll);
+          }
+        }
+      }
+      __syncthreads();
+      for (int set0 = 0; set0 < nspec; set0 += kChainThreads / 160) {
+        const int sl = tid / 160, set = set0 + sl;
+        if (sl < kChainThreads / 160 && set < nspec) reduce_staged_sums(recm + (size_t)set * cap, nblocks, redm[set], sl * 160);
+      }
+      __syncthreads();
+    }
+    RH_STAMP(6);
+    // the hypothesis against the real scores: the gain test of core.cpp:172 on the state the evaluation started from
+    {
+      bool accepted = false;
+      if (tid < nspec) {
+        const LmState& t = stc[tid];
+        const float Fnew = redm[tid][0];
+        double den = 0.0;
+        for (int i = 0; i < 3; ++i) den += (0.5 * (double)t.h[i]) * (double)(t.u * t.h[i] - t.JtF[i]);
+        const float gain = (float)((double)(t.F - Fnew) / den);
+        accepted = gain > 0.0f;
+      }
+      if (wid == 0) {
+        const unsigned long long am = __ballot(accepted);
+        if (lane == 0) first_accept = am ? (__ffsll((long long)am) - 1) : -1;
+      }
+      __syncthreads();
+    }
+    fa = first_accept;
+    RH_STAMP(7);
+    if (fa < 0) {
+      if (tid == 0) {  // every evaluation rejected: the last rejection is the final step of core.cpp:166-185 (no new trial point)
+        LmState t = stc[nspec - 1];
+        t.u *= t.v;
+        t.v = (float)((double)t.v * 2.0);
+        s = t;
+      }
+      __syncthreads();
+    } else {
+      // evaluation 2 + fa was accepted: go on from there the ordinary way. Roll back, clear the keys the speculative last
+      // evaluation published, and let nobody publish a repeated evaluation before everybody has read the speculative sets.
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the keys other workgroups issued before their last record set
+      if (tid == 0) s = stc[fa];
+#pragma unroll
+      for (int k = 0; k < kSpecMax; ++k)
+        if (k == fa) res = res_hist[k];
+      for (int i = blockIdx.x * kChainThreads + tid; i < p.kmax; i += live_wgs * kChainThreads) nm.fwd_key[i] = 0ull;
+      __syncthreads();
+      if (tid == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        xch_publish(xch_sync + blockIdx.x, tag_final, 1.0f);
+      }
+      for (int i = tid; i < live_wgs; i += kChainThreads) (void)xch_wait(xch_sync + i, tag_final, bar_err, slow_poll);
+      __syncthreads();
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      for (int call = 3 + fa; call < calls; ++call) normal_pass(call, 1);
+      collect(calls - 1, tag_of(calls - 1, (calls - 1 >= fa + 3) ? 1 : 0));
+      if (tid == 0) lm_step(s, red, calls, true);
+      __syncthreads();
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    *st_out = s;
+    if (slot) {  // zero-copy: the host reads these after the pair's event
+      slot->lm = s;
+      slot->new_st = *nm.st;
+      slot->old_st = *om.st;
+    }
+  }
+  RH_STAMP(8);
+  if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
+  if (blockIdx.x == 0 && tid < 3) xch_publish(xch_final + tid, tag_final, s.vel[tid]);
+  if (!lm_live) {
+    if (tid < 3) s.vel[tid] = xch_wait(xch_final + tid, tag_final, bar_err, slow_poll);
+    __syncthreads();
+  }
+  const float vx = s.vel[0], vy = s.vel[1], vz = s.vel[2];
+  float row[6] = {0, 0, 0, 0, 0, 0};
+  float Y = 0.f;
+  int cnt = 0;
+  if (idx < n_new) {
+    xk.key = __hip_atomic_load(&nm.fwd_key[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xrv_eval(p, om, nm, idx, 1, xk, vx, vy, vz, row, &Y, &cnt);
+  }
+  float v[28];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) v[k++] = row[i] * row[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[21 + i] = row[i] * Y;
+    v[27] = (float)cnt;
+  }
+  wave_total63_fN(v);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
+  }
+  __syncthreads();
+  if (tid < kChainGroups * 32) {
+    const int g = tid >> 5, k = tid & 31;
+    if (k < 28) {
+      float acc = 0.f;
+      for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
+      xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
+    }
+  }
+  RH_STAMP(9);
+  if (stamps && blockIdx.x == 0 && tid == 0) stamps[0] = 1ull;
+#undef RH_STAMP
+}
+
+template <int kChainThreads>
+__global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec(KParams p, MapDev om, MapDev nm, int calls, const LmState* __restrict__ st_in,
+                                                                 LmState* __restrict__ st_out, unsigned long long* __restrict__ xch,
+                                                                 unsigned tag_base, int* __restrict__ bar_err, const int* __restrict__ hist,
+                                                                 float* __restrict__ xrv_part, PairSlot* __restrict__ slot,
+                                                                 int* __restrict__ hist_to_zero, unsigned long long* __restrict__ stamps) {
+  lm_chain_spec_body<kChainThreads>(p, om, nm, calls, st_in, st_out, xch, tag_base, bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps,
+                                    0);
+}
+template <int kChainThreads>
+__global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec_b(KParams p, const LaneStatic* __restrict__ ls,
+                                                                   const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  PairSlot* slot = L.slot[d.slot];
+  lm_chain_spec_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls,
+                                    L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, slot->xrv, slot, L.hist,
+                                    nullptr, slow_poll);
 }
 
 template <int kChainThreads>
@@ -1864,10 +2285,25 @@ void launch_try_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const M
                      (const LmState*)st_in, st_out, part_prev, part_out, hist, (unsigned)frame_count);
 }
 
+// Speculative form (k_lm_chain_spec; do_ext == 2 / spec != 0 allows it, the context's REBVIO_HIP_LM=seq does not). Needs at
+// least two speculative evaluations, at most kSpecMax, and the staged record sets in the default 64 KB of LDS with the static part.
+static size_t lm_spec_shm(int kmax, int calls) {
+  const int groups = std::min(div_up(kmax, 256), kMaxRecBlocks);
+  return (size_t)(calls - 2) * groups * kPartStride * sizeof(float);
+}
+static bool lm_spec_usable(int kmax, int calls) {
+  return calls - 2 >= 2 && calls - 2 <= kSpecMax && calls <= kMaxLmCalls && lm_spec_shm(kmax, calls) <= 40 * 1024;
+}
+
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
                      LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
                      PairSlot* slot, int* hist_to_zero, unsigned long long* stamps) {
   const dim3 grid(lm_chain_grid(p.kmax));
+  if (do_ext == 2 && lm_chain_threads() == 512 && lm_spec_usable(p.kmax, calls)) {
+    RH_LAUNCH(k_lm_chain_spec<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out, xch,
+              tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
+    return;
+  }
   switch (lm_chain_threads()) {
     case 256:
       RH_LAUNCH(k_lm_chain<256>, grid, dim3(256), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
@@ -1979,12 +2415,17 @@ void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m,
             p.quantile_num_bins, g_dev);
 }
 
-void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls) {
+void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
+                       int spec) {
   // 512-thread workgroups (the single-stream default); lanes x 30 workgroups at 16k keylines must all be resident: with one
   // workgroup per CU that holds up to 8 lanes on 256 CUs
   static const int slow = std::getenv("REBVIO_HIP_BATCH_POLL") ? std::atoi(std::getenv("REBVIO_HIP_BATCH_POLL")) : -1;
   const int slow_poll = slow >= 0 ? slow : (lanes >= 3 ? 1 : 0);
-  RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll);
+  if (spec && lm_spec_usable(p.kmax, calls))
+    RH_LAUNCH(k_lm_chain_spec_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), lm_spec_shm(p.kmax, calls), s, p, ls, maptab,
+              dyn, calls, slow_poll);
+  else
+    RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll);
 }
 
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,

@@ -509,6 +509,47 @@ def test_persistent_lm_kernel_equals_per_call_kernels(B, c2_stream, monkeypatch)
     assert len(a_stream) > 10 and a_stream == b_stream
 
 
+def test_speculative_lm_kernel_rolls_back_when_a_later_step_is_accepted(B, monkeypatch):
+    """The default persistent kernel evaluates minimizeVel's evaluations 2.. in one pass under the hypothesis that all of
+    them are rejected (what consecutive frames do: accept mask 00001), checks the hypothesis with the real scores and
+    otherwise goes on sequentially from the first accepted one. Pairs of frames several steps apart (and other search
+    ranges / iteration counts) give masks with later accepts: on all of them the kernel must equal the sequential
+    persistent kernel (REBVIO_HIP_LM=seq) bit for bit, and the sweep must actually contain such masks."""
+    from rebvio_amd import synth
+    streams = [synth.render_stream(640, 480, 12, stream_id=sid) for sid in (0, 1)]
+
+    def run(mode):
+        monkeypatch.setenv("REBVIO_HIP_LM", mode)   # read when the context is created
+        res = {}
+        for sid, variant, kw in [(sid, v, kw) for sid in (0, 1) for v, kw in (("default", {}), ("sr10", dict(search_range=10.0)),
+                                                                            ("it7", dict(iterations=7)), ("it3", dict(iterations=3)))]:
+            frames, cam = streams[sid]
+            ctx = B.Context(params_for(B, cam, **dict(KW_C2, **kw)))
+            for skip in (1, 2, 4, 7):
+                for i in range(skip, len(frames)):
+                    # fresh maps per pair: forwardMatch keys and depth state of a map belong to ONE pair step
+                    maps = [ctx.detect_u8(frames[i - skip], 0), ctx.detect_u8(frames[i], skip * 50000)]
+                    o = ctx.track_pair(maps[0], maps[1])
+                    v = np.concatenate([np.array(o.Vg), np.array(o.P_Vg), [o.F, o.sigma_rho_min], np.array(o.Xv), np.array(o.W_Xv),
+                                        np.array(o.V), np.array(o.P_V),
+                                        [o.klm_num, o.kf_matches, o.reg_num, o.lm_accept_mask, o.status]]).astype(np.float32)
+                    kl = maps[1].keylines()
+                    res[(sid, variant, skip, i)] = (int(o.lm_accept_mask), v, kl["match_id"].copy(), kl["rho"].copy())
+                    for m in maps:
+                        m.release()
+            ctx.close()
+        return res
+
+    a, b = run("spec"), run("seq")
+    masks = {m for m, *_ in b.values()}
+    assert 1 in masks and len(masks - {1}) >= 3, masks           # the common case and several kinds of mis-speculation
+    assert any(m & ~3 for m in masks), masks                      # an accept at the third step or later
+    for k in b:
+        assert a[k][0] == b[k][0], k
+        assert _bits_equal(a[k][1], b[k][1]), k
+        assert np.array_equal(a[k][2], b[k][2]) and _bits_equal(a[k][3], b[k][3]), k
+
+
 def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
     """The throughput pipeline (detect worker + five streams + persistent pair kernel + deferred counters) against the
     oracle's own stream driver on the same 30-frame ping-pong sequence, state carried independently on both sides:
