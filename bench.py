@@ -86,11 +86,14 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_depth_ekf": 48 * N,
     }
     base = kernel.split("<")[0] if kernel.startswith(("k_lm_chain", "k_df_tiles", "k_df_lists")) else kernel
+    # same work under other names: the speculative LM kernel, the four-column column pass, the batched (_b) forms
+    base = {"k_lm_chain_spec": "k_lm_chain", "k_lm_chain_spec_b": "k_lm_chain", "k_lm_chain_b": "k_lm_chain",
+            "k_colscan4": "k_colscan"}.get(base, base)
     return float(table.get(base, 0))
 
 
 def launches_per_frame(kernel: str, iterations: int = 5) -> int:
-    return {"k_rowscan<2>": 2, "k_colscan": 3, "k_try_vel": iterations + 1, "k_rotate": 2}.get(kernel, 1)
+    return {"k_rowscan<2>": 2, "k_colscan": 3, "k_colscan4": 3, "k_try_vel": iterations + 1, "k_rotate": 2}.get(kernel, 1)
 
 
 # Stages at the reference's REBVIO_TIMER tick sites -> the kernels that do that work here.
@@ -320,7 +323,7 @@ def main():
         fps = shard.whole_job_fps(world, steps, tmax)
         dom_us = dom[0]
         ab = algorithmic_bytes(dominant, npx, n_keylines)
-        if dominant == "k_colscan":
+        if dominant in ("k_colscan", "k_colscan4"):
             ab = (8 * npx + 16 * npx + 16 * npx) / 3.0  # mean over its three launches per frame (1, 2, 2 filters)
         achieved = ab / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
         result = {
@@ -435,7 +438,7 @@ def batched_run(lanes, frames0, cam, cfg, kw, base_frames, npx, n_keylines, step
     torch.cuda.synchronize()
     c0 = bat.lanes[0]
     c0.profile_reset()
-    c0.profile(True, only="k_lm_chain_b<512>", stride=8)
+    c0.profile(True, only="k_lm_chain*", stride=8)  # k_lm_chain_spec_b<512>, or k_lm_chain_b<512> under REBVIO_HIP_LM=seq
     bad = 0
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -444,7 +447,9 @@ def batched_run(lanes, frames0, cam, cfg, kw, base_frames, npx, n_keylines, step
         k += 1
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    dom = c0.profile_read().get("k_lm_chain_b<512>", (0.0, 0))
+    prof = c0.profile_read()
+    dom_name = next((kname for kname in prof if kname.startswith("k_lm_chain")), "k_lm_chain_spec_b<512>")
+    dom = prof.get(dom_name, (0.0, 0))
     c0.profile(False)
     bat.flush()
     bat.close()
@@ -453,7 +458,7 @@ def batched_run(lanes, frames0, cam, cfg, kw, base_frames, npx, n_keylines, step
     fps = lanes * steps / (t1 - t0)
     return {"lanes": lanes, "value": fps, "unit": "frames/s (all lanes)", "us_per_step": (t1 - t0) / steps * 1e6, "steps": steps,
             "non_zero_statuses": bad,
-            "roofline": {"bound": "hbm", "kernel": "k_lm_chain_b<512>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "avg_launch_us": dom[0], "launches": dom[1], "algorithmic_bytes_per_launch": ab},
             "frame_achieved_GBs": (112 * npx + 1740 * n_keylines) * fps / 1e9}
 

@@ -103,6 +103,11 @@ thread_local ProfOpen t_open;
 }  // namespace
 
 namespace rh {
+// selection by exact name, or by prefix when the selector ends with '*'
+static bool prof_name_selected(const std::string& only, const char* name) {
+  if (!only.empty() && only.back() == '*') return std::strncmp(only.c_str(), name, only.size() - 1) == 0;
+  return only == name;
+}
 void prof_begin(hipStream_t s, const char* name) {
   if (!g_prof.on) return;
   if (t_open.group_depth > 0) return;
@@ -110,7 +115,7 @@ void prof_begin(hipStream_t s, const char* name) {
   t_open.name = -1;
   {
     std::lock_guard<std::mutex> g(g_prof.mu);
-    if (!g_prof.only.empty() && g_prof.only != name) return;
+    if (!g_prof.only.empty() && !prof_name_selected(g_prof.only, name)) return;
     if (g_prof.stride > 1 && (g_prof.seen[name]++ % (unsigned)g_prof.stride) != 0) return;
     if (g_prof.samples.size() >= g_prof.cap) return;
     t_open.name = g_prof.name_id(name);
@@ -171,6 +176,8 @@ struct rebvio_hip_ctx {
   KParams K{};
   int device = 0;
   hipStream_t s_det{}, s_key{}, s_df{}, s_trk{}, s_cpy{};
+  bool scan_split = true;       // last column pass + k_dog_mag on s_key (detect_launch)
+  float* sa2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [frame parity][filter]: sb.a per parity ([0] aliases sb.a)
   // scale-space outputs (DoG, squared gradient, per-row counts) are double buffered: the scans of frame f+1 (s_det)
   // overlap the keyline extraction of frame f (s_key)
   float* dog2[2]{};
@@ -444,6 +451,10 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   sb.scale0 = sb.scale1 = nullptr;
   sb.dog = c->dog2[b];
   sb.mag = c->mag2[b];
+  if (c->scan_split) {  // the third filter's integral images change streams: one pair per frame parity
+    sb.a[0] = c->sa2[b][0];
+    sb.a[1] = c->sa2[b][1];
+  }
   DetectBufs db = c->db;
   db.rowcount = c->rowcount2[b];
   // scans of this frame (s_det); its DoG / gradient buffers were last read by the candidate kernel two frames ago
@@ -455,10 +466,15 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
     img = c->undist_img[b];
     is_u8 = 0;
   }
-  launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount);
+  // The scan stream is the busiest of the three: it hands the frame over after the last ROW pass, the last column pass and
+  // the DoG / gradient kernel run at the head of the keyline stream (REBVIO_HIP_SCAN_SPLIT=0: all seven on the scan stream).
+  // Their inputs sb.a[] are then read while the scan stream already works on the next frame, hence the pair per parity;
+  // the frame after next waits for ev_flag[b] (recorded behind them) above.
+  launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount, c->scan_split ? 1 : 3);
   HIPCHK(hipEventRecord(c->ev_scan[b], c->s_det));
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
   HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
+  if (c->scan_split) launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2);
   if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done, 0));
   launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st);
   HIPCHK(hipGetLastError());
@@ -630,9 +646,9 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
   if (c->lm_stamps && c->lm_stamps[0]) {  // stamps of the previous launch (the caller has synchronised on its slot since)
     // the buffer may be half rewritten by a launch that is already running (streaming driver): take a snapshot and use it
     // only if it is monotonic and spans less than a millisecond
-    const bool spec = c->lm_stamps[0] == 1ull;  // k_lm_chain_spec: stamps 1..9, [0] is a marker
+    const bool spec = c->lm_stamps[0] == 1ull;  // k_lm_chain_spec: stamps 1..14, [0] is a marker
     const int i0 = spec ? 1 : 0;
-    const int ns = spec ? 10 : 3 + calls * 6;
+    const int ns = spec ? 15 : 3 + calls * 6;
     unsigned long long snap[64];
     for (int i = 0; i < ns; ++i) snap[i] = c->lm_stamps[i];
     bool sane = snap[ns - 1] > snap[i0] && snap[ns - 1] - snap[i0] < 100000ull;
@@ -831,6 +847,11 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_flag[i], hipEventDisableTiming));
   }
+  c->scan_split = !(std::getenv("REBVIO_HIP_SCAN_SPLIT") && std::atoi(std::getenv("REBVIO_HIP_SCAN_SPLIT")) == 0);
+  for (int f = 0; f < 2; ++f) {
+    c->sa2[0][f] = c->sb.a[f];
+    HIPCHK(hipMalloc(&c->sa2[1][f], Pp * sizeof(float)));
+  }
   HIPCHK(hipMalloc(&c->dog2[1], Pn * sizeof(float)));
   HIPCHK(hipMalloc(&c->mag2[1], Pn * sizeof(float)));
   HIPCHK(hipMalloc(&c->rowcount2[1], (size_t)p->rows * sizeof(int)));
@@ -985,6 +1006,8 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
                   c->part, c->xrv_part, c->hist, c->fscratch};
   for (void* p : dptr)
     if (p) (void)hipFree(p);
+  for (int f = 0; f < 2; ++f)
+    if (c->sa2[1][f]) (void)hipFree(c->sa2[1][f]);
   void* hptr[] = {c->h_lm, c->h_part, c->h_xrv, c->h_st, c->h_f};
   for (void* p : hptr)
     if (p) (void)hipHostFree(p);
@@ -1964,8 +1987,10 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     const double n = (double)c->lm_stamp_n;
     std::fprintf(stderr,
                  "[rebvio_hip] k_lm_chain_spec workgroup 0, mean us over %llu launches: eval0 %.2f  eval1 %.2f  collect+states %.2f  "
-                 "speculative evals %.2f  collect all %.2f  check %.2f  finish %.2f  forwardMatch+extRotVel %.2f\n",
-                 (unsigned long long)c->lm_stamp_n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, a[8] / n, a[9] / n);
+                 "speculative evals [project %.2f  issue gathers %.2f  match %.2f  neighbour round %.2f  weighted sums %.2f  publish %.2f]  "
+                 "collect all %.2f  check %.2f  finish %.2f  forwardMatch+extRotVel %.2f\n",
+                 (unsigned long long)c->lm_stamp_n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, a[8] / n, a[9] / n, a[10] / n,
+                 a[11] / n, a[12] / n, a[13] / n, a[14] / n);
   } else if (c->lm_stamps && c->lm_stamp_n) {
     const int calls = (int)c->P.iterations + 1;
     std::fprintf(stderr, "[rebvio_hip] k_lm_chain workgroup 0, mean us per segment over %llu launches\n", (unsigned long long)c->lm_stamp_n);

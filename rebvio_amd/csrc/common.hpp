@@ -140,7 +140,7 @@ void upload_tables(const float* recip128, const float* pinv75);
 
 void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, const int2* map, float* dst);
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
-                        const int widths[2][3], int* rowcount_to_zero);
+                        const int widths[2][3], int* rowcount_to_zero, int part = 3);
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
                      const DetState* det_in, DetState* det_out, const MapState* prev_st);
 // Distance-field build: LDS tiles (default) or the global-atomic scatter kernel (REBVIO_HIP_DF=scatter, kept as a reference).

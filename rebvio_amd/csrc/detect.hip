@@ -151,10 +151,66 @@ __device__ __forceinline__ float4 rowscan_fetch(const void* __restrict__ src, in
   }
 }
 
+// ---- the sequential fp32 chain of a scan, on one wave with the data in registers ------------------------------------
+// Bit-exactness pins the ORDER of the adds (s += x[i], i ascending), not who performs them. A lone lane walking an LDS
+// array pays an LDS round trip per group of elements (reads and writes share the in-order lgkm counter: ~20 cycles per
+// element measured). Here the n4 float4 chunks of the array are dealt to the lanes of one wave in blocks of KQ consecutive
+// chunks (one LDS read), and the chain hops from lane to lane: step j runs the 4*KQ dependent adds of lane j's block with
+// only that lane enabled, the running sum crosses to the next lane through v_readlane. No memory operation sits on the
+// chain: ~5 cycles per element. Same adds in the same order as the one-lane loop, so the same bits.
+// The first element is taken as it is (the reference starts the sum from it, scale_space.cpp:52,60).
+template <int KQ>
+__device__ __forceinline__ void wave_chain(float* __restrict__ arr /* LDS, 16-byte aligned */, int n4) {
+  const int lane = (int)threadIdx.x & 63;
+  const int first = lane * KQ;
+  float4 a[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q)
+    a[q] = (first + q < n4) ? *reinterpret_cast<const float4*>(arr + (size_t)(first + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nl = (n4 + KQ - 1) / KQ;  // lanes that hold data
+  float total = 0.f;
+  for (int j = 0; j < nl; ++j) {
+    const float carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), j > 0 ? j - 1 : 0));
+    if (lane == j) {
+      float p = (j == 0) ? a[0].x : carry + a[0].x;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        if (q > 0) p = p + a[q].x;
+        a[q].x = p;
+        p = p + a[q].y;
+        a[q].y = p;
+        p = p + a[q].z;
+        a[q].z = p;
+        p = p + a[q].w;
+        a[q].w = p;
+      }
+      total = p;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KQ; ++q)
+    if (first + q < n4) *reinterpret_cast<float4*>(arr + (size_t)(first + q) * 4) = a[q];
+}
+// n4 <= 512 chunks (2048 elements); longer arrays keep the one-lane loop of the caller
+__device__ __forceinline__ bool wave_chain_any(float* __restrict__ arr, int n4) {
+  switch ((n4 + 63) >> 6) {
+    case 1: wave_chain<1>(arr, n4); return true;
+    case 2: wave_chain<2>(arr, n4); return true;
+    case 3: wave_chain<3>(arr, n4); return true;
+    case 4: wave_chain<4>(arr, n4); return true;
+    case 5: wave_chain<5>(arr, n4); return true;
+    case 6: wave_chain<6>(arr, n4); return true;
+    case 7: wave_chain<7>(arr, n4); return true;
+    case 8: wave_chain<8>(arr, n4); return true;
+    default: return false;
+  }
+}
+
 template <int MODE>  // 0: u8 image * 3.0f, 1: fp32 image, 2: box average (width d) of an integral image
 __device__ __forceinline__ void rowscan_body(const void* __restrict__ src0, const void* __restrict__ src1,
                                                  float* __restrict__ dst0, float* __restrict__ dst1, int R, int Cimg, int d0,
-                                                 int d1, int ldw) {
+                                                 int d1, int ldw_signed) {
+  const int ldw = abs(ldw_signed);  // (negative: the caller asks for the one-lane chain, REBVIO_HIP_ROWSCAN=lane)
   // C = row pitch of the integral images = the image width rounded up to a multiple of 4; the chain also runs over the
   // padding columns (they follow the image's columns, so the image's prefix values do not depend on them)
   const int C = (Cimg + 3) & ~3;
@@ -190,7 +246,9 @@ __device__ __forceinline__ void rowscan_body(const void* __restrict__ src0, cons
 #undef RH_RS_ST
   }
   __syncthreads();
-  if ((int)threadIdx.x < nrows) {
+  const bool wide = ldw_signed > 0 && C4 <= 512;  // wave lr chains strip row lr in registers (wave_chain); else one lane per row below
+  if (wide && rvalid) (void)wave_chain_any(tile + lr * ldw, C4);
+  if (!wide && (int)threadIdx.x < nrows) {
     // sequential chain over the row; LDS reads run four float4 ahead of the adds (two register groups)
     float* rowp = tile + threadIdx.x * ldw;
     float4 v = *reinterpret_cast<float4*>(rowp);
@@ -382,6 +440,67 @@ __device__ __forceinline__ void colscan_body(float* __restrict__ buf0, float* __
   }
 }
 
+// Column accumulation with the chain on whole waves (wave_chain): a workgroup of COLS waves owns COLS columns (COLS / 4
+// 16-byte chunks per row), stages them transposed in LDS (tile[col][row]) exactly as colscan_body does and wave w runs
+// column w. For images of at most 2048 rows. COLS = 16: 1024 threads, the strip geometry of colscan_body with four times
+// the loads in flight per workgroup; COLS = 4: 256 threads and one chunk per row (more workgroups, 16-byte rows).
+template <int COLS>
+__device__ __forceinline__ void colscanw_body(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh) {
+  constexpr int Q = COLS / 4;  // chunks per strip row
+  extern __shared__ float4 smem4[];
+  float* tile = reinterpret_cast<float*>(smem4);  // [COLS][ldh]
+  float* __restrict__ buf = blockIdx.y ? buf1 : buf0;
+  const int c0 = blockIdx.x * COLS;
+  const int ncols = min(COLS, C - c0);  // multiple of 4
+  const int t = (int)threadIdx.x;
+  const int c4 = t & (Q - 1);
+  const bool cvalid = c4 * 4 < ncols;
+  const int rb = t / Q;  // 256 rows per pass
+  float* g = buf + c0 + min(c4 * 4, ncols - 4);
+  for (int base = 0; base < R; base += 512) {
+#define RH_CW_LD(k) *reinterpret_cast<const float4*>(g + (size_t)min(base + (k) * 256 + rb, R - 1) * C)
+    const float4 v0 = RH_CW_LD(0), v1 = RH_CW_LD(1);
+#undef RH_CW_LD
+    __builtin_amdgcn_sched_barrier(0);  // both loads are in flight before the first LDS write
+#define RH_CW_ST(k, v)                            \
+    {                                             \
+      const int r = base + (k) * 256 + rb;        \
+      if (r < R && cvalid) {                      \
+        float* tp = tile + (c4 * 4) * ldh + r;    \
+        tp[0] = v.x;                              \
+        tp[ldh] = v.y;                            \
+        tp[2 * ldh] = v.z;                        \
+        tp[3 * ldh] = v.w;                        \
+      }                                           \
+    }
+    RH_CW_ST(0, v0) RH_CW_ST(1, v1)
+#undef RH_CW_ST
+  }
+  __syncthreads();
+  if ((t >> 6) < ncols) {
+    float* colp = tile + (t >> 6) * ldh;
+    const int R4 = R >> 2;
+    (void)wave_chain_any(colp, R4);
+    if ((R & 3) && (t & 63) == 0) {  // rows % 4 tail (the wave's own LDS writes above are visible to it in program order)
+      float sacc = colp[R4 * 4 - 1];
+      for (int r = R4 * 4; r < R; ++r) {
+        sacc = sacc + colp[r];
+        colp[r] = sacc;
+      }
+    }
+  }
+  __syncthreads();
+  if (cvalid)
+    for (int r = rb; r < R; r += 256) {
+      const float* tp = tile + (c4 * 4) * ldh + r;
+      *reinterpret_cast<float4*>(g + (size_t)r * C) = make_float4(tp[0], tp[ldh], tp[2 * ldh], tp[3 * ldh]);
+    }
+}
+template <int COLS>
+__global__ __launch_bounds__(COLS * 64) void k_colscanw(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
+  colscanw_body<COLS>(buf0, buf1, R, C, ldh);
+}
+
 __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
   colscan_body(buf0, buf1, R, C, ldh);
 }
@@ -389,6 +508,11 @@ __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float
 __global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh) {
   const LaneStatic& L = ls[lane0 + blockIdx.z];
   colscan_body(which == 1 ? L.sb[0] : L.sa[0], which == 0 ? L.sa[0] : (which == 1 ? L.sb[1] : L.sa[1]), R, C, ldh);
+}
+template <int COLS>
+__global__ __launch_bounds__(COLS * 64) void k_colscanw_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh) {
+  const LaneStatic& L = ls[lane0 + blockIdx.z];
+  colscanw_body<COLS>(which == 1 ? L.sb[0] : L.sa[0], which == 0 ? L.sa[0] : (which == 1 ? L.sb[1] : L.sa[1]), R, C, ldh);
 }
 
 // ---- last box pass of both filters fused with DoG and squared gradient (scale_space.cpp:210-233) ------
@@ -1257,6 +1381,33 @@ static int lds_pitch(int cols) {
   if (((cols + pad) / 4) % 2 == 0) pad = 8;
   return cols + pad;
 }
+static bool rowscan_lane_chain() {  // REBVIO_HIP_ROWSCAN=lane: one lane per row walks the LDS row (A/B against wave_chain)
+  static const bool on = [] {
+    const char* e = std::getenv("REBVIO_HIP_ROWSCAN");
+    return e && std::strcmp(e, "lane") == 0;
+  }();
+  return on;
+}
+// column pass: 16-column strips with one lane per column (k_colscan). REBVIO_HIP_COLSCAN = w16 | w8 | w4 selects the form with
+// the chain on whole waves (that many columns per workgroup, up to 2048 rows) for A/B. Measured at 640x480 (rocprofv3, mean
+// of 3672 launches): lane 9.2 us, w16 10.4, w8 10.6, w4 12.0 - unlike the row pass (13.5 -> 11.4 us with wave_chain) the
+// column pass is bound by its transposing strip loads, not by the chain, and 16 waves per strip only add to that.
+static int colscan_waves(int R) {
+  static const int sel = [] {
+    const char* e = std::getenv("REBVIO_HIP_COLSCAN");
+    if (!e) return 0;
+    if (std::strcmp(e, "w4") == 0) return 4;
+    if (std::strcmp(e, "w8") == 0) return 8;
+    if (std::strcmp(e, "w16") == 0) return 16;
+    return 0;
+  }();
+  if (sel == 0) return 0;
+  if (R > 2048) return 0;
+  int cw = sel;
+  const int ldh = lds_pitch(R + (4 - R % 4) % 4);
+  while (cw > 4 && (size_t)cw * ldh * sizeof(float) > 60 * 1024) cw >>= 1;  // the strip stays inside the default 64 KB of LDS
+  return cw;
+}
 
 // ---- front end: convertTo(CV_32F, 3.0) + cv::undistort as one gather kernel (rebvio.cpp:43-47) -------
 // map = fixed-point source coordinates (1/32 px, hostmath.hpp undistort_fixed_map). Weights (1-a)(1-b) .. with a, b
@@ -1285,12 +1436,15 @@ void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, co
   RH_LAUNCH(k_front_end_u8, dim3(div_up(p.rows * p.cols, 256)), dim3(256), 0, s, src, map, dst, p.rows, p.cols);
 }
 
+// part: 1 = everything up to the row pass of the third box filter (five kernels), 2 = its column pass + k_dog_mag, 3 = both.
+// The streaming driver runs part 2 on the keyline stream: the scan stream is the busiest of a frame's three.
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
-                        const int widths[2][3], int* rowcount_to_zero) {
+                        const int widths[2][3], int* rowcount_to_zero, int part) {
   const int R = p.rows, C = p.cols;
   const int Cp = (C + 3) & ~3;  // pitch of the scan buffers sb.a / sb.b
-  const int ldw = lds_pitch(Cp);
-  const size_t shm = (size_t)kStrip * ldw * sizeof(float);
+  const int ldw_abs = lds_pitch(Cp);
+  const size_t shm = (size_t)kStrip * ldw_abs * sizeof(float);
+  const int ldw = rowscan_lane_chain() ? -ldw_abs : ldw_abs;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1303,23 +1457,42 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
   const dim3 c1(div_up(Cp, kColStrip), 1), c2(div_up(Cp, kColStrip), 2);
   const int ldh = lds_pitch(R + (4 - R % 4) % 4);
   const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
-  // pass 1: both filters share the integral image of the input (scale_space.cpp:175)
-  if (img_is_u8)
-    RH_LAUNCH(k_rowscan<0>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
-  else
-    RH_LAUNCH(k_rowscan<1>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
-  RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, sb.a[0], sb.a[0], R, Cp, ldh);
-  // pass 2: average(width[0]) fused into the row scan, per filter
-  RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.a[0], (const void*)sb.a[0], sb.b[0], sb.b[1], R,
-                     C, widths[0][0], widths[1][0], ldw);
-  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.b[0], sb.b[1], R, Cp, ldh);
-  // pass 3: filter f averages its own integral image
-  RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R,
-                     C, widths[0][1], widths[1][1], ldw);
-  RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.a[0], sb.a[1], R, Cp, ldh);
-  const dim3 gt(div_up(C, 64), div_up(R, 4));
-  RH_LAUNCH(k_dog_mag, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2],
-                     widths[1][2], sb.dog, sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
+  const int cw = colscan_waves(R);
+  const size_t wshm = (size_t)ldh * (cw ? cw : 4) * sizeof(float);
+#define RH_COLSCAN(one, b0, b1)                                                                                          \
+  do {                                                                                                                   \
+    const dim3 wg(div_up(Cp, cw ? cw : 4), (one) ? 1 : 2);                                                               \
+    if (cw == 16)                                                                                                        \
+      RH_LAUNCH(k_colscanw<16>, wg, dim3(1024), wshm, s, b0, b1, R, Cp, ldh);                                            \
+    else if (cw == 8)                                                                                                    \
+      RH_LAUNCH(k_colscanw<8>, wg, dim3(512), wshm, s, b0, b1, R, Cp, ldh);                                              \
+    else if (cw == 4)                                                                                                    \
+      RH_LAUNCH(k_colscanw<4>, wg, dim3(256), wshm, s, b0, b1, R, Cp, ldh);                                              \
+    else                                                                                                                 \
+      RH_LAUNCH(k_colscan, (one) ? c1 : c2, dim3(256), cshm, s, b0, b1, R, Cp, ldh);                                     \
+  } while (0)
+  if (part & 1) {
+    // pass 1: both filters share the integral image of the input (scale_space.cpp:175)
+    if (img_is_u8)
+      RH_LAUNCH(k_rowscan<0>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
+    else
+      RH_LAUNCH(k_rowscan<1>, g1, dim3(256), shm, s, img, img, sb.a[0], sb.a[0], R, C, 0, 0, ldw);
+    RH_COLSCAN(true, sb.a[0], sb.a[0]);
+    // pass 2: average(width[0]) fused into the row scan, per filter
+    RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.a[0], (const void*)sb.a[0], sb.b[0], sb.b[1], R,
+                       C, widths[0][0], widths[1][0], ldw);
+    RH_COLSCAN(false, sb.b[0], sb.b[1]);
+    // pass 3: filter f averages its own integral image
+    RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R,
+                       C, widths[0][1], widths[1][1], ldw);
+  }
+  if (part & 2) {
+    RH_COLSCAN(false, sb.a[0], sb.a[1]);
+    const dim3 gt(div_up(C, 64), div_up(R, 4));
+    RH_LAUNCH(k_dog_mag, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2],
+                       widths[1][2], sb.dog, sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
+  }
+#undef RH_COLSCAN
 }
 
 // ---- batched launchers (lane = blockIdx.z): the same grids with a third dimension ------------------------------------------
@@ -1327,8 +1500,9 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
                           const int widths[2][3]) {
   const int R = p.rows, C = p.cols;
   const int Cp = (C + 3) & ~3;
-  const int ldw = lds_pitch(Cp);
-  const size_t shm = (size_t)kStrip * ldw * sizeof(float);
+  const int ldw_abs = lds_pitch(Cp);
+  const size_t shm = (size_t)kStrip * ldw_abs * sizeof(float);
+  const int ldw = rowscan_lane_chain() ? -ldw_abs : ldw_abs;
   const int ldh = lds_pitch(R + (4 - R % 4) % 4);
   const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
   static bool attr_done = false;
@@ -1341,12 +1515,27 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
   const unsigned z = (unsigned)lanes;
   const dim3 g1(div_up(R, kStrip), 1, z), g2(div_up(R, kStrip), 2, z);
   const dim3 c1(div_up(Cp, kColStrip), 1, z), c2(div_up(Cp, kColStrip), 2, z);
+  const int cw = colscan_waves(R);
+  const size_t wshm = (size_t)ldh * (cw ? cw : 4) * sizeof(float);
+#define RH_COLSCAN_B(which)                                                                              \
+  do {                                                                                                   \
+    const dim3 wg(div_up(Cp, cw ? cw : 4), (which) == 0 ? 1 : 2, z);                                     \
+    if (cw == 16)                                                                                        \
+      RH_LAUNCH(k_colscanw_b<16>, wg, dim3(1024), wshm, s, ls, lane0, which, R, Cp, ldh);                \
+    else if (cw == 8)                                                                                    \
+      RH_LAUNCH(k_colscanw_b<8>, wg, dim3(512), wshm, s, ls, lane0, which, R, Cp, ldh);                  \
+    else if (cw == 4)                                                                                    \
+      RH_LAUNCH(k_colscanw_b<4>, wg, dim3(256), wshm, s, ls, lane0, which, R, Cp, ldh);                  \
+    else                                                                                                 \
+      RH_LAUNCH(k_colscan_b, (which) == 0 ? c1 : c2, dim3(256), cshm, s, ls, lane0, which, R, Cp, ldh);  \
+  } while (0)
   RH_LAUNCH(k_rowscan_b<0>, g1, dim3(256), shm, s, ls, dyn, lane0, 0, R, C, 0, 0, ldw);
-  RH_LAUNCH(k_colscan_b, c1, dim3(256), cshm, s, ls, lane0, 0, R, Cp, ldh);
+  RH_COLSCAN_B(0);
   RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 1, R, C, widths[0][0], widths[1][0], ldw);
-  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, lane0, 1, R, Cp, ldh);
+  RH_COLSCAN_B(1);
   RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 2, R, C, widths[0][1], widths[1][1], ldw);
-  RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, lane0, 2, R, Cp, ldh);
+  RH_COLSCAN_B(2);
+#undef RH_COLSCAN_B
   RH_LAUNCH(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 4), z), dim3(64, 4), 0, s, ls, dyn, lane0, widths[0][2], widths[1][2], R, C);
 }
 

@@ -388,75 +388,125 @@ struct TvOut {
   int mfwd;
   bool contrib, matched, need_carry, wrote_res;
 };
-__device__ __forceinline__ TvOut try_vel_eval(const KParams& p, const MapDev& nm, const TvIn& k, float res_in, float cin, float vx,
-                                              float vy, float vz, float srm, float thr, unsigned min_matches) {
+// try_vel_eval in three steps, so that a caller with several trial velocities at hand (k_lm_chain_spec) can have the
+// dependent gathers of all of them in flight together: (1) projection of the keyline under the trial velocity - no memory,
+// nothing that depends on the residual; (2) the distance-field cell, then the geometry of the keyline it names; (3) the
+// arithmetic, which is where the residual of the previous evaluation (the IRLS weight) comes in.
+struct TvProj {
+  float rho_p, p_x, p_y, p_xc, p_yc;
+  int cell;  // y * cols + x, or -1 when there is no cell to look at (keyline skipped, or penalised before the lookup)
+  bool skip, penalty1;
+};
+struct TvGeo {
+  float2 g1, pn;
+  float gnn;
+  int id;  // -1: empty cell
+};
+__device__ __forceinline__ TvProj tv_project(const KParams& p, const TvIn& k, float vx, float vy, float vz, float srm, float thr,
+                                             unsigned min_matches) {
+  TvProj o{};
+  o.cell = -1;
+  o.skip = (thr > 0.0f && k.gn < thr) || (k.rs.y > srm) || (k.nmatches < min_matches);
+  if (o.skip) return o;
+  const float2 pi = k.pi;
+  const float z_p = (float)(k.inv_rho_d + (double)vz);
+  if (z_p <= 0.0f) {
+    o.penalty1 = true;
+  } else {
+    o.rho_p = (float)(1.0 / (double)z_p);
+    o.p_x = o.rho_p * (vx * p.fm - vz * pi.x) + pi.x;
+    o.p_y = o.rho_p * (vy * p.fm - vz * pi.y) + pi.y;
+    o.p_xc = o.p_x + p.cx;
+    o.p_yc = o.p_y + p.cy;
+    const int x = cvtt_f64((double)o.p_xc + 0.5);
+    const int y = cvtt_f64((double)o.p_yc + 0.5);
+    if (x < 1 || y < 1 || (unsigned)x >= (unsigned)p.cols - 1u || (unsigned)y >= (unsigned)p.rows - 1u)
+      o.penalty1 = true;
+    else
+      o.cell = y * p.cols + x;
+  }
+  return o;
+}
+__device__ __forceinline__ unsigned tv_cell(const MapDev& nm, const TvProj& pj) { return pj.cell >= 0 ? nm.df[(size_t)pj.cell] : kDfEmpty; }
+__device__ __forceinline__ TvGeo tv_geometry(const KParams& p, const MapDev& nm, unsigned key) {
+  TvGeo g{};
+  g.id = -1;
+  if (key != kDfEmpty) {
+    g.id = (int)((kDfSeqMask - (key & kDfSeqMask)) / (unsigned)p.df_nr);
+    g.g1 = nm.grad[g.id];
+    g.pn = nm.pos[g.id];  // issued with g1: one gather round trip
+    g.gnn = nm.gnorm[g.id];
+  }
+  return g;
+}
+// (3a) what does not depend on the residual: the similarity test of the cell's keyline (testfk), fi and the gradient of f
+struct TvMatch {
+  float fi, df_dx, df_dy, f0;  // f0: f before the IRLS weight
+  int mfwd;
+  bool matched, need_carry;
+};
+__device__ __forceinline__ TvMatch tv_match(const KParams& p, const TvIn& k, const TvProj& pj, const TvGeo& ge) {
+  TvMatch m{};
+  m.mfwd = -1;
+  if (pj.skip || pj.penalty1) return m;
   const float gn = k.gn;
-  const float2 rs = k.rs, pi = k.pi, g2 = k.g2;
-  float f = 0.f, jx = 0.f, jy = 0.f, jz = 0.f, fi = 0.f, res_out = 0.f;
-  bool contrib = false, matched = false, need_carry = false, wrote_res = false;
-  int mfwd = -1;
-  const bool skip = (thr > 0.0f && gn < thr) || (rs.y > srm) || (k.nmatches < min_matches);
-  if (!skip) {
+  const float2 rs = k.rs, g2 = k.g2;
+  if (ge.id >= 0) {
+    const float2 g1 = ge.g1;
+    const float norm_squared = gn * gn;
+    const float dot_product = g1.x * g2.x + g1.y * g2.y;
+    if (!(fabsf(dot_product - norm_squared) > p.match_treshold * norm_squared)) {
+      const float dx = pj.p_xc - ge.pn.x;
+      const float dy = pj.p_yc - ge.pn.y;
+      const float gnx = g1.x / ge.gnn;
+      const float gny = g1.y / ge.gnn;
+      m.fi = (dx * gnx + dy * gny);
+      m.df_dx = gnx / rs.y;
+      m.df_dy = gny / rs.y;
+      m.mfwd = ge.id;
+      m.f0 = m.fi / rs.y;
+      m.matched = true;
+    }
+  }
+  if (!m.matched) {
+    m.f0 = k.range_over_sig;
+    m.need_carry = true;
+  }
+  return m;
+}
+// (3b) the IRLS weight from the previous evaluation's residual, and the weighted terms
+__device__ __forceinline__ TvOut tv_weight(const KParams& p, const TvIn& k, const TvProj& pj, const TvMatch& m, float res_in, float cin) {
+  float f = 0.f, jx = 0.f, jy = 0.f, jz = 0.f, res_out = 0.f;
+  bool contrib = false, wrote_res = false;
+  if (!pj.skip) {
     float res = res_in;
     if (res == kResidualCarry) res = cin;
     res_out = res;
     float weight = 1.0f;
     if (res > p.reweight_distance) weight = p.reweight_distance / res;
-    const float z_p = (float)(k.inv_rho_d + (double)vz);
-    bool penalty1 = false;
-    float rho_p = 0.f, p_x = 0.f, p_y = 0.f, p_xc = 0.f, p_yc = 0.f;
-    int x = 0, y = 0;
-    if (z_p <= 0.0f) {
-      penalty1 = true;
-    } else {
-      rho_p = (float)(1.0 / (double)z_p);
-      p_x = rho_p * (vx * p.fm - vz * pi.x) + pi.x;
-      p_y = rho_p * (vy * p.fm - vz * pi.y) + pi.y;
-      p_xc = p_x + p.cx;
-      p_yc = p_y + p.cy;
-      x = cvtt_f64((double)p_xc + 0.5);
-      y = cvtt_f64((double)p_yc + 0.5);
-      if (x < 1 || y < 1 || (unsigned)x >= (unsigned)p.cols - 1u || (unsigned)y >= (unsigned)p.rows - 1u) penalty1 = true;
-    }
     contrib = true;
-    if (penalty1) {
+    if (pj.penalty1) {
       f = (float)((k.inv_sig_d * (double)p.search_range) * (double)weight);
     } else {
-      float df_dx = 0.f, df_dy = 0.f;
-      const unsigned key = nm.df[(size_t)y * p.cols + x];
-      if (key != kDfEmpty) {
-        const int id = (int)((kDfSeqMask - (key & kDfSeqMask)) / (unsigned)p.df_nr);
-        const float2 g1 = nm.grad[id];
-        const float2 pn = nm.pos[id];   // issued with g1: one gather round trip
-        const float gnn = nm.gnorm[id];
-        const float norm_squared = gn * gn;
-        const float dot_product = g1.x * g2.x + g1.y * g2.y;
-        if (!(fabsf(dot_product - norm_squared) > p.match_treshold * norm_squared)) {
-          const float dx = p_xc - pn.x;
-          const float dy = p_yc - pn.y;
-          const float gnx = g1.x / gnn;
-          const float gny = g1.y / gnn;
-          fi = (dx * gnx + dy * gny);
-          df_dx = gnx / rs.y;
-          df_dy = gny / rs.y;
-          mfwd = id;
-          f = fi / rs.y;
-          matched = true;
-        }
-      }
-      if (!matched) {
-        f = k.range_over_sig;
-        need_carry = true;
-      }
+      f = m.f0;
       f *= weight;
-      jx = rho_p * p.fm * df_dx * weight;
-      jy = rho_p * p.fm * df_dy * weight;
-      jz = -rho_p * (p_x * df_dx + p_y * df_dy) * weight;
-      if (matched) res_out = fabsf(fi);
+      jx = pj.rho_p * p.fm * m.df_dx * weight;
+      jy = pj.rho_p * p.fm * m.df_dy * weight;
+      jz = -pj.rho_p * (pj.p_x * m.df_dx + pj.p_y * m.df_dy) * weight;
+      if (m.matched) res_out = fabsf(m.fi);
     }
-    wrote_res = !need_carry;
+    wrote_res = !m.need_carry;
   }
-  return TvOut{f, jx, jy, jz, fi, res_out, mfwd, contrib, matched, need_carry, wrote_res};
+  return TvOut{f, jx, jy, jz, m.fi, res_out, m.mfwd, contrib, m.matched, m.need_carry, wrote_res};
+}
+__device__ __forceinline__ TvOut tv_finish(const KParams& p, const TvIn& k, const TvProj& pj, const TvGeo& ge, float res_in, float cin) {
+  return tv_weight(p, k, pj, tv_match(p, k, pj, ge), res_in, cin);
+}
+__device__ __forceinline__ TvOut try_vel_eval(const KParams& p, const MapDev& nm, const TvIn& k, float res_in, float cin, float vx,
+                                              float vy, float vz, float srm, float thr, unsigned min_matches) {
+  const TvProj pj = tv_project(p, k, vx, vy, vz, srm, thr, min_matches);
+  const TvGeo ge = tv_geometry(p, nm, tv_cell(nm, pj));
+  return tv_finish(p, k, pj, ge, res_in, cin);
 }
 
 // ---- Core::tryVel + calculatefJ + testfk (core.cpp:39-148) ---------------------------------------------------
@@ -1045,8 +1095,9 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
                                                    unsigned long long* __restrict__ stamps, int slow_poll) {
   constexpr int kChainGroups = kChainThreads / 256;
   constexpr int kWaves = kChainThreads / 64;
-  // REBVIO_HIP_LM_STAMPS: 1 start, 2/3 evaluations 0/1 published, 4 hypothesis states ready, 5 speculative evaluations published,
-  // 6 all record sets staged and reduced, 7 hypothesis checked, 8 LM done, 9 extRotVel rows out (stamps[0] = 1 marks the layout)
+  // REBVIO_HIP_LM_STAMPS: 1 start, 2/3 evaluations 0/1 published, 4 hypothesis states ready, speculative evaluations: 5 projected,
+  // 6 gathers issued, 7 matches known, 8 neighbour round done, 9 weighted sums done, 10 published; 11 all record sets staged and
+  // reduced, 12 hypothesis checked, 13 LM done, 14 extRotVel rows out (stamps[0] = 1 marks the layout)
 #define RH_STAMP(i) \
   do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   extern __shared__ float recm[];  // [nspec][cap * kPartStride] staged record sets (set 0 doubles as the ordinary collect's staging)
@@ -1060,6 +1111,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   __shared__ int whas[kWaves];
   __shared__ int shist[128];
   __shared__ int first_accept;
+  __shared__ float wsumk[kSpecMax][kWaves][10];  // speculative evaluations: per-wave sums, match flags, last fi, carry-in per group
+  __shared__ int whask[kSpecMax][kWaves];
+  __shared__ float wlastk[kSpecMax][kWaves];
+  __shared__ float carryk[kSpecMax + 1][kChainGroups];
 
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * kChainThreads + tid;
@@ -1102,13 +1157,12 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   auto set_words = [&](int call) { return xch + (size_t)call * nrec_launched * kPartStride; };
 
   // One evaluation at (vx, vy, vz): tryVel body, carry-forward, wave / workgroup sums, records published under `tag`.
-  // handoff: the NEXT evaluation follows in this pass without an exchange - resolve its carry-in through the neighbour words.
-  auto do_eval = [&](int call, unsigned tag, float vx, float vy, float vz, bool last, bool handoff) {
+  auto do_eval = [&](int call, unsigned tag, const TvProj& pj, const TvGeo& ge, bool last) {
     const float cin = carry_in[grp];
     TvOut e{};
     e.mfwd = -1;
     if (idx < n) {
-      e = try_vel_eval(p, nm, in, res, cin, vx, vy, vz, srm, thr, min_matches);
+      e = tv_finish(p, in, pj, ge, res, cin);
       if (e.wrote_res) res = e.res_out;
       if (last) {
         if (e.matched) {
@@ -1150,22 +1204,6 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       }
       res = r;
     }
-    // this workgroup's own last written fi (if any): out to the right neighbour at once when the next evaluation needs it
-    int own_has = 0;
-    float own_last = 0.f;
-    if (handoff && tid == kChainThreads - 1) {  // (a thread that publishes no record words below)
-      for (int w = kWaves - 1; w >= 0; --w)
-        if (whas[w]) {
-          own_has = 1;
-          own_last = wlast[w];
-          break;
-        }
-      if (own_has && (int)blockIdx.x + 1 < live_wgs) {
-        unsigned long long* cw = xch_carry + ((size_t)call * nwg + blockIdx.x) * 2;
-        xch_publish(cw, tag, 1.0f);
-        xch_publish(cw + 1, tag, own_last);
-      }
-    }
     if (tid < kChainGroups * 16) {
       if (last) __atomic_thread_fence(__ATOMIC_RELEASE);  // the forwardMatch keys issued before the __syncthreads above
       const int g = tid >> 4, k = tid & 15;
@@ -1185,30 +1223,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         xch_publish(out + k, tag, k == 10 ? hv : lv);
       }
     }
-    if (handoff && tid == kChainThreads - 1) {
-      // carry-in of this workgroup for the evaluation that follows: the left neighbour's word (workgroup 0: nothing before it)
-      float in_has = 0.f, in_fi = 0.f;
-      if (blockIdx.x > 0) {
-        const unsigned long long* cw = xch_carry + ((size_t)call * nwg + (blockIdx.x - 1)) * 2;
-        in_has = xch_wait(cw, tag, bar_err, slow_poll);
-        in_fi = xch_wait(cw + 1, tag, bar_err, slow_poll);
-      }
-      if (!own_has && (int)blockIdx.x + 1 < live_wgs) {  // nothing written here: what came in goes on to the right
-        unsigned long long* cw = xch_carry + ((size_t)call * nwg + blockIdx.x) * 2;
-        xch_publish(cw, tag, in_has);
-        xch_publish(cw + 1, tag, in_fi);
-      }
-      float c = (in_has != 0.f) ? fabsf(in_fi) : 0.f;
-      for (int g = 0; g < kChainGroups; ++g) {  // as reduce_staged_records derives it from the records: nearest earlier group with a match
-        carry_in[g] = c;
-        for (int w = 3; w >= 0; --w)
-          if (whas[g * 4 + w]) {
-            c = fabsf(wlast[g * 4 + w]);
-            break;
-          }
-      }
-    }
-    __syncthreads();  // wsum / whas / wlast are rewritten by the next evaluation; carry_in is set
+    __syncthreads();  // wsum / whas / wlast are rewritten by the next evaluation
   };
 
   // ordinary collect of one record set (+ carry-in per group) into recm[0 .. cap) / red
@@ -1225,7 +1240,13 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       if (tid == 0) lm_step(s, red, call, false);
       __syncthreads();
     }
-    do_eval(call, tag_of(call, phase), s.Vnew[0], s.Vnew[1], s.Vnew[2], call == calls - 1, false);
+    TvProj pj{};
+    TvGeo ge{};
+    if (idx < n) {
+      pj = tv_project(p, in, s.Vnew[0], s.Vnew[1], s.Vnew[2], srm, thr, min_matches);
+      ge = tv_geometry(p, nm, tv_cell(nm, pj));
+    }
+    do_eval(call, tag_of(call, phase), pj, ge, call == calls - 1);
   };
 
   const int nspec = calls - 2;  // evaluations 2 .. calls - 1 (the launcher guarantees 2 <= nspec <= kSpecMax)
@@ -1257,16 +1278,152 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     }
     __syncthreads();
     RH_STAMP(4);
+    // the gathers of all speculative evaluations in flight together: projections (no memory), then every field cell, then
+    // every matched keyline's geometry; what remains per evaluation is arithmetic and the workgroup / neighbour hand-offs
+    TvProj pj[kSpecMax];
+    unsigned cellkey[kSpecMax];
+    TvGeo ge[kSpecMax];
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k) {
+      pj[k] = TvProj{};
+      pj[k].cell = -1;
+      pj[k].skip = true;
+      if (k < nspec && idx < n) pj[k] = tv_project(p, in, stc[k].Vnew[0], stc[k].Vnew[1], stc[k].Vnew[2], srm, thr, min_matches);
+    }
+    RH_STAMP(5);
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k) cellkey[k] = tv_cell(nm, pj[k]);
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k) ge[k] = tv_geometry(p, nm, cellkey[k]);
+    // What an evaluation hands to the next one - who matched, the last written fi - does not depend on the residuals, so it is
+    // settled for ALL speculative evaluations first: one workgroup barrier and one neighbour round instead of one per
+    // evaluation. After that the residual / weight chain of a keyline is arithmetic on its own registers.
+    RH_STAMP(6);
+    TvMatch mt[kSpecMax];
+    float rcarry[kSpecMax];  // residual an unmatched keyline ends evaluation k with (|fi| of the last match before it, or the marker)
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k) {
+      mt[k] = tv_match(p, in, pj[k], ge[k]);
+      rcarry[k] = kResidualCarry;
+      if (k < nspec) {
+        const unsigned long long mm = __ballot(mt[k].matched);
+        const unsigned long long below = mm & ((1ull << lane) - 1ull);
+        const float fi_prev = __shfl(mt[k].fi, below ? (63 - __clzll((long long)below)) : 0);
+        const float fi_wlast = __shfl(mt[k].fi, mm ? (63 - __clzll((long long)mm)) : 0);
+        if (below) rcarry[k] = fabsf(fi_prev);
+        if (lane == 0) {
+          whask[k][wid] = mm ? 1 : 0;
+          wlastk[k][wid] = fi_wlast;
+        }
+        if (2 + k == calls - 1 && idx < n) {  // the side effects of the last evaluation (forwardMatch, edge_map.cpp:78-96)
+          if (mt[k].matched) {
+            const unsigned long long key = ((unsigned long long)order_key(in.rs.x) << 32) | (unsigned)idx;
+            atomicMax(&nm.fwd_key[mt[k].mfwd], key);
+          }
+          om.match_fwd[idx] = mt[k].mfwd;
+        }
+      }
+    }
+    RH_STAMP(7);
+    __syncthreads();
+    // thread kChainThreads - 1 - k: hand-off behind evaluation 2 + k (carry-in of evaluation 3 + k), as in do_eval
+    if (tid >= kChainThreads - (nspec - 1)) {
+      const int k = kChainThreads - 1 - tid;
+      const int call = 2 + k;
+      const unsigned tag = tag_of(call, 0);
+      int own_has = 0;
+      float own_last = 0.f;
+      for (int w = kWaves - 1; w >= 0; --w)
+        if (whask[k][w]) {
+          own_has = 1;
+          own_last = wlastk[k][w];
+          break;
+        }
+      unsigned long long* cw = xch_carry + ((size_t)call * nwg + blockIdx.x) * 2;
+      if (own_has && (int)blockIdx.x + 1 < live_wgs) {
+        xch_publish(cw, tag, 1.0f);
+        xch_publish(cw + 1, tag, own_last);
+      }
+      float in_has = 0.f, in_fi = 0.f;
+      if (blockIdx.x > 0) {
+        const unsigned long long* lw = xch_carry + ((size_t)call * nwg + (blockIdx.x - 1)) * 2;
+        in_has = xch_wait(lw, tag, bar_err, slow_poll);
+        in_fi = xch_wait(lw + 1, tag, bar_err, slow_poll);
+      }
+      if (!own_has && (int)blockIdx.x + 1 < live_wgs) {
+        xch_publish(cw, tag, in_has);
+        xch_publish(cw + 1, tag, in_fi);
+      }
+      float c = (in_has != 0.f) ? fabsf(in_fi) : 0.f;
+      for (int g = 0; g < kChainGroups; ++g) {
+        carryk[k + 1][g] = c;
+        for (int w = 3; w >= 0; --w)
+          if (whask[k][g * 4 + w]) {
+            c = fabsf(wlastk[k][g * 4 + w]);
+            break;
+          }
+      }
+    }
+    if (tid < kChainGroups) carryk[0][tid] = carry_in[tid];  // evaluation 2: from the records of evaluation 1 (collect above)
+    __syncthreads();
+    RH_STAMP(8);
     float res_hist[kSpecMax];
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k) {
       if (k < nspec) {
-        const int c = 2 + k;
-        do_eval(c, tag_of(c, 0), stc[k].Vnew[0], stc[k].Vnew[1], stc[k].Vnew[2], c == calls - 1, k + 1 < nspec);
+        TvOut e{};
+        if (idx < n) {
+          e = tv_weight(p, in, pj[k], mt[k], res, carryk[k][grp]);
+          if (e.wrote_res) res = e.res_out;
+        }
+        if (mt[k].need_carry) {  // (false for idx >= n: those never pass tv_project)
+          float r = rcarry[k];
+          if (r == kResidualCarry) {
+            for (int w = wig - 1; w >= 0; --w)
+              if (whask[k][grp * 4 + w]) {
+                r = fabsf(wlastk[k][grp * 4 + w]);
+                break;
+              }
+          }
+          res = r;
+        }
         res_hist[k] = res;
+        const float sc = e.contrib ? e.f * e.f : 0.f;
+        float v[10] = {sc, e.jx * e.jx, e.jy * e.jy, e.jz * e.jz, e.jx * e.jy, e.jx * e.jz, e.jy * e.jz, e.jx * e.f, e.jy * e.f, e.jz * e.f};
+        wave_total63_fN(v);
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < 10; ++q) wsumk[k][wid][q] = v[q];
+        }
       }
     }
-    RH_STAMP(5);
+    RH_STAMP(9);
+    __syncthreads();
+    if (tid < kChainGroups * 16) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);  // the forwardMatch keys of the last evaluation, issued before the barriers above
+      const int g = tid >> 4, q = tid & 15;
+      for (int k = 0; k < nspec; ++k) {
+        const int call = 2 + k;
+        const unsigned tag = tag_of(call, 0);
+        unsigned long long* out = set_words(call) + ((size_t)blockIdx.x * kChainGroups + g) * kPartStride;
+        if (q < 10) {
+          float acc = 0.f;
+          for (int w = 0; w < 4; ++w) acc += wsumk[k][g * 4 + w][q];
+          xch_publish(out + q, tag, acc);
+        } else if (q == 10 || q == 11) {
+          float hv = 0.f, lv = 0.f;
+          for (int w = 3; w >= 0; --w)
+            if (whask[k][g * 4 + w]) {
+              hv = 1.f;
+              lv = wlastk[k][g * 4 + w];
+              break;
+            }
+          xch_publish(out + q, tag, q == 10 ? hv : lv);
+        }
+      }
+    }
+    __syncthreads();  // (the roll-back path reuses the staging arrays)
+    RH_STAMP(10);
     // all nspec record sets at once: every thread first issues its loads together, then waits for the stragglers
     {
       const int total = nspec * cap;
@@ -1299,7 +1456,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       }
       __syncthreads();
     }
-    RH_STAMP(6);
+    RH_STAMP(11);
     // the hypothesis against the real scores: the gain test of core.cpp:172 on the state the evaluation started from
     {
       bool accepted = false;
@@ -1318,7 +1475,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       __syncthreads();
     }
     fa = first_accept;
-    RH_STAMP(7);
+    RH_STAMP(12);
     if (fa < 0) {
       if (tid == 0) {  // every evaluation rejected: the last rejection is the final step of core.cpp:166-185 (no new trial point)
         LmState t = stc[nspec - 1];
@@ -1335,7 +1492,9 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
 #pragma unroll
       for (int k = 0; k < kSpecMax; ++k)
         if (k == fa) res = res_hist[k];
-      for (int i = blockIdx.x * kChainThreads + tid; i < p.kmax; i += live_wgs * kChainThreads) nm.fwd_key[i] = 0ull;
+      // (fa == nspec - 1: the accepted evaluation is the last one - its trial point was the real one, its keys stand)
+      if (fa < nspec - 1)
+        for (int i = blockIdx.x * kChainThreads + tid; i < p.kmax; i += live_wgs * kChainThreads) nm.fwd_key[i] = 0ull;
       __syncthreads();
       if (tid == 0) {
         __atomic_thread_fence(__ATOMIC_RELEASE);
@@ -1358,7 +1517,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       slot->old_st = *om.st;
     }
   }
-  RH_STAMP(8);
+  RH_STAMP(13);
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
   if (blockIdx.x == 0 && tid < 3) xch_publish(xch_final + tid, tag_final, s.vel[tid]);
   if (!lm_live) {
@@ -1398,7 +1557,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
     }
   }
-  RH_STAMP(9);
+  RH_STAMP(14);
   if (stamps && blockIdx.x == 0 && tid == 0) stamps[0] = 1ull;
 #undef RH_STAMP
 }
@@ -2299,9 +2458,13 @@ void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const 
                      LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
                      PairSlot* slot, int* hist_to_zero, unsigned long long* stamps) {
   const dim3 grid(lm_chain_grid(p.kmax));
-  if (do_ext == 2 && lm_chain_threads() == 512 && lm_spec_usable(p.kmax, calls)) {
-    RH_LAUNCH(k_lm_chain_spec<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out, xch,
-              tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
+  if (do_ext == 2 && lm_chain_threads() <= 512 && lm_spec_usable(p.kmax, calls)) {
+    if (lm_chain_threads() == 256)
+      RH_LAUNCH(k_lm_chain_spec<256>, grid, dim3(256), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out,
+                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
+    else
+      RH_LAUNCH(k_lm_chain_spec<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out,
+                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
     return;
   }
   switch (lm_chain_threads()) {
