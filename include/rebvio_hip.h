@@ -231,14 +231,20 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, r
  * its counters / status (what rebvio.cpp:245-259 needs for the "insufficient matches" stop and what the odometry record carries).
  * Allowed order: begin(k), finish_async(k), begin(k+1), result(k), finish_async(k+1), ... - one result may be outstanding.
  * Between _begin and _finish(_async) of a pair only _result of the previous pair may be called.
- * (REBVIO_HIP_PAIR_PRELAUNCH=1, opt-in for single-threaded hosts: _begin queues the second half itself, parked behind a pinned
- * flag that _finish releases - no other thread may synchronise with the context's track stream meanwhile.) */
+ * A pair's match counters ride to the host in the NEXT pair's first-half record when that pair continues from this pair's new
+ * map (no copy, no extra wait); otherwise _begin / _result copy them.
+ * (REBVIO_HIP_PAIR_PRELAUNCH=1, opt-in: _begin queues the second half itself, parked behind a pinned flag that _finish
+ * releases; the library's own waits for the track stream poll meanwhile, see DESIGN.md. Measured no faster than the default.) */
 /* R_prior_next (may be NULL): the IMU inter-frame rotation the NEXT pair's _begin will be given as R_prior, when the caller
  * already has it. That pair's first rotateKeylines (rebvio.cpp:163-165) then runs inside this pair's last kernel and its
  * _begin launches one kernel less; _begin returns -7 if its R_prior (or the gyro state) does not match what was applied. */
 int rebvio_hip_track_pair_finish_async(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, rebvio_hip_map* new_map, const float V[3],
                                        const float P_V[9], const float Rgva[9], const float R_second[9], const float* R_prior_next);
 int rebvio_hip_track_pair_result(rebvio_hip_ctx* ctx, int* klm_num, int* kf_matches, int* reg_num, int* status);
+/* Optional, before _finish(_async) of a pair: the map the NEXT pair will track as its new map (already handed to detect).
+ * The track stream's wait for that map's detection is queued now, ahead of this pair's second half, instead of between the two
+ * pairs (one barrier packet less on the pair-to-pair path). The reference has no counterpart: its maps are host objects. */
+int rebvio_hip_track_pair_hint_next(rebvio_hip_ctx* ctx, rebvio_hip_map* next_new_map);
 
 /* Streaming driver used by the bench: a software pipeline, detect(frame) on the scan / keyline streams overlapped with
  * the tracking of EARLIER pairs on the track stream. `out` receives the most recent COMPLETE pair, in pair order, several

@@ -98,6 +98,7 @@ SIGNATURES = {
     "rebvio_hip_track_pair_finish": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _fp, _ip, _ip, _ip, _ip]),
     "rebvio_hip_track_pair_finish_async": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _fp, _fp]),
     "rebvio_hip_track_pair_result": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "rebvio_hip_track_pair_hint_next": (C.c_int, [_vp, _vp]),
     "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_flush": (C.c_int, [_vp]),
     "rebvio_hip_batch_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(_vp)]),

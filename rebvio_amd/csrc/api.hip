@@ -166,6 +166,9 @@ struct rebvio_hip_map {
   int n_host = -1;
   float thr_host = -1.0f;
   bool trk_waited = false;  // the track stream already holds a wait on `ready` (a second one is another barrier packet)
+  // set once any track-stream operation referencing this map has been enqueued: until then a download only has to wait for
+  // the map's own detection (`ready`), not for the track stream (which may hold another pair's parked second half)
+  std::atomic<bool> trk_touched{false};
   hm::M3 pre_R{};           // ... with this rotation (per-pair API: checked against the prior the next _begin is given)
   int tab_idx = -1;         // entry of this map in its lane's device map table (batch driver)
   MapDev canon{};           // ... as uploaded there (the live `d` differs from it by the ping-pong swaps only)
@@ -176,6 +179,9 @@ struct rebvio_hip_ctx {
   KParams K{};
   int device = 0;
   hipStream_t s_det{}, s_key{}, s_df{}, s_trk{}, s_cpy{};
+  double t_begin_enq = 0, t_begin_wait = 0;  // REBVIO_HIP_DEBUG: host time of track_pair_begin (enqueue / wait for the first half)
+  uint64_t t_begin_n = 0;
+  std::mutex dl_mu;             // rebvio_hip_map_download: aos_dev
   bool scan_split = true;       // last column pass + k_dog_mag on s_key (detect_launch)
   float* sa2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [frame parity][filter]: sb.a per parity ([0] aliases sb.a)
   // scale-space outputs (DoG, squared gradient, per-row counts) are double buffered: the scans of frame f+1 (s_det)
@@ -200,6 +206,7 @@ struct rebvio_hip_ctx {
   void* pin[kPin]{};
   hipEvent_t pin_ev[kPin]{};
   bool pin_used[kPin]{};
+  std::atomic<int> pin_staged[kPin]{};  // 1: the slot holds a frame whose host-to-device copy the detect worker has not queued yet
   uint64_t pin_next = 0;
   int2* undist_map = nullptr;      // fixed-point source coordinates (null: no lens distortion, front end = x3 only)
   float* undist_img[2]{};          // undistorted fp32 frame, double-buffered like dog2 / mag2
@@ -275,6 +282,8 @@ struct rebvio_hip_ctx {
     const DetState* det_in;
     DetState* det_out;
     const MapState* prev_st;
+    int pin_slot = -1;      // host-frame entries: pinned ring slot to copy to `img` (device staging frame) ahead of the scans
+    size_t pin_bytes = 0;
   };
   std::thread det_thread;
   std::mutex det_mu;
@@ -289,7 +298,11 @@ struct rebvio_hip_ctx {
   uint64_t t_frames = 0;
   bool owns_streams = true;  // false for the lanes of a batch (rebvio_hip_batch_*)
   // track_pair_begin / _finish with the second half parked behind a wait on glue_flag[kSlots - 1] (see track_pair_begin)
-  bool bf_parked = false;
+  std::atomic<bool> bf_parked{false};
+  std::thread::id bf_park_thread;             // the thread whose _begin parked the second half (it must not wait for the track stream)
+  rebvio_hip_map* bf_map[2] = {nullptr, nullptr};  // new map of the pair whose counters result slot r will report
+  bool bf_have[2] = {false, false};           // h_bf[r] already holds them (taken from the next pair's slot, or copied)
+  bool bf_copy_queued[2] = {false, false};    // a device-to-host copy + bf_done[r] are queued for them
   unsigned bf_seq = 0, bf_counter = 0;
   // two result slots: the next pair's first half (and its parked second half) may be queued before the caller fetches the
   // previous pair's counters (rebvio_hip_track_pair_finish_async / _result)
@@ -327,6 +340,21 @@ void release_parked_pair(rebvio_hip_ctx* c) {
   gl.nan_v = 1;
   write_glue_and_flag(c, rebvio_hip_ctx::kSlots - 1, c->bf_seq, gl);
   c->bf_parked = false;
+}
+
+// Wait for the track stream by polling. A thread sitting inside hipStreamSynchronize on a stream that holds a parked second
+// half (track_pair_begin) blocked the fusion thread's next runtime call and with it the release of that second half
+// (observed with rebvio::Rebvio's two workers); hipStreamQuery holds nothing while it waits. The thread that parked the
+// pair must finish it first: waiting here would be waiting for itself.
+int trk_sync(rebvio_hip_ctx* c) {
+  if (c->bf_parked.load(std::memory_order_acquire) && c->bf_park_thread == std::this_thread::get_id())
+    return fail_msg("a pair is in flight on this thread (track_pair_begin): call track_pair_finish before anything that waits for the track stream", -7);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(c->s_trk);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) HIPCHK(e);
+    std::this_thread::yield();
+  }
 }
 
 int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
@@ -401,6 +429,7 @@ rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
     m->n_host = -1;
     m->thr_host = -1.0f;
     m->trk_waited = false;
+    m->trk_touched.store(false, std::memory_order_relaxed);  // (its previous life drained before its detection: m->done)
     return m;
   }
   // every pooled map is alive (a caller queues detections faster than it tracks, like the reference's unbounded
@@ -437,6 +466,19 @@ int fetch_map_state(rebvio_hip_map* m, MapState* out, hipStream_t after) {
   return 0;
 }
 
+// Every use of a map on the track stream starts with this wait on its detection (+ distance field).
+hipError_t trk_wait_ready(hipStream_t s, rebvio_hip_map* m) {
+  m->trk_touched.store(true, std::memory_order_release);
+  return hipStreamWaitEvent(s, m->ready, 0);
+}
+// The same, once per map and context stream: every wait is a barrier packet of its own between two kernels of the track
+// stream (~2 us each on the pair-to-pair critical path); `ready` is recorded once per detection, a second wait adds nothing.
+hipError_t trk_wait_ready_once(rebvio_hip_ctx* c, rebvio_hip_map* m) {
+  if (m->trk_waited) return hipSuccess;
+  m->trk_waited = true;
+  return trk_wait_ready(c->s_trk, m);
+}
+
 int ensure_size(rebvio_hip_map* m) {
   if (m->n_host >= 0) return 0;
   MapState st;
@@ -457,6 +499,11 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   }
   DetectBufs db = c->db;
   db.rowcount = c->rowcount2[b];
+  if (j.pin_slot >= 0) {  // host frame: pinned slot -> device staging frame, read by this stream's own kernels only
+    HIPCHK(hipMemcpyAsync(const_cast<void*>(j.img), c->pin[j.pin_slot], j.pin_bytes, hipMemcpyHostToDevice, c->s_det));
+    HIPCHK(hipEventRecord(c->pin_ev[j.pin_slot], c->s_det));
+    c->pin_staged[j.pin_slot].store(0, std::memory_order_release);
+  }
   // scans of this frame (s_det); its DoG / gradient buffers were last read by the candidate kernel two frames ago
   if (c->ev_flag_used[b]) HIPCHK(hipStreamWaitEvent(c->s_det, c->ev_flag[b], 0));
   const void* img = j.img;
@@ -673,7 +720,9 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
 // memory is staged inside the runtime, which stays busy for the whole transfer and stalls the launches of the tracking
 // thread of rebvio::Rebvio (measured: second half of the pair step 215 us -> 47 us); it also must not outlive the caller's
 // buffer. The device staging frames are read by the scan stream's own kernels only, so stream order is reuse order.
-int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, size_t row_bytes, void* dst_dev) {
+// Host half (caller's thread): frame -> pinned ring slot. The copy to the device and the reuse event are queued by whoever
+// launches the frame's detection (detect_launch), in stream order with its kernels.
+int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, size_t row_bytes, int* slot_out, size_t* bytes_out) {
   if (!c->pin[0]) {
     for (int i = 0; i < rebvio_hip_ctx::kPin; ++i) {
       HIPCHK(hipHostMalloc(&c->pin[i], (size_t)c->P.rows * c->P.cols * sizeof(float), hipHostMallocDefault));
@@ -681,6 +730,7 @@ int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, siz
     }
   }
   const int ps = (int)(c->pin_next++ % rebvio_hip_ctx::kPin);
+  while (c->pin_staged[ps].load(std::memory_order_acquire)) std::this_thread::yield();  // the worker is kPin frames behind
   if (c->pin_used[ps]) HIPCHK(hipEventSynchronize(c->pin_ev[ps]));  // its previous copy has left the slot
   uint8_t* dst = static_cast<uint8_t*>(c->pin[ps]);
   const uint8_t* src = static_cast<const uint8_t*>(img);
@@ -688,9 +738,49 @@ int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, siz
     std::memcpy(dst, src, (size_t)c->P.rows * row_bytes);
   else
     for (int r = 0; r < c->P.rows; ++r) std::memcpy(dst + (size_t)r * row_bytes, src + (size_t)r * pitch_bytes, row_bytes);
-  HIPCHK(hipMemcpyAsync(dst_dev, dst, (size_t)c->P.rows * row_bytes, hipMemcpyHostToDevice, c->s_det));
-  HIPCHK(hipEventRecord(c->pin_ev[ps], c->s_det));
   c->pin_used[ps] = true;
+  c->pin_staged[ps].store(1, std::memory_order_release);
+  *slot_out = ps;
+  *bytes_out = (size_t)c->P.rows * row_bytes;
+  return 0;
+}
+
+// Detection of a host frame: staged here and launched by the caller, or (REBVIO_HIP_DETECT_ASYNC=1) by the context's detect
+// worker, so that the ~20 runtime calls of a frame's detection do not sit on the thread that stages the frames. Measured
+// with rebvio::Rebvio (tools/host_class_probe.py): the acquisition thread drops from 58-107 to 23-30 us per frame, but the
+// fusion thread's own launches slow down by as much (runtime calls of different threads largely serialise: its second half
+// 12 -> 26 us) and the class's rate stays where it was (7.7-8.4k frames/s either way) - hence opt-in. Everything that reads
+// the map waits for the launch (wait_enqueued); a worker-side error surfaces at the next detect call.
+int detect_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, size_t row_bytes, void* dst_dev, int is_u8, uint64_t ts,
+                      rebvio_hip_map** out) {
+  static const bool sync_mode = !(std::getenv("REBVIO_HIP_DETECT_ASYNC") && std::atoi(std::getenv("REBVIO_HIP_DETECT_ASYNC")) != 0);
+  {
+    std::lock_guard<std::mutex> lk(c->det_mu);
+    if (!c->det_error.empty()) return fail_msg(c->det_error.c_str(), -8);
+  }
+  rebvio_hip_ctx::DetJob job;
+  int rc = stage_host_frame(c, img, pitch_bytes, row_bytes, &job.pin_slot, &job.pin_bytes);
+  if (rc) return rc;
+  rc = detect_prepare(c, dst_dev, is_u8, ts, &job);
+  if (rc) {
+    c->pin_staged[job.pin_slot].store(0, std::memory_order_release);
+    return rc;
+  }
+  if (sync_mode) {
+    while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    rc = detect_launch(c, job);
+    if (rc) return rc;
+  } else {
+    if (!c->det_thread.joinable()) c->det_thread = std::thread(det_worker_main, c);
+    job.m->enqueued.store(0, std::memory_order_relaxed);
+    c->det_pending.fetch_add(1, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(c->det_mu);
+      c->det_jobs.push_back(job);
+    }
+    c->det_cv.notify_one();
+  }
+  *out = job.m;
   return 0;
 }
 
@@ -987,6 +1077,9 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   release_parked_pair(c);
+  if (std::getenv("REBVIO_HIP_DEBUG") && c->t_begin_n)
+    std::fprintf(stderr, "[rebvio_hip] track_pair_begin over %llu pairs (us): enqueue %.1f  wait for the first half %.1f\n",
+                 (unsigned long long)c->t_begin_n, c->t_begin_enq / c->t_begin_n, c->t_begin_wait / c->t_begin_n);
   if (c->det_thread.joinable()) {
     {
       std::lock_guard<std::mutex> lk(c->det_mu);
@@ -1081,9 +1174,7 @@ int rebvio_hip_detect(rebvio_hip_ctx* c, const float* img, size_t pitch_bytes, u
   HIPCHK(hipSetDevice(c->device));
   const size_t rowb = (size_t)c->P.cols * sizeof(float);
   if (pitch_bytes == 0) pitch_bytes = rowb;
-  int rc = stage_host_frame(c, img, pitch_bytes, rowb, c->img_dev);
-  if (rc) return rc;
-  return detect_common(c, c->img_dev, 0, ts_us, out);
+  return detect_host_frame(c, img, pitch_bytes, rowb, c->img_dev, 0, ts_us, out);
 }
 
 int rebvio_hip_detect_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_map** out) {
@@ -1095,9 +1186,7 @@ int rebvio_hip_detect_u8(rebvio_hip_ctx* c, const uint8_t* img, size_t pitch_byt
   HIPCHK(hipSetDevice(c->device));
   const size_t rowb = (size_t)c->P.cols;
   if (pitch_bytes == 0) pitch_bytes = rowb;
-  int rc = stage_host_frame(c, img, pitch_bytes, rowb, c->img8_dev);
-  if (rc) return rc;
-  return detect_common(c, c->img8_dev, 1, ts_us, out);
+  return detect_host_frame(c, img, pitch_bytes, rowb, c->img8_dev, 1, ts_us, out);
 }
 
 int rebvio_hip_set_undistort(rebvio_hip_ctx* c, const float K4[4], const float D5[5]) {
@@ -1172,11 +1261,20 @@ int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int
   HIPCHK(hipSetDevice(c->device));
   int rc = ensure_size(m);
   if (rc) return rc;
-  // mirror reflects everything enqueued so far on every stream
-  HIPCHK(hipStreamSynchronize(c->s_det));
-  HIPCHK(hipStreamSynchronize(c->s_key));
-  HIPCHK(hipStreamSynchronize(c->s_df));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  // The mirror reflects everything enqueued so far that concerns THIS map: its detection and distance field (`ready`,
+  // recorded behind them; ensure_size has waited for the detect worker to enqueue them) and, once the tracker has used the
+  // map, the track stream. A map fresh from detect() (edge-image callbacks, ros_rebvio.cpp:32-50) does not wait for the
+  // tracker - which may be a pair ahead, or hold a second half parked until the fusion thread releases it.
+  if (m->trk_touched.load(std::memory_order_acquire) || !c->owns_streams) {
+    HIPCHK(hipStreamSynchronize(c->s_det));
+    HIPCHK(hipStreamSynchronize(c->s_key));
+    HIPCHK(hipStreamSynchronize(c->s_df));
+    { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
+  } else {
+    wait_enqueued(m);
+    HIPCHK(hipEventSynchronize(m->ready));
+  }
+  std::lock_guard<std::mutex> dl(c->dl_mu);  // one packing buffer per context (callbacks and the fusion thread may both mirror maps)
   if (keylines && m->n_host > 0) {
     launch_map_pack(c->s_cpy, c->K, m->d, c->aos_dev);
     HIPCHK(hipMemcpyAsync(keylines, c->aos_dev, (size_t)m->n_host * sizeof(rebvio_hip_keyline), hipMemcpyDeviceToHost, c->s_cpy));
@@ -1193,7 +1291,7 @@ int rebvio_hip_render_edge_image(rebvio_hip_map* m, const uint8_t* gray, uint8_t
   HIPCHK(hipStreamSynchronize(c->s_det));  // the staging frame and the scratch are shared with the detect path
   HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_df));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   const size_t Pn = (size_t)c->P.rows * c->P.cols;
   uint8_t* rgb = reinterpret_cast<uint8_t*>(c->scratch_i);  // 8 bytes/pixel available, 3 used
   if (gray) HIPCHK(hipMemcpyAsync(c->img8_dev, gray, Pn, hipMemcpyHostToDevice, c->s_cpy));
@@ -1213,7 +1311,7 @@ int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines,
   HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_key));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   if (n > 0) {
     HIPCHK(hipMemcpyAsync(c->aos_dev, keylines, (size_t)n * sizeof(rebvio_hip_keyline), hipMemcpyHostToDevice, c->s_cpy));
     launch_map_unpack(c->s_cpy, c->K, m->d, c->aos_dev, n);
@@ -1238,7 +1336,8 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
 
 int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  wait_enqueued(m);
+  HIPCHK(trk_wait_ready_once(c, m));
   static const bool force = std::getenv("REBVIO_HIP_DF_FORCE") != nullptr;  // diagnostic: rebuild on every call (tools/df_probe.py)
   if (!m->df_built || force) {
     if (!m->raster_order) HIPCHK(hipMemsetAsync(m->d.df, 0xFF, (size_t)c->P.rows * c->P.cols * sizeof(unsigned), c->s_trk));
@@ -1258,7 +1357,7 @@ int rebvio_hip_distance_field(rebvio_hip_ctx* c, int* id_out, int* dist_out) {
   HIPCHK(hipGetLastError());
   if (id_out) HIPCHK(hipMemcpyAsync(id_out, c->scratch_i, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
   if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, c->scratch_i + Pn, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   return 0;
 }
 
@@ -1267,13 +1366,13 @@ int rebvio_hip_map_distance_field(rebvio_hip_map* m, int* id_out, int* dist_out)
   HIPCHK(hipSetDevice(c->device));
   if (!m->df_built) return fail_msg("map_distance_field: no distance field has been built from this map", -7);
   wait_enqueued(m);
-  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, m));
   const size_t Pn = (size_t)c->P.rows * c->P.cols;
   launch_df_decode(c->s_trk, c->K, m->d, c->scratch_i, c->scratch_i + Pn);
   HIPCHK(hipGetLastError());
   if (id_out) HIPCHK(hipMemcpyAsync(id_out, c->scratch_i, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
   if (dist_out) HIPCHK(hipMemcpyAsync(dist_out, c->scratch_i + Pn, Pn * sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   return 0;
 }
 
@@ -1282,12 +1381,12 @@ int rebvio_hip_search_match(rebvio_hip_ctx* c, rebvio_hip_map* searched, const r
   HIPCHK(hipSetDevice(c->device));
   if (!(query->gradient_norm > 0.0f)) return fail_msg("search_match: the query keyline needs a positive gradient_norm", -3);
   wait_enqueued(searched);
-  HIPCHK(hipStreamWaitEvent(c->s_trk, searched->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, searched));
   int* out_dev = reinterpret_cast<int*>(c->fscratch) + 32;
   launch_search_match_one(c->s_trk, c->K, searched->d, *query, vel, Rvel, Rback, max_radius, out_dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_f + 32, out_dev, sizeof(int), hipMemcpyDeviceToHost, c->s_trk));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   std::memcpy(idx_out, c->h_f + 32, sizeof(int));
   return 0;
 }
@@ -1319,7 +1418,7 @@ int rebvio_hip_smooth(rebvio_hip_ctx* c, const float* img, const int widths3[3],
 
 int rebvio_hip_rotate(rebvio_hip_ctx* c, rebvio_hip_map* m, const float R[9]) {
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, m));
   launch_rotate(c->s_trk, c->K, m->d, R, nullptr, 0);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1328,12 +1427,12 @@ int rebvio_hip_rotate(rebvio_hip_ctx* c, rebvio_hip_map* m, const float R[9]) {
 int rebvio_hip_quantile(rebvio_hip_ctx* c, rebvio_hip_map* m, float percentile, int num_bins, float* out) {
   HIPCHK(hipSetDevice(c->device));
   if (num_bins < 1 || num_bins > 128) return fail_msg("num_bins must be in 1..128", -3);
-  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, m));
   launch_quantile(c->s_trk, c->K, m->d, c->hist, percentile, num_bins, c->fscratch);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_f, c->fscratch, sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
   HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));  // invariant: the histogram is zero between uses
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   *out = c->h_f[0];
   return 0;
 }
@@ -1345,7 +1444,7 @@ int rebvio_hip_try_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, const float vel[3],
   int rc = ensure_size(m);
   if (rc) return rc;
   const int n = m->n_host;
-  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, m));
   if (n > 0) HIPCHK(hipMemcpyAsync(m->d.residual, residuals, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->s_trk));
   LmState st;
   std::memset(&st, 0, sizeof(st));
@@ -1358,7 +1457,7 @@ int rebvio_hip_try_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, const float vel[3],
   const int nb = std::max(1, div_up(n, 256));
   HIPCHK(hipMemcpyAsync(c->h_part, c->part, (size_t)nb * kPartStride * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
   if (n > 0) HIPCHK(hipMemcpyAsync(residuals, m->d.residual, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   for (int k = 0; k < 10; ++k) {
     float acc = 0.f;  // same fixed order as the device-side reducer
     for (int b = 0; b < div_up(n, 256); ++b) acc += c->h_part[(size_t)b * kPartStride + k];
@@ -1379,7 +1478,7 @@ int rebvio_hip_minimize_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, float vel[3], 
                             float* sigma_rho_min) {
   HIPCHK(hipSetDevice(c->device));
   if (!c->df_map) return fail_msg("minimize_vel needs a distance field", -7);
-  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, m));
   HIPCHK(hipMemsetAsync(m->d.residual, 0, (size_t)c->P.keylines_max * sizeof(float), c->s_trk));
   HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));
   // histogram of sigma_rho for estimateQuantile (core.cpp:153)
@@ -1391,15 +1490,15 @@ int rebvio_hip_minimize_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, float vel[3], 
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(&c->h_lm[0], c->lm + calls + 1, sizeof(LmState), hipMemcpyDeviceToHost, c->s_trk));
   HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));  // invariant: the histogram is zero between uses
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   lm_to_out(c->h_lm[0], vel, Rvel, F, accept_mask, sigma_rho_min);
   return 0;
 }
 
 int rebvio_hip_forward_match(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm) {
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamWaitEvent(c->s_trk, om->ready, 0));
-  HIPCHK(hipStreamWaitEvent(c->s_trk, nm->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, om));
+  HIPCHK(trk_wait_ready(c->s_trk, nm));
   launch_forward_keys(c->s_trk, c->K, om->d, nm->d);
   const float v0[3] = {0, 0, 0};
   launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 0, 0, c->lm, c->lm, c->part, c->xrv_part, v0, nullptr, nullptr);
@@ -1417,7 +1516,7 @@ int rebvio_hip_ext_rot_vel(rebvio_hip_ctx* c, const float vel[3], float Wx[36], 
   HIPCHK(hipGetLastError());
   const int nb = std::max(1, div_up(nm->n_host, 256));
   HIPCHK(hipMemcpyAsync(c->h_xrv, c->xrv_part, (size_t)nb * kXrvStride * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   float jtf[6];
   sum_xrv(c->h_xrv, div_up(nm->n_host, 256), Wx, jtf, nullptr);
   if (JtF) std::memcpy(JtF, jtf, sizeof(jtf));
@@ -1432,8 +1531,8 @@ int rebvio_hip_ext_rot_vel(rebvio_hip_ctx* c, const float vel[3], float Wx[36], 
 int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_map* om, const float vel[3],
                               const float Rvel[9], const float Rback[9], float max_radius, int* matches, int* kf_matches) {
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamWaitEvent(c->s_trk, om->ready, 0));
-  HIPCHK(hipStreamWaitEvent(c->s_trk, nm->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, om));
+  HIPCHK(trk_wait_ready(c->s_trk, nm));
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, vel, Rvel, Rback, vel_r, Rvel_r);
   HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 3 * sizeof(int), c->s_trk));
@@ -1450,7 +1549,7 @@ int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_
 
 int rebvio_hip_regularize(rebvio_hip_ctx* c, rebvio_hip_map* m, int* count) {
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamWaitEvent(c->s_trk, m->ready, 0));
+  HIPCHK(trk_wait_ready(c->s_trk, m));
   HIPCHK(hipMemsetAsync(&m->d.st->reg_count, 0, sizeof(int), c->s_trk));
   launch_regularize(c->s_trk, c->K, m->d, 0, nullptr);
   HIPCHK(hipGetLastError());
@@ -1560,8 +1659,8 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   HIPCHK(hipSetDevice(c->device));
   std::memset(out, 0, sizeof(*out));
   hipStream_t s = c->s_trk;
-  HIPCHK(hipStreamWaitEvent(s, om->ready, 0));
-  HIPCHK(hipStreamWaitEvent(s, nm->ready, 0));
+  HIPCHK(trk_wait_ready(s, om));
+  HIPCHK(trk_wait_ready(s, nm));
   int rc = rebvio_hip_build_distance_field(c, nm);  // rebvio.cpp:142 (no-op when detect already built it)
   if (rc) return rc;
   const hm::M3 R = prior_rotation(c, R_prior);
@@ -1596,6 +1695,7 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
 int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float* R_prior, float frame_dt,
                                 rebvio_hip_pair_mid* mid) {
   HIPCHK(hipSetDevice(c->device));
+  const auto tb0 = std::chrono::steady_clock::now();
   std::memset(mid, 0, sizeof(*mid));
   hipStream_t s = c->s_trk;
   release_parked_pair(c);  // (a previous begin that never saw its finish)
@@ -1604,10 +1704,20 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
     for (auto& e : c->bf_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   c->bf_cur = (c->bf_res == 0) ? 1 : 0;  // the slot that does not hold an unfetched result
+  // The previous pair's match counters (unfetched: result slot bf_res). If this pair continues from its new map they arrive
+  // for free with this pair's slot (the first-half kernel copies its old map's state record into pinned memory); otherwise a
+  // copy is queued here, AHEAD of this pair (and of its parked second half).
+  const int pr = c->bf_res;
+  const bool prev_from_slot = pr >= 0 && !c->bf_have[pr] && !c->bf_copy_queued[pr] && c->bf_map[pr] == om;
+  if (pr >= 0 && !c->bf_have[pr] && !c->bf_copy_queued[pr] && !prev_from_slot) {
+    HIPCHK(hipMemcpyAsync(&c->h_bf[pr], c->bf_map[pr]->d.st, sizeof(MapState), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->bf_done[pr], s));
+    c->bf_copy_queued[pr] = true;
+  }
   wait_enqueued(om);
   wait_enqueued(nm);
-  HIPCHK(hipStreamWaitEvent(s, om->ready, 0));
-  HIPCHK(hipStreamWaitEvent(s, nm->ready, 0));
+  HIPCHK(trk_wait_ready_once(c, om));
+  HIPCHK(trk_wait_ready_once(c, nm));
   int rc = rebvio_hip_build_distance_field(c, nm);
   if (rc) return rc;
   const hm::M3 R = prior_rotation(c, R_prior);
@@ -1631,24 +1741,33 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   if (c->prelaunch_b && park_pairs) {
     // OPT-IN (REBVIO_HIP_PAIR_PRELAUNCH=1): the second half is queued NOW, parked behind a wait on a pinned flag, and reads what
     // the caller passes to _finish from memory at run time: no kernel launch sits between the caller's inertial fusion and the
-    // matching kernels (the streaming driver's scheme, see enqueue_a_chain). Only for hosts whose OTHER threads never
-    // synchronise with the track stream meanwhile: a thread inside hipStreamSynchronize on the parked stream (e.g. an edge-image
-    // callback reading a keyline mirror, rebvio_hip_map_download) and this thread enqueueing behind the wait block each
-    // other for good - observed with rebvio::Rebvio's two workers, which is why the default is off. What matters for the rate is
-    // _finish_async (the next pair's first half queued behind this pair's second half), which needs no parking.
+    // matching kernels (the streaming driver's scheme, see enqueue_a_chain). Measured with rebvio::Rebvio (tools/
+    // host_class_probe.py, 4000 frames, two runs each): 7.97k / 8.36k frames/s parked, 8.40k / 9.16k with _finish_async
+    // launching the second half itself - the command processor takes as long to notice the flag as a launch takes to reach
+    // the GPU, and the parked kernels' launches only move into _begin. So the default stays off. While a pair is parked nobody
+    // may sit inside hipStreamSynchronize on the track stream: the library's own waits poll (trk_sync), and a download of a
+    // map the tracker has not touched yet does not look at the track stream at all.
     constexpr int ks = rebvio_hip_ctx::kSlots - 1;
     c->bf_seq = 0x80000000u | (++c->bf_counter & 0x7FFFFFFFu);
     HIPCHK(hipStreamWaitValue32(s, c->glue_flag + ks, c->bf_seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
-    c->bf_parked = true;
+    c->bf_park_thread = std::this_thread::get_id();
+    c->bf_parked.store(true, std::memory_order_release);
     launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_host[ks], c->glue_dev + ks, c->P.search_range, c->dm_work, c->dm_work_n);
     const int gate = (int)c->P.global_min_matches_threshold;
     launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + ks, gate > 0 ? gate : 0, c->dm_work_n, c->hist);
     std::swap(nm->d.rs, nm->d.rs_tmp);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&c->h_bf[c->bf_cur], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(c->bf_done[c->bf_cur], s));
   }
+  const auto tb1 = std::chrono::steady_clock::now();
   HIPCHK(hipEventSynchronize(c->slot_ev[0]));
+  const auto tb2 = std::chrono::steady_clock::now();
+  c->t_begin_enq += std::chrono::duration<double, std::micro>(tb1 - tb0).count();
+  c->t_begin_wait += std::chrono::duration<double, std::micro>(tb2 - tb1).count();
+  c->t_begin_n++;
+  if (prev_from_slot) {
+    c->h_bf[pr] = slot->old_st;
+    c->bf_have[pr] = true;
+  }
   nm->n_host = slot->new_st.n;
   nm->thr_host = slot->new_st.threshold;
   lm_to_out(slot->lm, mid->Vg, mid->P_Vg, &mid->F, &mid->lm_accept_mask, &mid->sigma_rho_min);
@@ -1684,27 +1803,44 @@ int rebvio_hip_track_pair_finish_async(rebvio_hip_ctx* c, rebvio_hip_map* om, re
   if (c->bf_res >= 0) return fail_msg("track_pair_finish_async: fetch the previous pair's result first (rebvio_hip_track_pair_result)", -7);
   c->bf_nan[c->bf_cur] = g.nan_v;
   c->bf_res = c->bf_cur;
-  if (c->bf_parked) {  // the second half is already queued (see _begin): hand it the fusion's results and let it go
+  c->bf_map[c->bf_cur] = nm;  // its state record will hold the counters: fetched by the next _begin or by _result
+  c->bf_have[c->bf_cur] = false;
+  c->bf_copy_queued[c->bf_cur] = false;
+  float RT_next[9];
+  if (R_prior_next) {  // the next pair's first rotateKeylines rides in this pair's last kernel (rebvio.cpp:163-165 of that pair)
+    nm->pre_R = prior_rotation(c, R_prior_next);
+    hm::store3(hm::transpose(nm->pre_R), RT_next);
+  }
+  if (c->bf_parked.load(std::memory_order_acquire)) {
+    // the second half is already queued (see _begin): hand it the fusion's results and let it go. No runtime call from here
+    // to the flag.
     GlueDev gl{};
     rotate_inputs(c, g.V, g.P_V, g.Rgva, gl.vel_r, gl.Rvel_r);
     std::memcpy(gl.Rgva, g.Rgva, sizeof(g.Rgva));
     std::memcpy(gl.R0a, g.R0a, sizeof(g.R0a));
     std::memcpy(gl.V, g.V, sizeof(g.V));
     gl.nan_v = g.nan_v ? 1 : 0;
-    gl.has_next = 0;  // (the parked kernels were given their argument layout in _begin: no next rotation on this path)
+    gl.has_next = R_prior_next ? 1 : 0;  // read by the last kernel at run time
+    if (R_prior_next) {
+      std::memcpy(gl.RT_next, RT_next, sizeof(RT_next));
+      std::swap(nm->d.grad, nm->d.grad_tmp);  // (host-side handles: they only shape LATER launches)
+      nm->pre_rotated = true;
+    }
     write_glue_and_flag(c, rebvio_hip_ctx::kSlots - 1, c->bf_seq, gl);
-    c->bf_parked = false;
+    c->bf_parked.store(false, std::memory_order_release);
     return 0;
-  }
-  float RT_next[9];
-  if (R_prior_next) {  // the next pair's first rotateKeylines rides in this pair's last kernel (rebvio.cpp:163-165 of that pair)
-    nm->pre_R = prior_rotation(c, R_prior_next);
-    hm::store3(hm::transpose(nm->pre_R), RT_next);
   }
   enqueue_b_chain(c, om, nm, g, R_prior_next ? RT_next : nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(&c->h_bf[c->bf_cur], nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
-  HIPCHK(hipEventRecord(c->bf_done[c->bf_cur], c->s_trk));
+  return 0;
+}
+
+int rebvio_hip_track_pair_hint_next(rebvio_hip_ctx* c, rebvio_hip_map* next_new_map) {
+  if (!c || !next_new_map || next_new_map->ctx != c) return fail_msg("track_pair_hint_next: map of another context", -3);
+  if (c->bf_parked.load(std::memory_order_acquire)) return 0;  // (would queue behind the parked second half: nothing gained)
+  HIPCHK(hipSetDevice(c->device));
+  wait_enqueued(next_new_map);
+  HIPCHK(trk_wait_ready_once(c, next_new_map));
   return 0;
 }
 
@@ -1716,7 +1852,14 @@ int rebvio_hip_track_pair_result(rebvio_hip_ctx* c, int* klm_num, int* kf_matche
   if (c->bf_res < 0) return fail_msg("track_pair_result: no finished pair to report", -7);
   const int r = c->bf_res;
   c->bf_res = -1;
-  HIPCHK(hipEventSynchronize(c->bf_done[r]));
+  if (!c->bf_have[r]) {
+    if (!c->bf_copy_queued[r]) {  // no later pair has been begun: fetch the record now (nothing is parked at this point)
+      HIPCHK(hipMemcpyAsync(&c->h_bf[r], c->bf_map[r]->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
+      HIPCHK(hipEventRecord(c->bf_done[r], c->s_trk));
+    }
+    HIPCHK(hipEventSynchronize(c->bf_done[r]));  // (a copy queued by _begin sits ahead of that pair's parked second half)
+    c->bf_have[r] = true;
+  }
   if (c->bf_nan[r]) {
     if (status) *status = 1;
     return 0;
@@ -1758,7 +1901,7 @@ int enqueue_a_waits(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
   for (rebvio_hip_map* m : {pp.om, pp.nm}) {
     if (m->trk_waited && c->slim_ops) continue;
     wait_enqueued(m);
-    HIPCHK(hipStreamWaitEvent(s, m->ready, 0));
+    HIPCHK(trk_wait_ready(s, m));
     m->trk_waited = true;
   }
   return 0;
@@ -2029,7 +2172,7 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_df));
-  HIPCHK(hipStreamSynchronize(c->s_trk));
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   return 0;
 }
 

@@ -153,10 +153,20 @@ namespace {
 struct StageTimers {
   bool on = std::getenv("REBVIO_HOST_TIMERS") != nullptr;
   double t[4] = {0, 0, 0, 0};
+  double t_in = 0;  // from the end of a pair to the next pair's first device call (input queue, IMU pre-integration read)
+  std::chrono::steady_clock::time_point pair_end;
+  bool have_end = false;
   unsigned n = 0;
   std::chrono::steady_clock::time_point last;
   void start() {
-    if (on) last = std::chrono::steady_clock::now();
+    if (!on) return;
+    last = std::chrono::steady_clock::now();
+    if (have_end) t_in += std::chrono::duration<double, std::micro>(last - pair_end).count();
+  }
+  void end_pair() {
+    if (!on) return;
+    pair_end = std::chrono::steady_clock::now();
+    have_end = true;
   }
   void lap(int i) {
     if (!on) return;
@@ -166,8 +176,8 @@ struct StageTimers {
   }
   ~StageTimers() {
     if (on && n)
-      std::fprintf(stderr, "[Rebvio] per pair (us): first half on device %.1f  acceleration + bias/scale filter %.1f  second half on device %.1f  pose + callbacks %.1f\n",
-                   t[0] / n, t[1] / n, t[2] / n, t[3] / n);
+      std::fprintf(stderr, "[Rebvio] per pair (us): first half on device %.1f  acceleration + bias/scale filter %.1f  second half on device %.1f  pose + callbacks %.1f  (between pairs: input queue + IMU read %.1f)\n",
+                   t[0] / n, t[1] / n, t[2] / n, t[3] / n, t_in / n);
   }
 };
 }  // namespace
@@ -200,13 +210,25 @@ void Rebvio::stateEstimationProcess() {
   // fetched AFTER the next pair's first half has been queued, so the record waits here for one loop turn (or until the
   // input runs dry). Returns false when the pair ended the run (minimization error / too few matches).
   struct Pending {
-    bool have = false;
+    bool have = false;     // a pair whose counters have not been fetched yet
+    bool fetched = false;  // counters in, record not yet handed to the callbacks
     types::Odometry odometry;
     rebvio::EdgeMap::SharedPtr old_map, new_map;
   } pending;
-  auto complete_pending = [&]() -> bool {
+  // Two steps: the counters (and with them the stop conditions of rebvio.cpp:236-252) are fetched as soon as the next pair's
+  // first half is back; the callbacks run after that pair's second half has been launched, off the path between its halves.
+  auto publish_pending = [&]() {
+    if (!pending.fetched) return;
+    pending.fetched = false;
+    for (auto& cb : odometry_callbacks_) cb(pending.odometry);
+    pending.old_map.reset();
+    pending.new_map.reset();
+    ++num_published_;
+  };
+  auto fetch_pending = [&]() -> bool {
     if (!pending.have) return true;
     pending.have = false;
+    pending.fetched = true;
     int klm_num = 0, kf_matches = 0, reg_num = 0, status = 0;
     backend::check("rebvio_hip_track_pair_result", rebvio_hip_track_pair_result(ctx, &klm_num, &kf_matches, &reg_num, &status));
     pending.old_map->invalidateMirror();
@@ -224,10 +246,11 @@ void Rebvio::stateEstimationProcess() {
       ok = false;
     }
     pending.odometry.klm_num = klm_num;
-    for (auto& cb : odometry_callbacks_) cb(pending.odometry);
-    pending.old_map.reset();
-    pending.new_map.reset();
-    ++num_published_;
+    return ok;
+  };
+  auto complete_pending = [&]() -> bool {
+    const bool ok = fetch_pending();
+    publish_pending();
     return ok;
   };
 
@@ -286,7 +309,8 @@ void Rebvio::stateEstimationProcess() {
                    rebvio_hip_track_pair_begin(ctx, old_edge_map->handle(), new_edge_map->handle(), Rp, frame_dt, &mid));
     // this pair's first half (and its parked second half) are queued behind the previous pair's second half: now that pair's
     // counters can be fetched without leaving the GPU idle
-    if (!complete_pending()) {
+    if (!fetch_pending()) {
+      publish_pending();
       const float nanv[3] = {std::numeric_limits<float>::quiet_NaN(), 0.f, 0.f}, I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       int st = 0;  // the run has ended: let this pair's parked second half fall through
       (void)rebvio_hip_track_pair_finish(ctx, old_edge_map->handle(), new_edge_map->handle(), nanv, I9, I9, I9, nullptr, nullptr, nullptr, &st);
@@ -366,16 +390,23 @@ void Rebvio::stateEstimationProcess() {
     // initialised (until then the bias still changes between pairs, rebvio.cpp:146-160).
     float Rnext[9];
     bool have_next = false;
-    if (imu_state_.initialized) {
+    rebvio::EdgeMap::SharedPtr next_map;
+    {
       std::lock_guard<std::mutex> guard(edge_map_buffer_mutex_);
       if (edge_map_buffer_.size() >= 2) {
-        store3(edge_map_buffer_[1]->imu().R(), Rnext);
-        have_next = true;
+        next_map = edge_map_buffer_[1];
+        if (imu_state_.initialized) {
+          store3(next_map->imu().R(), Rnext);
+          have_next = true;
+        }
       }
     }
+    // the track stream's wait for the next frame's detection goes in ahead of this pair's second half
+    if (next_map) backend::check("rebvio_hip_track_pair_hint_next", rebvio_hip_track_pair_hint_next(ctx, next_map->handle()));
     backend::check("rebvio_hip_track_pair_finish_async",
                    rebvio_hip_track_pair_finish_async(ctx, old_edge_map->handle(), new_edge_map->handle(), V, pv, rg, r2,
                                                       have_next ? Rnext : nullptr));
+    publish_pending();  // the previous pair's record: its callbacks run while the device works on this pair's second half
     timers.lap(2);
 
     // gravity-aligned pose integration (rebvio.cpp:263-271)
@@ -401,6 +432,7 @@ void Rebvio::stateEstimationProcess() {
     pending.old_map = old_edge_map;
     pending.new_map = new_edge_map;
     timers.lap(3);
+    timers.end_pair();
     timers.n++;
     ++num_frames_;
   }

@@ -3,6 +3,7 @@
 //   rebvio_replay --raw frames.u8 --size W H [--imu imu.bin] [--dt 50000] [--camera fm cx cy [k1 k2 p1 p2 k3]] --out odometry.txt
 // --euroc selects the reference's built-in EuRoC MH cam0 model (camera.hpp:25-45). With the real MH_03 data
 // (first = the frame at 15 s) this replays what ros_rebvio/test/test_ros_rebvio.cpp checks against its golden file.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -86,9 +87,12 @@ int main(int argc, char** argv) {
     rebvio::Rebvio rebvio(config);
     std::mutex mu;
     size_t n_odo = 0;
+    std::chrono::steady_clock::time_point t_first, t_last;
     rebvio.registerOdometryCallback([&](rebvio::types::Odometry& o) {
       std::lock_guard<std::mutex> g(mu);
       writer.write(o);
+      t_last = std::chrono::steady_clock::now();
+      if (n_odo == 0) t_first = t_last;
       ++n_odo;
     });
     const size_t n = rebvio::io::replay(
@@ -96,6 +100,11 @@ int main(int argc, char** argv) {
         [&](rebvio::types::Imu&& s) { rebvio.imuCallback(std::move(s)); }, first, count);
     rebvio.waitIdle();
     std::fprintf(stderr, "frames=%zu odometry=%zu running=%d\n", n, n_odo, (int)rebvio.running());
+    if (n_odo > 1) {  // wall clock between the first and the last published odometry: the whole class, input thread included
+      const double sec = std::chrono::duration<double>(t_last - t_first).count();
+      std::fprintf(stderr, "[replay] %zu odometry records in %.3f s = %.0f frames/s (wall clock, first to last record)\n", n_odo, sec,
+                   (double)(n_odo - 1) / sec);
+    }
     return (n_odo + 1 == n || n == 0) ? 0 : 1;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
