@@ -399,6 +399,34 @@ class Context:
         _chk(lib().rebvio_hip_track_pair(self.h, old.h, new.h, pr, frame_dt, C.byref(out)))
         return out
 
+    # the pair step in two halves (what rebvio::Rebvio drives, with the host's inertial fusion in between)
+    def track_pair_begin(self, old: Map, new: Map, R_prior=None, frame_dt=0.05) -> PairMid:
+        mid = PairMid()
+        pr = None
+        if R_prior is not None:
+            R_prior, pr = _f(np.asarray(R_prior).reshape(9))
+        _chk(lib().rebvio_hip_track_pair_begin(self.h, old.h, new.h, pr, frame_dt, C.byref(mid)))
+        return mid
+
+    def track_pair_finish_async(self, old: Map, new: Map, V, P_V, Rgva, R_second, R_prior_next=None):
+        V, pv = _f(V)
+        P_V, ppv = _f(np.asarray(P_V).reshape(9))
+        Rgva, prg = _f(np.asarray(Rgva).reshape(9))
+        R_second, pr2 = _f(np.asarray(R_second).reshape(9))
+        prn = None
+        if R_prior_next is not None:
+            R_prior_next, prn = _f(np.asarray(R_prior_next).reshape(9))
+        _chk(lib().rebvio_hip_track_pair_finish_async(self.h, old.h, new.h, pv, ppv, prg, pr2, prn))
+
+    def track_pair_result(self):
+        """(klm_num, kf_matches, reg_num, status) of the pair whose _finish_async came last but one / last."""
+        v = [C.c_int() for _ in range(4)]
+        _chk(lib().rebvio_hip_track_pair_result(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def track_pair_hint_next(self, next_new: Map):
+        _chk(lib().rebvio_hip_track_pair_hint_next(self.h, next_new.h))
+
     def push_frame_u8_device(self, dev_addr: int, ts_us: int):
         out = PairOut()
         n = C.c_int()

@@ -106,6 +106,38 @@ def test_stream_example_runs_like_ros_rebvio(host_lib, tmp_path):
     assert "running=1" in r.stderr
 
 
+@pytest.mark.gpu
+def test_host_class_modes_publish_the_same_records(host_lib, tmp_path):
+    """rebvio::Rebvio with its edge-image callback reading a keyline of every fresh map (as ros_rebvio.cpp:44 does), under the
+    backend's scheduling options: second halves parked behind a pinned flag (REBVIO_HIP_PAIR_PRELAUNCH=1; a callback's map
+    download used to dead-lock with this - the run is bounded by the timeout), host-frame detections launched by the detect
+    worker (REBVIO_HIP_DETECT_ASYNC=1), both, and the sequential LM kernel. None of them may change a digit of the output."""
+    from rebvio_amd import synth
+    n = 40
+    frames, cam = synth.render_stream(320, 240, n)
+    scene = synth.make_scene(0)
+    ts, gyro, acc = synth.imu_samples(scene, n, noise_seed=1)
+    fp, ip = tmp_path / "frames.u8", tmp_path / "imu.bin"
+    frames.tofile(fp)
+    _write_imu(ip, ts, gyro, acc)
+    exe = os.path.join(host_lib, "rebvio_stream_example")
+
+    def run(**env):
+        r = subprocess.run([exe, str(fp), "320", "240", str(n), str(cam.fm), str(cam.cx), str(cam.cy), "3000", "4000", str(ip), "100"],
+                           capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        assert r.returncode == 0, (env, r.stdout[-1000:], r.stderr[-1000:])
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln and ln[0].isdigit()]
+        assert len(lines) == n - 1
+        return lines
+
+    base = run()
+    assert run(REBVIO_HIP_PAIR_PRELAUNCH="1") == base
+    assert run(REBVIO_HIP_DETECT_ASYNC="1") == base
+    assert run(REBVIO_HIP_PAIR_PRELAUNCH="1", REBVIO_HIP_DETECT_ASYNC="1") == base
+    assert run(REBVIO_HIP_LM="seq") == base
+    assert run(REBVIO_HIP_SCAN_SPLIT="0", REBVIO_HIP_ROWSCAN="lane") == base
+
+
 def _write_imu(path, ts, gyro, acc):
     rec = np.zeros(len(ts), dtype=[("ts", "<i8"), ("gyro", "<f4", 3), ("acc", "<f4", 3)])
     rec["ts"], rec["gyro"], rec["acc"] = ts, gyro, acc

@@ -550,6 +550,80 @@ def test_speculative_lm_kernel_rolls_back_when_a_later_step_is_accepted(B, monke
         assert np.array_equal(a[k][2], b[k][2]) and _bits_equal(a[k][3], b[k][3]), k
 
 
+def _vision_only_fusion(mid):
+    """rebvio.cpp:195-203,225-233 without the inertial filter, in numpy (only has to be the SAME in every call order below)."""
+    from scipy.spatial.transform import Rotation
+    Xgv = np.array(mid.Xgv, np.float64)
+    R = np.array(mid.R, np.float64).reshape(3, 3)
+    R0 = Rotation.from_rotvec(Xgv[3:]).as_matrix()
+    R = (R0 @ R.T).T
+    V = R0 @ np.array(mid.Vg, np.float64) + Xgv[:3]
+    P = np.linalg.inv(np.array(mid.W_Xgv, np.float64).reshape(6, 6))[:3, :3]
+    return V.astype(np.float32), P.astype(np.float32), R.astype(np.float32), R0.astype(np.float32)
+
+
+def test_pair_halves_report_the_same_counters_in_every_call_order(B, c2_stream):
+    """rebvio_hip_track_pair_begin / _finish_async / _result: a pair's match counters come back with the next pair's first half
+    when that pair continues from the same map (no copy), through a copy queued by _begin when it does not, and through a
+    copy made by _result when no pair follows; rebvio_hip_track_pair_hint_next only moves a wait. Same inputs -> the same
+    counters and the same keylines whichever way they travel."""
+    frames, cam = c2_stream
+    n = 8
+
+    def run(order, hint):
+        ctx = B.Context(params_for(B, cam, **KW_C2))
+        maps = [ctx.detect_u8(frames[i], i * 50000) for i in range(n)]
+        res = []
+        if order == "overlapped":      # begin(k), finish_async(k), begin(k+1), result(k), ...: what rebvio::Rebvio does
+            pending = False
+            for k in range(n - 1):
+                mid = ctx.track_pair_begin(maps[k], maps[k + 1])
+                if pending:
+                    res.append(ctx.track_pair_result())
+                if hint and k + 2 < n:
+                    ctx.track_pair_hint_next(maps[k + 2])
+                ctx.track_pair_finish_async(maps[k], maps[k + 1], *_vision_only_fusion(mid))
+                pending = True
+            res.append(ctx.track_pair_result())
+        elif order == "serial":        # begin(k), finish_async(k), result(k): _result copies
+            for k in range(n - 1):
+                mid = ctx.track_pair_begin(maps[k], maps[k + 1])
+                ctx.track_pair_finish_async(maps[k], maps[k + 1], *_vision_only_fusion(mid))
+                res.append(ctx.track_pair_result())
+        else:                          # every other pair restarts from fresh maps: _begin queues the copy
+            for k in range(0, n - 1, 2):
+                mid = ctx.track_pair_begin(maps[k], maps[k + 1])
+                if res or k:
+                    res.append(ctx.track_pair_result())
+                ctx.track_pair_finish_async(maps[k], maps[k + 1], *_vision_only_fusion(mid))
+            res.append(ctx.track_pair_result())
+        kl = maps[n - 1].keylines() if order != "disjoint" else maps[n - 1 - (n % 2)].keylines()
+        for m in maps:
+            m.release()
+        ctx.close()
+        return res, kl
+
+    a, kla = run("overlapped", False)
+    b, klb = run("serial", False)
+    c, klc = run("overlapped", True)
+    assert len(a) == n - 1 and a == b == c
+    assert all(r[3] == 0 and r[0] > 5000 for r in a), a
+    assert_keylines_equal(kla, klb, what="overlapped vs serial")
+    assert_keylines_equal(kla, klc, what="with vs without the hint")
+    d, _ = run("disjoint", False)
+    e = []
+    ctx = B.Context(params_for(B, cam, **KW_C2))   # the same disjoint pairs one at a time
+    maps = [ctx.detect_u8(frames[i], i * 50000) for i in range(n)]
+    for k in range(0, n - 1, 2):
+        mid = ctx.track_pair_begin(maps[k], maps[k + 1])
+        ctx.track_pair_finish_async(maps[k], maps[k + 1], *_vision_only_fusion(mid))
+        e.append(ctx.track_pair_result())
+    for m in maps:
+        m.release()
+    ctx.close()
+    assert d == e and len(d) == n // 2
+
+
 def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
     """The throughput pipeline (detect worker + five streams + persistent pair kernel + deferred counters) against the
     oracle's own stream driver on the same 30-frame ping-pong sequence, state carried independently on both sides:
