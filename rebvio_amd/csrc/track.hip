@@ -2446,6 +2446,9 @@ void launch_try_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const M
 
 // Speculative form (k_lm_chain_spec; do_ext == 2 / spec != 0 allows it, the context's REBVIO_HIP_LM=seq does not). Needs at
 // least two speculative evaluations, at most kSpecMax, and the staged record sets in the default 64 KB of LDS with the static part.
+// The LDS bound also keeps it to maps of up to ~40k keylines: with the attribute raised it ran at 64k keylines (1280x960,
+// 125 workgroups) and was slower than the sequential kernel there (5.3k vs 6.5k frames/s) - four evaluations' arithmetic
+// per pass on every workgroup and a 125-hop neighbour chain outweigh the three exchange rounds saved.
 static size_t lm_spec_shm(int kmax, int calls) {
   const int groups = std::min(div_up(kmax, 256), kMaxRecBlocks);
   return (size_t)(calls - 2) * groups * kPartStride * sizeof(float);

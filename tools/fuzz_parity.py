@@ -129,7 +129,8 @@ def make_trial(rng, k):
     px = W * H
     base = max(64, int(px * 0.05))
     kref = int(base * rng.uniform(0.3, 1.2))
-    kmax = int(kref * rng.uniform(1.02, 1.5))
+    kmax = min(int(kref * rng.uniform(1.02, 1.5)), 65536)  # rebvio_hip_create: keylines_max <= 65536
+    kref = min(kref, kmax)
     return dict(size=(W, H), frames=int(rng.integers(4, 7)), stream=int(rng.integers(0, 1 << 20)), density=float(rng.uniform(0.4, 2.6)),
                 kref=kref, kmax=kmax, rot=(float(rng.normal(0, 0.004)), float(rng.normal(0, 0.003))),
                 vel=[float(x) for x in rng.normal(0, 0.012, 3)])
