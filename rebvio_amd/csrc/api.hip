@@ -2169,6 +2169,10 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
   for (auto* m : c->frames)
     if (m->in_use) rebvio_hip_map_release(m);
   c->frames.clear();
+  // The last second half binned the sigma histogram for a pair that will not come (its next-rotation rides in the last
+  // kernel): a stream that continues after the flush must not find those counts under its first pair's (they put the
+  // quantile cut below every fresh keyline's sigma and the pair came back with status 1).
+  HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));
   HIPCHK(hipStreamSynchronize(c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_df));
@@ -2810,6 +2814,8 @@ int rebvio_hip_batch_flush(rebvio_hip_batch* b) {
   for (auto& f : b->frames)
     for (size_t l = 0; l < f.m.size(); ++l) batch_release_map(f.m[l], l + 1 == f.m.size());
   b->frames.clear();
+  for (auto* c : b->lane)  // as rebvio_hip_flush: no histogram counts of a pair that will not come
+    HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), b->st.s_trk));
   HIPCHK(hipStreamSynchronize(b->st.s_det));
   if (b->s_det2) HIPCHK(hipStreamSynchronize(b->s_det2));
   HIPCHK(hipStreamSynchronize(b->st.s_key));

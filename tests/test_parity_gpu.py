@@ -624,6 +624,34 @@ def test_pair_halves_report_the_same_counters_in_every_call_order(B, c2_stream):
     assert d == e and len(d) == n // 2
 
 
+def test_stream_continues_cleanly_after_a_flush(B, c2_stream):
+    """rebvio_hip_flush() in the middle of a stream: the stream that follows must start like a fresh one. The last second
+    half before the flush has already binned the sigma histogram for a pair that never comes; those counts used to put the
+    quantile cut of the first pair after the flush below every fresh keyline's sigma (status 1, no matches)."""
+    from rebvio_amd import synth
+    frames, cam = c2_stream
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    dev = ctx.upload_frames(frames)
+    npx = cam.width * cam.height
+    order = synth.pingpong_indices(len(frames), 90)
+
+    def segment(k0):
+        rec = []
+        for k in range(k0, k0 + 30):
+            out, _ = ctx.push_frame_u8_device(dev + int(order[k]) * npx, k * 50000)
+            if out.status >= 0:
+                rec.append((out.status, out.lm_accept_mask, out.klm_num, float(out.sigma_rho_min)))
+        ctx.flush()
+        return rec
+
+    first, second, third = segment(0), segment(30), segment(60)
+    for rec in (first, second, third):
+        assert len(rec) >= 15
+        assert all(r[0] == 0 for r in rec), rec[:4]
+        assert rec[0][3] == first[0][3]            # every segment's first pair starts from the fresh maps' sigma (quantile of 1000s)
+        assert all(r[2] > 5000 for r in rec), rec[:4]
+
+
 def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
     """The throughput pipeline (detect worker + five streams + persistent pair kernel + deferred counters) against the
     oracle's own stream driver on the same 30-frame ping-pong sequence, state carried independently on both sides:
