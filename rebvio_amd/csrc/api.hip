@@ -226,7 +226,9 @@ struct rebvio_hip_ctx {
   // persistent LM kernel: record exchange words, tags consumed so far, sticky time-out flag
   unsigned long long* lm_xch = nullptr;
   unsigned lm_tag_base = 0;
-  bool lm_spec = true;
+  bool lm_spec = true;          // the speculative kernel may be used ...
+  bool lm_spec_forced = false;  // ... always (REBVIO_HIP_LM=spec), instead of by the stream's recent miss rate
+  float lm_miss_ema = 0.f;
   int* lm_bar_err = nullptr;  // pinned, zero-copy
   unsigned long long* lm_stamps = nullptr;  // pinned; REBVIO_HIP_LM_STAMPS diagnostic (phase stamps of workgroup 0)
   double lm_stamp_acc[64]{};
@@ -628,6 +630,16 @@ void sum_xrv(const float* h_xrv, int nblocks, float Wx[36], float JtF[6], int* n
   if (nm) *nm = (int)std::lround(acc[27]);
 }
 
+// The speculative LM kernel bets that minimizeVel rejects every step after the first accepted one (track.hip). Where the
+// bet fails often - large inter-frame motion: 35 % of the pairs when a 20 Hz stream is replayed in jumps of 1..6 frames - it
+// costs more than it saves (measured there: 3.7 % slower than the sequential kernel; 4-5 % faster on consecutive frames;
+// break-even near one miss in six). Both kernels give the same bits, so the choice follows the recent miss rate of the
+// stream (exponential average over ~16 pairs, known with a lag of two pairs in the streaming driver).
+void note_accept_mask(rebvio_hip_ctx* c, int mask) {
+  const float miss = (mask >> 1) != 0 ? 1.0f : 0.0f;  // an accept after the second evaluation = a failed hypothesis
+  c->lm_miss_ema += (miss - c->lm_miss_ema) * (1.0f / 16.0f);
+}
+
 void lm_to_out(const LmState& s, float vel[3], float Rvel[9], float* F, int* mask, float* srm) {
   for (int i = 0; i < 3; ++i) vel[i] = s.vel[i];
   hm::M3 J;
@@ -706,7 +718,8 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
       c->lm_stamp_spec = spec;
     }
   }
-  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, c->lm_spec ? 2 : 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
+  const bool spec_now = c->lm_spec && (c->lm_spec_forced || c->lm_miss_ema < 0.17f);
+  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, spec_now ? 2 : 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
                   slot->xrv, slot, c->hist, c->lm_stamps);
   c->lm_tag_base += 2u * ((unsigned)calls + 1u);  // (the speculative kernel numbers repeated evaluations in a second range)
   if (c->lm_tag_base > 0xFFFFFF00u) {  // tags must stay unique and non-zero: restart the sequence on clean exchange words
@@ -975,6 +988,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   if (const char* e = std::getenv("REBVIO_HIP_LM")) {
     c->lm_persistent = std::strcmp(e, "percall") != 0;
     c->lm_spec = std::strcmp(e, "seq") != 0;
+    c->lm_spec_forced = std::strcmp(e, "spec") == 0;
   }
   HIPCHK(hipMalloc(&c->lm, 16 * sizeof(LmState)));
   HIPCHK(hipMemset(c->lm, 0, 16 * sizeof(LmState)));
@@ -1581,6 +1595,7 @@ GlueOut pair_glue(rebvio_hip_ctx* c, const LmState& lm, const float* xrv, int n_
   GlueOut g;
   float Vg[3], P_Vg[9];
   lm_to_out(lm, Vg, P_Vg, &out->F, &out->lm_accept_mask, &out->sigma_rho_min);
+  note_accept_mask(c, out->lm_accept_mask);
   float Xv[6], W_Xv[36], JtF6[6];
   sum_xrv(xrv, div_up(n_new, 256), W_Xv, JtF6, nullptr);
   hm::sym6_solve(W_Xv, JtF6, Xv);
@@ -1771,6 +1786,7 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   nm->n_host = slot->new_st.n;
   nm->thr_host = slot->new_st.threshold;
   lm_to_out(slot->lm, mid->Vg, mid->P_Vg, &mid->F, &mid->lm_accept_mask, &mid->sigma_rho_min);
+  note_accept_mask(c, mid->lm_accept_mask);
   float JtF6[6];
   sum_xrv(slot->xrv, div_up(nm->n_host, 256), mid->W_Xv, JtF6, nullptr);
   hm::sym6_solve(mid->W_Xv, JtF6, mid->Xv);
@@ -2528,7 +2544,10 @@ int batch_enqueue_a(rebvio_hip_batch* b, rebvio_hip_batch::Pair& pp) {
       c->lm_tag_base = 0;
     }
   }
-  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, b->lane[0]->lm_spec ? 1 : 0);
+  bool spec_now = b->lane[0]->lm_spec;  // one launch for all lanes: speculative while every lane's recent miss rate allows it
+  if (spec_now && !b->lane[0]->lm_spec_forced)
+    for (auto* c : b->lane) spec_now = spec_now && c->lm_miss_ema < 0.17f;
+  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->slot_ev[pp.slot], s));
   return 0;
