@@ -946,6 +946,9 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
         om.match_fwd[idx] = e.mfwd;
       }
     }
+    // last evaluation: this wave's forwardMatch atomics are acknowledged before the workgroup publishes its records (see
+    // k_lm_chain_spec; a release fence on the publishing threads would order only their own operations)
+    if (last) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     RH_STAMP(1 + call * 6 + 3);
     // carry-forward of the last written fi in index order (see k_try_vel)
     const unsigned long long mm = __ballot(e.matched);
@@ -983,8 +986,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
     }
     if (tid < kChainGroups * 16) {
       // publish this evaluation's records (self-contained words, relaxed); only the last evaluation has other data to
-      // order before them: the forwardMatch keys this workgroup issued before the __syncthreads above
-      if (last) __atomic_thread_fence(__ATOMIC_RELEASE);
+      // order before them: the forwardMatch keys this workgroup issued - and waited for - before the __syncthreads above
       const int g = tid >> 4, k = tid & 15;
       unsigned long long* out = xch + ((size_t)(call & 1) * nrec_launched + (size_t)blockIdx.x * kChainGroups + g) * kPartStride;
       const unsigned tag = tag_base + (unsigned)call + 1u;
@@ -1172,6 +1174,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         om.match_fwd[idx] = e.mfwd;
       }
     }
+    if (last) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the keys are out before the records (see the speculative phase)
     const unsigned long long mm = __ballot(e.matched);
     const unsigned long long below = mm & ((1ull << lane) - 1ull);
     const int src = below ? (63 - __clzll((long long)below)) : 0;
@@ -1205,7 +1208,6 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       res = r;
     }
     if (tid < kChainGroups * 16) {
-      if (last) __atomic_thread_fence(__ATOMIC_RELEASE);  // the forwardMatch keys issued before the __syncthreads above
       const int g = tid >> 4, k = tid & 15;
       unsigned long long* out = set_words(call) + ((size_t)blockIdx.x * kChainGroups + g) * kPartStride;
       if (k < 10) {
@@ -1324,6 +1326,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         }
       }
     }
+    // Every wave's forwardMatch atomics (performed at the memory side, device scope) are ACKNOWLEDGED before the workgroup goes
+    // on to publish its records: vmcnt(0) here, on the waves that issued them. (A system-scope release fence on the
+    // publishing threads, as before, orders only THEIR OWN operations and writes the XCD's whole L2 back for it.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     RH_STAMP(7);
     __syncthreads();
     // thread kChainThreads - 1 - k: hand-off behind evaluation 2 + k (carry-in of evaluation 3 + k), as in do_eval
@@ -1400,7 +1406,6 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     RH_STAMP(9);
     __syncthreads();
     if (tid < kChainGroups * 16) {
-      __atomic_thread_fence(__ATOMIC_RELEASE);  // the forwardMatch keys of the last evaluation, issued before the barriers above
       const int g = tid >> 4, q = tid & 15;
       for (int k = 0; k < nspec; ++k) {
         const int call = 2 + k;
