@@ -530,8 +530,10 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   HIPCHK(hipEventRecord(c->ev_flag[b], c->s_key));  // (after join: coarser than needed, same stream order)
   c->ev_flag_used[b] = true;
   // distance field of this map on its own stream
-  HIPCHK(hipEventRecord(m->detected, c->s_key));
-  HIPCHK(hipStreamWaitEvent(c->s_df, m->detected, 0));
+  if (c->s_df != c->s_key) {  // (the default shares the stream: stream order is the dependency, two runtime calls less per frame)
+    HIPCHK(hipEventRecord(m->detected, c->s_key));
+    HIPCHK(hipStreamWaitEvent(c->s_df, m->detected, 0));
+  }
   launch_df_build(c->s_df, c->K, m->d, j.det_out, true);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(m->ready, c->s_df));
