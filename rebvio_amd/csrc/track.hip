@@ -844,6 +844,58 @@ __device__ __forceinline__ float xch_wait(const unsigned long long* w, unsigned 
   return __uint_as_float((unsigned)v);
 }
 
+// Up to N words per thread polled TOGETHER: every round re-loads the words still missing in one batch (one memory round trip
+// per round whatever their number), until all carry their tags. Waiting for them one after the other costs a round trip per
+// word once the first has arrived; loading all once and then waiting one by one (tried) adds a round trip in the usual case
+// that nothing is out yet. ok[j] false = no word for this thread in slot j. Same bound and diagnostics as xch_wait.
+template <int N>
+__device__ __forceinline__ void xch_wait_many(const unsigned long long* const (&w)[N], const unsigned (&tag)[N], const bool (&ok)[N],
+                                              float (&out)[N], int* err, int slow) {
+  bool have[N];
+  bool all = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    have[j] = !ok[j];
+    out[j] = 0.f;
+    all = all && have[j];
+  }
+  unsigned spins = 0;
+  while (!all) {
+    unsigned long long v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (!have[j]) v[j] = __hip_atomic_load(w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    all = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (!have[j]) {
+        if ((unsigned)(v[j] >> 32) == tag[j]) {
+          have[j] = true;
+          out[j] = __uint_as_float((unsigned)v[j]);
+        } else {
+          all = false;
+        }
+      }
+    if (all) break;
+    if (slow)
+      __builtin_amdgcn_s_sleep(12);
+    else
+      __builtin_amdgcn_s_sleep(1);
+    if (++spins > kXchSpinLimit) {
+      if (__hip_atomic_exchange(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        err[1] = (int)blockIdx.x;
+        err[2] = (int)threadIdx.x;
+        err[3] = (int)tag[0];
+        err[4] = 0;
+        err[5] = 0;
+        err[6] = (int)gridDim.x;
+        err[7] = -3;
+      }
+      break;
+    }
+  }
+}
+
 // Wait for the records every live group published for evaluation `tag`, stage them in LDS and reduce them.
 template <int kChainThreads>
 __device__ __forceinline__ void chain_collect_records(const unsigned long long* __restrict__ slot_words, unsigned tag, int nblocks,
@@ -1230,8 +1282,17 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
 
   // ordinary collect of one record set (+ carry-in per group) into recm[0 .. cap) / red
   auto collect = [&](int call_of_set, unsigned tag) {
-    for (int i = tid; i < cap; i += kChainThreads)
-      if ((i & (kPartStride - 1)) < 12) recm[i] = xch_wait(set_words(call_of_set) + i, tag, bar_err, slow_poll);
+    const unsigned long long* sw = set_words(call_of_set);
+    for (int i0 = 0; i0 < cap; i0 += kChainThreads * 2) {  // a thread's two words of a 16k-keyline map polled together
+      const int ia = i0 + tid, ib = i0 + kChainThreads + tid;
+      const unsigned long long* const w2[2] = {sw + min(ia, cap - 1), sw + min(ib, cap - 1)};
+      const unsigned t2[2] = {tag, tag};
+      const bool ok2[2] = {ia < cap && (ia & (kPartStride - 1)) < 12, ib < cap && (ib & (kPartStride - 1)) < 12};
+      float o2[2];
+      xch_wait_many<2>(w2, t2, ok2, o2, bar_err, slow_poll);
+      if (ok2[0]) recm[ia] = o2[0];
+      if (ok2[1]) recm[ib] = o2[1];
+    }
     __syncthreads();
     reduce_staged_records(recm, nblocks, red, carry_in, (int)blockIdx.x * kChainGroups, kChainGroups);
     __syncthreads();
@@ -1433,26 +1494,22 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     {
       const int total = nspec * cap;
       for (int i0 = 0; i0 < total; i0 += kChainThreads * 8) {
-        unsigned long long w8[8];
+        const unsigned long long* w8[8];
+        unsigned t8[8];
+        bool ok8[8];
+        float o8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int i = i0 + j * kChainThreads + tid;
-          w8[j] = 0ull;
-          if (i < total && ((i % cap) & (kPartStride - 1)) < 12) {
-            const int set = i / cap, w = i - set * cap;
-            w8[j] = __hip_atomic_load(set_words(2 + set) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          const int i = min(i0 + j * kChainThreads + tid, total - 1);
+          const int set = i / cap, w = i - set * cap;
+          ok8[j] = i0 + j * kChainThreads + tid < total && (w & (kPartStride - 1)) < 12;
+          w8[j] = set_words(2 + set) + w;
+          t8[j] = tag_of(2 + set, 0);
         }
+        xch_wait_many<8>(w8, t8, ok8, o8, bar_err, slow_poll);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = i0 + j * kChainThreads + tid;
-          if (i < total && ((i % cap) & (kPartStride - 1)) < 12) {
-            const int set = i / cap, w = i - set * cap;
-            const unsigned tag = tag_of(2 + set, 0);
-            recm[i] = ((unsigned)(w8[j] >> 32) == tag) ? __uint_as_float((unsigned)w8[j])
-                                                        : xch_wait(set_words(2 + set) + w, tag, bar_err, slow_poll);
-          }
-        }
+        for (int j = 0; j < 8; ++j)
+          if (ok8[j]) recm[i0 + j * kChainThreads + tid] = o8[j];
       }
       __syncthreads();
       for (int set0 = 0; set0 < nspec; set0 += kChainThreads / 160) {
