@@ -232,7 +232,8 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, r
  * Allowed order: begin(k), finish_async(k), begin(k+1), result(k), finish_async(k+1), ... - one result may be outstanding.
  * Between _begin and _finish(_async) of a pair only _result of the previous pair may be called.
  * A pair's match counters ride to the host in the NEXT pair's first-half record when that pair continues from this pair's new
- * map (no copy, no extra wait); otherwise _begin / _result copy them.
+ * map (no copy, no extra wait); otherwise _begin / _result copy them. (Releasing that map before _result is allowed: the
+ * release copies them out first.)
  * (REBVIO_HIP_PAIR_PRELAUNCH=1, opt-in: _begin queues the second half itself, parked behind a pinned flag that _finish
  * releases; the library's own waits for the track stream poll meanwhile, see DESIGN.md. Measured no faster than the default.) */
 /* R_prior_next (may be NULL): the IMU inter-frame rotation the NEXT pair's _begin will be given as R_prior, when the caller

@@ -1343,6 +1343,14 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
   rebvio_hip_ctx* c = m->ctx;
   (void)hipSetDevice(c->device);
   wait_enqueued(m);
+  // a pair's counters still waiting in this map's state record (track_pair_finish_async without its _result yet): copy them
+  // out in stream order before the map can be handed to another frame
+  if (c->h_bf && c->bf_res >= 0 && c->bf_map[c->bf_res] == m && !c->bf_have[c->bf_res] && !c->bf_copy_queued[c->bf_res]) {
+    const int r = c->bf_res;
+    if (hipMemcpyAsync(&c->h_bf[r], m->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk) == hipSuccess &&
+        hipEventRecord(c->bf_done[r], c->s_trk) == hipSuccess)
+      c->bf_copy_queued[r] = true;
+  }
   (void)hipEventRecord(m->done, c->s_trk);
   m->has_done = true;
   if (c->df_map == m) c->df_map = nullptr;

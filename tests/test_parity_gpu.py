@@ -622,6 +622,18 @@ def test_pair_halves_report_the_same_counters_in_every_call_order(B, c2_stream):
         m.release()
     ctx.close()
     assert d == e and len(d) == n // 2
+    # the new map released before its pair's result is fetched: the release copies the counters out first
+    f = []
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    maps = [ctx.detect_u8(frames[i], i * 50000) for i in range(n)]
+    for k in range(0, n - 1, 2):
+        mid = ctx.track_pair_begin(maps[k], maps[k + 1])
+        ctx.track_pair_finish_async(maps[k], maps[k + 1], *_vision_only_fusion(mid))
+        maps[k + 1].release()
+        maps[k].release()
+        f.append(ctx.track_pair_result())
+    ctx.close()
+    assert f == e
 
 
 def test_stream_continues_cleanly_after_a_flush(B, c2_stream):
