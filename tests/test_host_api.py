@@ -136,6 +136,8 @@ def test_host_class_modes_publish_the_same_records(host_lib, tmp_path):
     assert run(REBVIO_HIP_PAIR_PRELAUNCH="1", REBVIO_HIP_DETECT_ASYNC="1") == base
     assert run(REBVIO_HIP_LM="seq") == base
     assert run(REBVIO_HIP_SCAN_SPLIT="0", REBVIO_HIP_ROWSCAN="lane") == base
+    assert run(REBVIO_HIP_COLSCAN="w16") == base     # the wave-resident column pass kept for A/B
+    assert run(REBVIO_HIP_COLSCAN="w4") == base
 
 
 def _write_imu(path, ts, gyro, acc):

@@ -636,6 +636,37 @@ def test_pair_halves_report_the_same_counters_in_every_call_order(B, c2_stream):
     assert f == e
 
 
+def test_streaming_records_do_not_depend_on_the_lm_kernel_choice(B, c2_stream, monkeypatch):
+    """The streaming driver picks the speculative or the sequential persistent LM kernel per pair from the stream's recent
+    accept masks (api.hip, note_accept_mask). Replaying the frames in jumps makes the masks vary, so the default switches
+    back and forth; its records must be those of either kernel pinned."""
+    frames, cam = c2_stream
+    rng = np.random.default_rng(3)
+    order = np.cumsum(rng.integers(1, 6, size=160)) % len(frames)
+    npx = cam.width * cam.height
+
+    def run(mode):
+        if mode is None:
+            monkeypatch.delenv("REBVIO_HIP_LM", raising=False)
+        else:
+            monkeypatch.setenv("REBVIO_HIP_LM", mode)
+        ctx = B.Context(params_for(B, cam, **KW_C2))
+        dev = ctx.upload_frames(frames)
+        rec = []
+        for k, i in enumerate(order):
+            out, n = ctx.push_frame_u8_device(dev + int(i) * npx, k * 50000)
+            if out.status >= 0:
+                rec.append((out.status, out.lm_accept_mask, tuple(out.Vg), tuple(out.Xv), out.klm_num, out.reg_num, n))
+        ctx.flush()
+        ctx.close()
+        return rec
+
+    a, b, c = run(None), run("seq"), run("spec")
+    assert len(a) > 100 and a == b == c
+    masks = {r[1] for r in a}
+    assert 1 in masks and len(masks) >= 3, masks   # consecutive-like pairs and several kinds of later accepts
+
+
 def test_stream_continues_cleanly_after_a_flush(B, c2_stream):
     """rebvio_hip_flush() in the middle of a stream: the stream that follows must start like a fresh one. The last second
     half before the flush has already binned the sigma histogram for a pair that never comes; those counts used to put the
