@@ -191,6 +191,58 @@ __device__ __forceinline__ void wave_chain(float* __restrict__ arr /* LDS, 16-by
   for (int q = 0; q < KQ; ++q)
     if (first + q < n4) *reinterpret_cast<float4*>(arr + (size_t)(first + q) * 4) = a[q];
 }
+// The same array layout, for the FIRST row pass only: its input is the u8 frame times 3.0f, so every partial sum of a row is an
+// integer below 2^24 (cols <= 4096: at most 3.1e6) and exactly representable - any order of the adds gives the bits of the
+// sequential one. So the lanes prefix their own blocks, an inclusive scan over the lanes' totals (six shuffles) gives every
+// lane its offset, and one more add per element finishes: ~40 dependent adds instead of one per element.
+template <int KQ>
+__device__ __forceinline__ void wave_prefix_exact(float* __restrict__ arr /* LDS, 16-byte aligned */, int n4) {
+  const int lane = (int)threadIdx.x & 63;
+  const int first = lane * KQ;
+  float4 a[KQ];
+  float p = 0.f;
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    a[q] = (first + q < n4) ? *reinterpret_cast<const float4*>(arr + (size_t)(first + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    p = p + a[q].x;
+    a[q].x = p;
+    p = p + a[q].y;
+    a[q].y = p;
+    p = p + a[q].z;
+    a[q].z = p;
+    p = p + a[q].w;
+    a[q].w = p;
+  }
+  float incl = p;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(incl, d);
+    if (lane >= d) incl = incl + t;
+  }
+  const float off = incl - p;  // sum of the lower lanes' blocks (exact)
+#pragma unroll
+  for (int q = 0; q < KQ; ++q)
+    if (first + q < n4) {
+      a[q].x = off + a[q].x;
+      a[q].y = off + a[q].y;
+      a[q].z = off + a[q].z;
+      a[q].w = off + a[q].w;
+      *reinterpret_cast<float4*>(arr + (size_t)(first + q) * 4) = a[q];
+    }
+}
+__device__ __forceinline__ bool wave_prefix_exact_any(float* __restrict__ arr, int n4) {
+  switch ((n4 + 63) >> 6) {
+    case 1: wave_prefix_exact<1>(arr, n4); return true;
+    case 2: wave_prefix_exact<2>(arr, n4); return true;
+    case 3: wave_prefix_exact<3>(arr, n4); return true;
+    case 4: wave_prefix_exact<4>(arr, n4); return true;
+    case 5: wave_prefix_exact<5>(arr, n4); return true;
+    case 6: wave_prefix_exact<6>(arr, n4); return true;
+    case 7: wave_prefix_exact<7>(arr, n4); return true;
+    case 8: wave_prefix_exact<8>(arr, n4); return true;
+    default: return false;
+  }
+}
 // n4 <= 512 chunks (2048 elements); longer arrays keep the one-lane loop of the caller
 __device__ __forceinline__ bool wave_chain_any(float* __restrict__ arr, int n4) {
   switch ((n4 + 63) >> 6) {
@@ -247,7 +299,12 @@ __device__ __forceinline__ void rowscan_body(const void* __restrict__ src0, cons
   }
   __syncthreads();
   const bool wide = ldw_signed > 0 && C4 <= 512;  // wave lr chains strip row lr in registers (wave_chain); else one lane per row below
-  if (wide && rvalid) (void)wave_chain_any(tile + lr * ldw, C4);
+  if (wide && rvalid) {
+    if (MODE == 0)
+      (void)wave_prefix_exact_any(tile + lr * ldw, C4);  // integer-valued sums: order free (see wave_prefix_exact)
+    else
+      (void)wave_chain_any(tile + lr * ldw, C4);
+  }
   if (!wide && (int)threadIdx.x < nrows) {
     // sequential chain over the row; LDS reads run four float4 ahead of the adds (two register groups)
     float* rowp = tile + threadIdx.x * ldw;
