@@ -167,8 +167,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=None,
-                    help="untimed frames, exactly as given; default 1000: the stream needs ~1000 frames until depths / match "
-                         "queues reach their steady state")
+                    help="untimed frames in front of the timed region, exactly as given (default 1000). The stream needs ~1000 "
+                         "frames until depths / match queues reach their steady state: a shorter warm-up is preceded by "
+                         "1000 - W untimed settle frames (config.settle_frames in the line)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--base-frames", type=int, default=24, help="distinct rendered frames (ping-pong replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,7 +269,15 @@ def main():
     ctx = B.Context(B.default_params(H, W, **kw))
     dev = ctx.upload_frames(frames)
     npx = W * H
-    order = synth.pingpong_indices(args.base_frames, warmup + steps + 64)  # GPU leg only; the CPU leg builds its own list
+    # The stream needs ~1000 frames until depth filters and match queues reach their steady state (the first frames run faster:
+    # few long searches). A run with a short --warmup is first brought there by `settle` untimed frames, so that the timed
+    # window measures the SUSTAINED rate whatever W is; the W warm-up frames as given follow, then the timed region.
+    settle = max(0, 1000 - warmup)
+    # A window of few frames also carries the pipeline's fill and drain (GPU idle at both brackets, ~130 us = 1.6 frames,
+    # 8 % of a 20-frame window): runs shorter than 1000 steps are followed by an extra, separately bracketed window of 2000
+    # frames whose rate is reported next to the contract's figure (config.long_window), never instead of it.
+    long_steps = 2000 if steps < 1000 else 0
+    order = synth.pingpong_indices(args.base_frames, settle + warmup + steps + long_steps + 96)  # GPU leg only; the CPU leg builds its own list
 
     def push(i):
         return ctx.push_frame_u8_device(dev + int(order[i]) * npx, i * 50000)
@@ -280,12 +289,15 @@ def main():
 
     # ---- warm-up (threshold servo settles at keylines_ref; pools, streams, code objects warm) --------------
     k = 0
-    for _ in range(warmup):
+    last_warm = min(warmup, 32)  # the warm-up frames that run directly in front of the timed region (below)
+    for _ in range(settle + warmup - last_warm):
         push(k)
         k += 1
     torch.cuda.synchronize()
 
-    # ---- find the dominant kernel (all-kernel event pass, untimed) ------------------------------------------
+    # ---- find the dominant kernel (all-kernel event pass, untimed; BEFORE the warm-up so that the W warm-up frames run
+    # right in front of the timed region - reading ~300 event pairs back keeps the host busy and the GPU idle for
+    # milliseconds, after which the first frames run a few per cent slower) ------------------------------------
     ctx.profile_reset()
     ctx.profile(True)
     nprof = 24
@@ -306,12 +318,20 @@ def main():
     dominant = max(debiased, key=debiased.get)
     n_keylines = int(np.median([c for c in kl_counts if c >= 0])) if kl_counts else 0
 
+    # ---- the last warm-up frames, directly in front of the timed region --------------------------------------------
+    for _ in range(last_warm):
+        push(k)
+        k += 1
+    torch.cuda.synchronize()
+
     # ---- timed region: EXACTLY `steps` frames ------------------------------------------------------------------
     ctx.profile_reset()
     # HIP events around every n-th launch of the dominant kernel (n >= 8, at most ~200 samples: the event pool is
     # preallocated, creating events inside the timed region would cost more than it measures), on the stream it runs on
     n_launch = steps * launches_per_frame(dominant)
-    ctx.profile(True, only=dominant, stride=max(8, n_launch // 200) if n_launch >= 160 else max(1, n_launch // 10))  # short runs: ~10 samples
+    # (an event pair is two more packets on the track stream, ~4 us on the chain of the pair it brackets - measured on a 20-frame
+    # window: every 2nd launch 11.4 k frames/s, every 4th 11.9 k, every 8th 12.1 k, none 12.2 k - hence every 8th at most)
+    ctx.profile(True, only=dominant, stride=int(os.environ.get("REBVIO_BENCH_STRIDE", max(8, n_launch // 200))))
     statuses = []
     matches = []
     push_done = np.zeros(steps, np.float64)
@@ -330,9 +350,21 @@ def main():
     elapsed = t1 - t0
     dom = ctx.profile_read().get(dominant, (0.0, 0))
     ctx.profile(False)
+    long_elapsed = 0.0
+    if long_steps:
+        barrier()
+        tl0 = time.perf_counter()
+        for _ in range(long_steps):
+            push(k)
+            k += 1
+        torch.cuda.synchronize()
+        long_elapsed = time.perf_counter() - tl0
+        if world > 1:
+            dist.barrier()
     ctx.flush()
 
     tmax = shard.max_over_ranks(elapsed, world, "cuda" if backend_name == "nccl" else "cpu")
+    long_tmax = shard.max_over_ranks(long_elapsed, world, "cuda" if backend_name == "nccl" else "cpu") if long_steps else 0.0
     bad = sum(1 for s in statuses if s not in (0, -1))  # -1: no finished pair to report in that call
     if bad:
         print(f"[rank {rank}] WARNING: {bad} of {steps} frame pairs ended with a non-zero tracking status", file=sys.stderr)
@@ -359,7 +391,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["name"], "streams": world, "keylines": n_keylines,
                        "mean_matches": float(np.mean([m for m in matches if m > 0])) if any(m > 0 for m in matches) else 0.0,
-                       "frames_in_hbm": args.base_frames, "parallelism": f"{world} independent streams, 1 per GPU",
+                       "frames_in_hbm": args.base_frames, "settle_frames": settle,
+                       "long_window": ({"steps": long_steps, "value": shard.whole_job_fps(world, long_steps, long_tmax), "unit": "frames/s",
+                                        "note": "same loop, bracketed the same way, right after the timed region: the rate without "
+                                                "the weight a short window gives to pipeline fill and drain"} if long_steps else None),
+                       "parallelism": f"{world} independent streams, 1 per GPU",
                        "rank0_numa_node": numa_node,
                        "pose_tolerance": "keyline set/order and every per-keyline output bit-exact vs the CPU restatement; pair "
                                          "velocity within 5e-3 (rel.) of the restatement run with double-accumulated sums - the "
