@@ -96,6 +96,25 @@ def test_scale_space_bit_exact(orc_mod, B, c2_stream):
             assert _bits_equal(so[k], sg[k]), f"{k} differs in {(so[k] != sg[k]).sum()} pixels"
 
 
+@pytest.mark.parametrize("width", [2048, 2044, 1300])
+def test_first_row_pass_is_exact_on_wide_bright_frames(orc_mod, B, width):
+    """The first row pass of a MONO8 frame is a parallel prefix (its partial sums are integers below 2^24, any order gives
+    the sequential bits: detect.hip, wave_prefix_exact). Widest frames the wave form takes (2048 columns, eight chunks per
+    lane), a width that fills the last lanes partially, and near-white pixels so that the row sums are as large as they get."""
+    h = 48
+    rng = np.random.default_rng(width)
+    frames = [rng.integers(200, 256, (h, width)).astype(np.uint8) for _ in range(2)]
+    frames[1][:, ::3] = 255
+    kw = dict(keylines_ref=3000, keylines_max=6000)
+    orc = orc_mod.Oracle(orc_mod.default_params(h, width, **kw))
+    ctx = B.Context(B.default_params(h, width, **kw))
+    for i, f in enumerate(frames):
+        om, gm = orc.detect_u8(f, i * 50000), ctx.detect_u8(f, i * 50000)
+        assert_keylines_equal(om.keylines(), gm.keylines(), what=f"{width} wide, frame {i}")
+        assert np.array_equal(om.mask(h, width), gm.mask())
+        assert om.threshold == gm.threshold
+
+
 @pytest.mark.parametrize("shape", [(64, 48), (100, 36), (752, 480), (642, 480), (65, 49), (131, 67)])
 def test_scale_space_ragged_sizes(orc_mod, B, shape):
     """Widths that are not multiples of the 64-lane tiles / 16-row strips, EuRoC's 752x480, and widths that are not a
