@@ -169,7 +169,8 @@ class Map:
 
     def release(self):
         if self.h:
-            lib().rebvio_hip_map_release(self.h)
+            if getattr(self.ctx, "h", None):  # the context owns the map's memory: nothing left to hand back once it is closed
+                lib().rebvio_hip_map_release(self.h)
             self.h = None
 
     def __del__(self):
