@@ -55,7 +55,9 @@ class EdgeMap {
   int regularize1Iter();
 
   // --- backend plumbing (not part of the reference surface) ---
-  void attach(rebvio_hip_ctx* ctx, rebvio_hip_map* handle);
+  // `keepalive` owns the backend context the handle belongs to (backend::Session): a map kept by an edge-image consumer
+  // (ros_rebvio.cpp:32-51) past ~Rebvio keeps its context alive and releases into it.
+  void attach(rebvio_hip_ctx* ctx, rebvio_hip_map* handle, std::shared_ptr<void> keepalive = nullptr);
   rebvio_hip_map* handle() const { return handle_; }
   rebvio_hip_ctx* ctx() const { return ctx_; }
   void invalidateMirror() { mirror_valid_ = false; mask_valid_ = false; }
@@ -65,6 +67,7 @@ class EdgeMap {
   rebvio::EdgeMapConfig::SharedPtr config_;
   rebvio::Camera::SharedPtr camera_;
   uint64_t ts_us_;
+  std::shared_ptr<void> keepalive_;  // declared before the handle: destroyed after the destructor body has released it
   rebvio_hip_ctx* ctx_ = nullptr;
   rebvio_hip_map* handle_ = nullptr;
   std::vector<rebvio::types::KeyLine> keylines_;

@@ -169,8 +169,7 @@ class Map:
 
     def release(self):
         if self.h:
-            if getattr(self.ctx, "h", None):  # the context owns the map's memory: nothing left to hand back once it is closed
-                lib().rebvio_hip_map_release(self.h)
+            lib().rebvio_hip_map_release(self.h)  # safe after the context is closed too: the library drops the husk
             self.h = None
 
     def __del__(self):

@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -149,8 +150,18 @@ void prof_group_end(hipStream_t s) {
 }  // namespace rh
 
 // ---- objects ----------------------------------------------------------------------------------------
+// Shared by a context and every map handle it has handed out: a map released (or queried) after rebvio_hip_destroy must not
+// touch the freed context. The block outlives the context for as long as a handle is still out; `dead` is set by destroy,
+// under `mu`, which also serialises destroy against a release from another thread (an EdgeMap::SharedPtr kept by an
+// edge-image consumer, ros_rebvio.cpp:32-51, is released whenever that consumer lets go of it).
+struct LifeBlock {
+  std::mutex mu;
+  std::atomic<bool> dead{false};
+};
+
 struct rebvio_hip_map {
   rebvio_hip_ctx* ctx = nullptr;
+  std::shared_ptr<LifeBlock> life;
   MapDev d{};
   bool in_use = false;
   uint64_t ts = 0;
@@ -175,13 +186,14 @@ struct rebvio_hip_map {
 };
 
 struct rebvio_hip_ctx {
+  std::shared_ptr<LifeBlock> life = std::make_shared<LifeBlock>();
   rebvio_hip_params P{};
   KParams K{};
   int device = 0;
   hipStream_t s_det{}, s_key{}, s_df{}, s_trk{}, s_cpy{};
   double t_begin_enq = 0, t_begin_wait = 0;  // REBVIO_HIP_DEBUG: host time of track_pair_begin (enqueue / wait for the first half)
   uint64_t t_begin_n = 0;
-  std::mutex dl_mu;             // rebvio_hip_map_download: aos_dev
+  std::mutex dl_mu;             // aos_dev / scratch_i users (map_download, map_upload, render, field decode) and trk_touched
   bool scan_split = true;       // last column pass + k_dog_mag on s_key (detect_launch)
   float* sa2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [frame parity][filter]: sb.a per parity ([0] aliases sb.a)
   // scale-space outputs (DoG, squared gradient, per-row counts) are double buffered: the scans of frame f+1 (s_det)
@@ -316,6 +328,17 @@ struct rebvio_hip_ctx {
 };
 
 namespace {
+void release_map(rebvio_hip_map* m);
+
+// A map handle whose context has been destroyed: every entry point that takes a map alone answers with this.
+inline bool map_dead(const rebvio_hip_map* m) { return !m || !m->life || m->life->dead.load(std::memory_order_acquire); }
+#define MAP_ALIVE_OR(m, ret)                                                   \
+  do {                                                                         \
+    if (map_dead(m)) {                                                         \
+      g_err = "the map's context has been destroyed (rebvio_hip_destroy)";     \
+      return ret;                                                              \
+    }                                                                          \
+  } while (0)
 
 // events of a map may only be waited on once the detect worker has recorded them
 inline void wait_enqueued(rebvio_hip_map* m) {
@@ -403,16 +426,20 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   return 0;
 }
 
-void free_map(rebvio_hip_map* m) {
+// device arrays and events of a map; the host struct stays (a handle the caller still holds is deleted by its release)
+void free_map_device(rebvio_hip_map* m) {
   MapDev& d = m->d;
   void* ptrs[] = {d.pos, d.pos_img, d.mpos_img, d.grad, d.grad_tmp, d.mgrad, d.gnorm, d.mgnorm, d.rs, d.rs_tmp, d.id_prev, d.id_next,
                   d.match_id, d.match_fwd, d.match_kf, d.matches, d.fwd_key, d.residual, d.mask, d.df, d.unit, d.tile_cnt, d.tile_list, d.row_start, d.st};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  d = MapDev{};
+  m->canon = MapDev{};
   if (m->ready) (void)hipEventDestroy(m->ready);
   if (m->detected) (void)hipEventDestroy(m->detected);
   if (m->done) (void)hipEventDestroy(m->done);
-  delete m;
+  m->ready = m->detected = m->done = hipEvent_t{};
+  m->ctx = nullptr;
 }
 
 int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m);
@@ -439,7 +466,9 @@ rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
   if (c->pool.size() >= 256) return nullptr;
   rebvio_hip_map* m = new rebvio_hip_map;
   m->ctx = c;
+  m->life = c->life;
   if (alloc_map(c, m) != 0) {
+    free_map_device(m);
     delete m;
     return nullptr;
   }
@@ -470,7 +499,12 @@ int fetch_map_state(rebvio_hip_map* m, MapState* out, hipStream_t after) {
 
 // Every use of a map on the track stream starts with this wait on its detection (+ distance field).
 hipError_t trk_wait_ready(hipStream_t s, rebvio_hip_map* m) {
-  m->trk_touched.store(true, std::memory_order_release);
+  if (!m->trk_touched.load(std::memory_order_relaxed)) {
+    // first use by the tracker: not while a download of an "untouched" map is packing it on the copy stream
+    // (rebvio_hip_map_download decides and packs under the same mutex)
+    std::lock_guard<std::mutex> dl(m->ctx->dl_mu);
+    m->trk_touched.store(true, std::memory_order_release);
+  }
   return hipStreamWaitEvent(s, m->ready, 0);
 }
 // The same, once per map and context stream: every wait is a barrier packet of its own between two kernels of the track
@@ -1076,6 +1110,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   for (int i = 0; i < pool; ++i) {
     rebvio_hip_map* m = new rebvio_hip_map;
     m->ctx = c;
+    m->life = c->life;
     c->pool.push_back(m);
     int rc = alloc_map(c, m);
     if (rc) return rc;
@@ -1091,6 +1126,10 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
 
 void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (!c) return;
+  // Map handles the caller still holds outlive the context as inert husks: every map entry point checks `dead`, and the
+  // husk is deleted by its rebvio_hip_map_release. The lock serialises this against a release running on another thread.
+  const std::shared_ptr<LifeBlock> life = c->life;
+  std::lock_guard<std::mutex> life_lk(life->mu);
   (void)hipSetDevice(c->device);
   release_parked_pair(c);
   if (std::getenv("REBVIO_HIP_DEBUG") && c->t_begin_n)
@@ -1109,7 +1148,16 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
     std::lock_guard<std::mutex> g(g_prof.mu);
     g_prof.drain();
   }
-  for (auto* m : c->pool) free_map(m);
+  // maps the streaming driver still holds are the library's own, not the caller's
+  for (auto* m : c->frames) m->in_use = false;
+  if (c->has_cur) c->cur.om->in_use = c->cur.nm->in_use = false;
+  if (c->has_prev) c->prev.nm->in_use = false;
+  life->dead.store(true, std::memory_order_release);
+  for (auto* m : c->pool) {
+    free_map_device(m);
+    if (!m->in_use) delete m;  // (else: a handle is still out; its release deletes the husk)
+  }
+  c->pool.clear();
   void* dptr[] = {c->sb.a[0], c->sb.a[1], c->sb.b[0], c->sb.b[1], c->sb.dog, c->sb.mag, c->db.stash, c->db.bits,
                   c->db.rowcount, c->det, c->img_dev, c->img8_dev, c->aos_dev, c->scratch_i, c->diag0, c->diag1, c->lm,
                   c->part, c->xrv_part, c->hist, c->fscratch};
@@ -1263,20 +1311,26 @@ int rebvio_hip_detector_state(rebvio_hip_ctx* c, float* threshold, float* auto_t
 }
 
 int rebvio_hip_map_size(rebvio_hip_map* m) {
+  MAP_ALIVE_OR(m, -10);
   if (ensure_size(m)) return -1;
   return m->n_host;
 }
 float rebvio_hip_map_threshold(rebvio_hip_map* m) {
+  MAP_ALIVE_OR(m, std::numeric_limits<float>::quiet_NaN());
   if (ensure_size(m)) return std::numeric_limits<float>::quiet_NaN();
   return m->thr_host;
 }
 uint64_t rebvio_hip_map_ts(rebvio_hip_map* m) { return m->ts; }
 
 int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int* mask) {
+  MAP_ALIVE_OR(m, -10);
   rebvio_hip_ctx* c = m->ctx;
   HIPCHK(hipSetDevice(c->device));
   int rc = ensure_size(m);
   if (rc) return rc;
+  // one packing buffer per context (callbacks and the fusion thread may both mirror maps); the same mutex orders the
+  // "has the tracker touched this map" decision below against the tracker's first use of it (trk_wait_ready)
+  std::lock_guard<std::mutex> dl(c->dl_mu);
   // The mirror reflects everything enqueued so far that concerns THIS map: its detection and distance field (`ready`,
   // recorded behind them; ensure_size has waited for the detect worker to enqueue them) and, once the tracker has used the
   // map, the track stream. A map fresh from detect() (edge-image callbacks, ros_rebvio.cpp:32-50) does not wait for the
@@ -1290,7 +1344,6 @@ int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int
     wait_enqueued(m);
     HIPCHK(hipEventSynchronize(m->ready));
   }
-  std::lock_guard<std::mutex> dl(c->dl_mu);  // one packing buffer per context (callbacks and the fusion thread may both mirror maps)
   if (keylines && m->n_host > 0) {
     launch_map_pack(c->s_cpy, c->K, m->d, c->aos_dev);
     HIPCHK(hipMemcpyAsync(keylines, c->aos_dev, (size_t)m->n_host * sizeof(rebvio_hip_keyline), hipMemcpyDeviceToHost, c->s_cpy));
@@ -1302,8 +1355,10 @@ int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int
 }
 
 int rebvio_hip_render_edge_image(rebvio_hip_map* m, const uint8_t* gray, uint8_t* rgb_out) {
+  MAP_ALIVE_OR(m, -10);
   rebvio_hip_ctx* c = m->ctx;
   HIPCHK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> dl(c->dl_mu);
   HIPCHK(hipStreamSynchronize(c->s_det));  // the staging frame and the scratch are shared with the detect path
   HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_df));
@@ -1319,11 +1374,13 @@ int rebvio_hip_render_edge_image(rebvio_hip_map* m, const uint8_t* gray, uint8_t
 }
 
 int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines, int n) {
+  MAP_ALIVE_OR(m, -10);
   rebvio_hip_ctx* c = m->ctx;
   HIPCHK(hipSetDevice(c->device));
   int rc = ensure_size(m);
   if (rc) return rc;
   if (n != m->n_host) return fail_msg("map_upload: count differs from map size", -6);
+  std::lock_guard<std::mutex> dl(c->dl_mu);
   HIPCHK(hipStreamSynchronize(c->s_df));
   HIPCHK(hipStreamSynchronize(c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_key));
@@ -1339,6 +1396,22 @@ int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines,
 }
 
 void rebvio_hip_map_release(rebvio_hip_map* m) {
+  if (!m) return;
+  const std::shared_ptr<LifeBlock> life = m->life;
+  std::lock_guard<std::mutex> lk(life->mu);
+  if (life->dead.load(std::memory_order_acquire)) {  // the context is gone (its memory with it): drop the husk
+    if (m->in_use) delete m;
+    return;
+  }
+  release_map(m);
+}
+
+}  // extern "C"
+
+namespace {
+// Stream-ordered return of a map to its pool (the library's own releases call this directly; the C-ABI entry adds the
+// lifetime check).
+void release_map(rebvio_hip_map* m) {
   if (!m || !m->in_use) return;
   rebvio_hip_ctx* c = m->ctx;
   (void)hipSetDevice(c->device);
@@ -1357,6 +1430,9 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
   m->release_seq = ++c->release_counter;
   m->in_use = false;  // (c->last_detected may keep pointing at it: only its MapState is read, stream-ordered)
 }
+}  // namespace
+
+extern "C" {
 
 int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipSetDevice(c->device));
@@ -1376,6 +1452,7 @@ int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
 int rebvio_hip_distance_field(rebvio_hip_ctx* c, int* id_out, int* dist_out) {
   HIPCHK(hipSetDevice(c->device));
   if (!c->df_map) return fail_msg("no distance field built", -7);
+  std::lock_guard<std::mutex> dl(c->dl_mu);
   const size_t Pn = (size_t)c->P.rows * c->P.cols;
   launch_df_decode(c->s_trk, c->K, c->df_map->d, c->scratch_i, c->scratch_i + Pn);
   HIPCHK(hipGetLastError());
@@ -1386,11 +1463,13 @@ int rebvio_hip_distance_field(rebvio_hip_ctx* c, int* id_out, int* dist_out) {
 }
 
 int rebvio_hip_map_distance_field(rebvio_hip_map* m, int* id_out, int* dist_out) {
+  MAP_ALIVE_OR(m, -10);
   rebvio_hip_ctx* c = m->ctx;
   HIPCHK(hipSetDevice(c->device));
   if (!m->df_built) return fail_msg("map_distance_field: no distance field has been built from this map", -7);
   wait_enqueued(m);
   HIPCHK(trk_wait_ready(c->s_trk, m));
+  std::lock_guard<std::mutex> dl(c->dl_mu);
   const size_t Pn = (size_t)c->P.rows * c->P.cols;
   launch_df_decode(c->s_trk, c->K, m->d, c->scratch_i, c->scratch_i + Pn);
   HIPCHK(hipGetLastError());
@@ -1966,7 +2045,7 @@ int enqueue_b_chain_pre(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp, bool
   std::swap(pp.nm->d.rs, pp.nm->d.rs_tmp);
   std::swap(pp.nm->d.grad, pp.nm->d.grad_tmp);
   pp.nm->pre_rotated = true;
-  if (!defer_release) rebvio_hip_map_release(pp.om);  // stream-ordered: reusable once the B-chain has drained
+  if (!defer_release) release_map(pp.om);  // stream-ordered: reusable once the B-chain has drained
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2044,7 +2123,7 @@ int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* compl
     enqueue_b_chain(c, cur.om, cur.nm, g, RT_next);
     c->t_b_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tg1).count();
     HIPCHK(hipGetLastError());
-    rebvio_hip_map_release(cur.om);  // stream-ordered: reusable once the B-chain has drained
+    release_map(cur.om);  // stream-ordered: reusable once the B-chain has drained
     guard.armed = false;
   }
   if (g.nan_v) cur.out.status = 1;
@@ -2115,7 +2194,7 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   }
   // the old map of the pair in flight: its release (an event record) goes behind the next first half, off the path between
   // k_regularize_ekf(k) and k_lm_chain(k+1)
-  if (deferred) rebvio_hip_map_release(deferred);
+  if (deferred) release_map(deferred);
   c->t_a_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta0).count();
   // 3. wait for the pair in flight, glue, release (also on the error paths above: finish_current's guard releases)
   if (c->has_cur) {
@@ -2189,11 +2268,11 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     if (rc2) return rc2;
   }
   if (c->has_prev) {
-    rebvio_hip_map_release(c->prev.nm);
+    release_map(c->prev.nm);
     c->has_prev = false;
   }
   for (auto* m : c->frames)
-    if (m->in_use) rebvio_hip_map_release(m);
+    if (m->in_use) release_map(m);
   c->frames.clear();
   // The last second half binned the sigma histogram for a pair that will not come (its next-rotation rides in the last
   // kernel): a stream that continues after the flush must not find those counts under its first pair's (they put the
@@ -2578,6 +2657,14 @@ void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
     b->det_thread.join();
   }
   (void)hipDeviceSynchronize();
+  // the maps of queued steps and of the pairs in flight are the batch's own, not handles a caller holds
+  for (auto& f : b->frames)
+    for (auto* m : f.m) m->in_use = false;
+  if (b->has_cur)
+    for (auto* fr : {&b->cur.of, &b->cur.nf})
+      for (auto* m : fr->m) m->in_use = false;
+  if (b->has_prev)
+    for (auto* m : b->prev.nf.m) m->in_use = false;
   for (auto* c : b->lane) rebvio_hip_destroy(c);
   if (b->ls_dev) (void)hipFree(b->ls_dev);
   if (b->maptab_dev) (void)hipFree(b->maptab_dev);

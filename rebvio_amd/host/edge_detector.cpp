@@ -26,7 +26,7 @@ rebvio::EdgeMap::SharedPtr EdgeDetector::detect(rebvio::types::Image& image) {
     backend::fail("EdgeDetector::detect: image must be CV_8UC1 or CV_32FC1", -1);
   }
   auto map = std::make_shared<rebvio::EdgeMap>(camera_, config_->keylines_max, image.ts_us);
-  map->attach(ctx, h);
+  map->attach(ctx, h, session_);
   return map;
 }
 

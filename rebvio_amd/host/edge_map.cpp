@@ -17,7 +17,8 @@ EdgeMap::~EdgeMap() {
   if (handle_) rebvio_hip_map_release(handle_);
 }
 
-void EdgeMap::attach(rebvio_hip_ctx* ctx, rebvio_hip_map* handle) {
+void EdgeMap::attach(rebvio_hip_ctx* ctx, rebvio_hip_map* handle, std::shared_ptr<void> keepalive) {
+  keepalive_ = std::move(keepalive);
   ctx_ = ctx;
   handle_ = handle;
   invalidateMirror();

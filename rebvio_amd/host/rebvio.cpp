@@ -31,6 +31,22 @@ namespace {
 struct ScopeOpener {  // runs before the detector/tracker members are constructed
   explicit ScopeOpener(int device) { backend::Session::newScope(device); }
 };
+
+// The reference library throws nothing from its workers: a failed step prints to stderr and clears run_
+// (rebvio.cpp:236-252). A backend error surfacing on a worker thread (edge-map pool exhausted, a HIP failure) does the
+// same here instead of ending the process through std::terminate.
+template <class Body>
+void run_worker(const char* name, std::atomic<bool>& run, Body&& body) {
+  try {
+    body();
+  } catch (const std::exception& e) {
+    std::cerr << name << " stopped: " << e.what() << "\n";
+    run = false;
+  } catch (...) {
+    std::cerr << name << " stopped: unknown error\n";
+    run = false;
+  }
+}
 }  // namespace
 
 Rebvio::Rebvio(rebvio::RebvioConfig& config)
@@ -41,8 +57,8 @@ Rebvio::Rebvio(rebvio::RebvioConfig& config)
       sab_state_(config_.imu_state) {
   core_.session()->setImuNoise(config_.imu_state.gyro_std_dev, config_.imu_state.gyro_bias_std_dev);
   core_.session()->ctx();  // create the device context now: fail loudly here, not in a worker thread
-  data_acquisition_thread_ = std::thread(&Rebvio::dataAcquisitionProcess, this);
-  state_estimation_thread_ = std::thread(&Rebvio::stateEstimationProcess, this);
+  data_acquisition_thread_ = std::thread([this] { run_worker("Data Acquisition Process", run_, [this] { dataAcquisitionProcess(); }); });
+  state_estimation_thread_ = std::thread([this] { run_worker("State Estimation Process", run_, [this] { stateEstimationProcess(); }); });
 }
 
 Rebvio::~Rebvio() {

@@ -107,6 +107,24 @@ def test_stream_example_runs_like_ros_rebvio(host_lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_edge_maps_outlive_their_pipeline(host_lib, tmp_path):
+    """Map lifetime (rebvio.hpp:104-109, ros_rebvio.cpp:32-51): EdgeMap::SharedPtrs kept by an edge-image consumer stay readable
+    after ~Rebvio and release cleanly; at the C-ABI a handle that outlives rebvio_hip_destroy answers -10 and its release frees
+    only the husk (round 2 dumped core here: a release dereferenced the freed pool)."""
+    from rebvio_amd import synth
+    n = 6
+    frames, cam = synth.render_stream(256, 192, n)
+    p = tmp_path / "frames.u8"
+    frames.tofile(p)
+    exe = str(tmp_path / "map_lifetime")
+    subprocess.run(["g++", "-std=c++17", "-O1"] + INC + [os.path.join(ROOT, "tests", "cpp", "test_map_lifetime.cpp"), "-o", exe,
+                    "-L", host_lib, "-lrebvio", "-lrebvio_hip", f"-Wl,-rpath,{host_lib}", "-pthread"], check=True)
+    r = subprocess.run([exe, str(p), "256", "192", str(n), repr(cam.fm), repr(cam.cx), repr(cam.cy)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
 def test_host_class_modes_publish_the_same_records(host_lib, tmp_path):
     """rebvio::Rebvio with its edge-image callback reading a keyline of every fresh map (as ros_rebvio.cpp:44 does), under the
     backend's scheduling options: second halves parked behind a pinned flag (REBVIO_HIP_PAIR_PRELAUNCH=1; a callback's map
