@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define REBVIO_HIP_ABI_VERSION 1
+#define REBVIO_HIP_ABI_VERSION 2
 
 /* Host mirror of one keyline: field-for-field rebvio::types::KeyLine
  * (rebvio/include/rebvio/types/keyline.hpp:24-40), 84 bytes. Device storage is SoA. */
@@ -134,7 +134,10 @@ int rebvio_hip_map_size(rebvio_hip_map* m);
 float rebvio_hip_map_threshold(rebvio_hip_map* m);
 uint64_t rebvio_hip_map_ts(rebvio_hip_map* m);
 /* Lazy host mirror of keylines() / mask() (edge_map.hpp:50,75): AoS keylines (may be NULL) and the
- * dense image-index -> keyline-index table (may be NULL; -1 = none). */
+ * dense image-index -> keyline-index table (may be NULL; -1 = none). A map fresh from detect() only waits for its own detection;
+ * once a tracking call has been given the map the download waits for the track stream as well. Downloading a map from one
+ * thread WHILE another thread's tracking call works on it mirrors some state in between (as reading a reference EdgeMap
+ * during its tracking step would). */
 int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int* mask);
 /* Edge image for registerEdgeImageCallback consumers, rendered on the device the way ros_rebvio.cpp:32-50 draws it on
  * the host: the grey frame (rows*cols bytes, NULL = black) replicated to RGB, each keyline's pixel
@@ -143,6 +146,9 @@ int rebvio_hip_render_edge_image(rebvio_hip_map* map, const uint8_t* gray_host, 
 
 /* Test hook: overwrite the device keylines (count must equal the map size). */
 int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines, int n);
+/* Map handles may outlive their context: after rebvio_hip_destroy the entries that take a map alone (size, threshold, download,
+ * render, upload, map_distance_field) fail with -10 (NaN for the threshold) and rebvio_hip_map_release frees what is left of the
+ * handle - nothing of the destroyed context is touched. (A handle must still be released exactly once.) */
 void rebvio_hip_map_release(rebvio_hip_map* m);
 
 /* Core::buildDistanceField / DistanceField::build (core.cpp:33-37, core.hpp:37-59). */
@@ -233,12 +239,12 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, r
  * Between _begin and _finish(_async) of a pair only _result of the previous pair may be called.
  * A pair's match counters ride to the host in the NEXT pair's first-half record when that pair continues from this pair's new
  * map (no copy, no extra wait); otherwise _begin / _result copy them. (Releasing that map before _result is allowed: the
- * release copies them out first.)
- * (REBVIO_HIP_PAIR_PRELAUNCH=1, opt-in: _begin queues the second half itself, parked behind a pinned flag that _finish
- * releases; the library's own waits for the track stream poll meanwhile, see DESIGN.md. Measured no faster than the default.) */
+ * release copies them out first.) */
 /* R_prior_next (may be NULL): the IMU inter-frame rotation the NEXT pair's _begin will be given as R_prior, when the caller
  * already has it. That pair's first rotateKeylines (rebvio.cpp:163-165) then runs inside this pair's last kernel and its
- * _begin launches one kernel less; _begin returns -7 if its R_prior (or the gyro state) does not match what was applied. */
+ * _begin launches one kernel less. R_prior_next is a promise: the old map is rotated in place with it, so the next _begin must
+ * be given the same R_prior and must find the gyro state this pair's _begin left (no rebvio_hip_set_gyro_state / _reset_state
+ * in between); otherwise it returns -7 and that pair cannot be tracked from this map any more. */
 int rebvio_hip_track_pair_finish_async(rebvio_hip_ctx* ctx, rebvio_hip_map* old_map, rebvio_hip_map* new_map, const float V[3],
                                        const float P_V[9], const float Rgva[9], const float R_second[9], const float* R_prior_next);
 int rebvio_hip_track_pair_result(rebvio_hip_ctx* ctx, int* klm_num, int* kf_matches, int* reg_num, int* status);
@@ -248,12 +254,19 @@ int rebvio_hip_track_pair_result(rebvio_hip_ctx* ctx, int* klm_num, int* kf_matc
 int rebvio_hip_track_pair_hint_next(rebvio_hip_ctx* ctx, rebvio_hip_map* next_new_map);
 
 /* Streaming driver used by the bench: a software pipeline, detect(frame) on the scan / keyline streams overlapped with
- * the tracking of EARLIER pairs on the track stream. `out` receives the most recent COMPLETE pair, in pair order, several
- * calls behind `frame` (the detect stage leads the tracker by REBVIO_HIP_LEAD frames, default 5, and a pair's match
- * counters arrive with the next pair); status -1 while nothing is complete yet. rebvio_hip_flush() finishes the pair in
- * flight and drops the frames no pair was started for. */
+ * the tracking of EARLIER pairs on the track stream. A pair runs on the device from end to end: the glue between its halves
+ * (6x6 solve, gyroBiasCorrection, SO3, covariance: rebvio.cpp:177-233 without the accelerometer branch) is evaluated in front
+ * of the directedMatch kernel from the first half's records, with the gyro-bias state kept in device memory, so the host only
+ * queues launches and reads records. `out` receives the oldest COMPLETE pair not handed out yet, in pair order, several calls
+ * behind `frame` (the detect stage leads the tracker by REBVIO_HIP_LEAD frames, default 5; a pair's match counters arrive with
+ * the next pair; up to seven pairs are in flight between the device and the host); status -1 while there is none.
+ * rebvio_hip_flush() finishes the pairs in flight and drops the frames no pair was started for; the records it completes (and
+ * any others not handed out yet) are fetched with rebvio_hip_next_record: 1 = *out / *keylines filled, 0 = none left.
+ * rebvio_hip_get_gyro_state follows the stream with that lag and is exact after a flush; rebvio_hip_set_gyro_state is refused
+ * (-7) while frames are in flight. */
 int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_dev, uint64_t ts_us,
                                     rebvio_hip_pair_out* out, int* keylines);
+int rebvio_hip_next_record(rebvio_hip_ctx* ctx, rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_flush(rebvio_hip_ctx* ctx);
 
 /* Several camera streams on ONE GPU, advanced in lock-step ("lanes" of a batch). The reference runs one rebvio::Rebvio per
@@ -262,9 +275,15 @@ int rebvio_hip_flush(rebvio_hip_ctx* ctx);
  * of an MI355X busy - its kernels are short latency chains - so a batched step costs about what a single stream's step costs
  * and the frame rate scales with the lane count until the chip fills. Every lane is a full context (own maps, servo, gyro-bias
  * state) sharing the batch's three streams; its records are bit-identical to those of a stand-alone context fed the same
- * frames. lanes in 1..8, keylines_max <= 32768, no lens model (the device front end is not part of the batched path).
+ * frames. lanes in 1..16, any keylines_max a context accepts; rebvio_hip_batch_create checks that the device can hold every
+ * lane's persistent tracking workgroups at once and refuses (-3, with the bound in the message) otherwise: 8 lanes at 16k
+ * keylines on an MI355X. A lens model (rebvio_hip_set_undistort on every lane's context, or on none) puts the batched front end
+ * (x3 + undistort, rebvio.cpp:43-47) ahead of the scans, each lane through its own model.
  * push: frames_dev[l] = this step's u8 frame of lane l in device memory (all lanes share ts_us); out[l] / keylines[l] receive
- * lane l's most recent COMPLETE pair like rebvio_hip_push_frame_u8_device (status -1 while the pipeline fills). */
+ * lane l's oldest COMPLETE pair not handed out yet, like rebvio_hip_push_frame_u8_device (status -1 while there is none);
+ * after rebvio_hip_batch_flush the remaining steps' records are fetched with rebvio_hip_batch_next_records (1 = filled, 0 = none).
+ * A push that fails after some lanes have been prepared leaves the batch out of lock-step: it is marked and every later call
+ * returns -11. */
 typedef struct rebvio_hip_batch rebvio_hip_batch;
 int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_batch** out);
 void rebvio_hip_batch_destroy(rebvio_hip_batch* b);
@@ -273,6 +292,7 @@ int rebvio_hip_batch_lanes(rebvio_hip_batch* b);
 rebvio_hip_ctx* rebvio_hip_batch_lane(rebvio_hip_batch* b, int lane);
 int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* frames_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
                                     int* keylines);
+int rebvio_hip_batch_next_records(rebvio_hip_batch* b, rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_batch_flush(rebvio_hip_batch* b);
 
 /* Per-kernel device timing of the last N launches of each kernel, measured with HIP events on the

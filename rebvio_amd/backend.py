@@ -100,12 +100,14 @@ SIGNATURES = {
     "rebvio_hip_track_pair_result": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "rebvio_hip_track_pair_hint_next": (C.c_int, [_vp, _vp]),
     "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
+    "rebvio_hip_next_record": (C.c_int, [_vp, C.POINTER(PairOut), _ip]),
     "rebvio_hip_flush": (C.c_int, [_vp]),
     "rebvio_hip_batch_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(_vp)]),
     "rebvio_hip_batch_destroy": (None, [_vp]),
     "rebvio_hip_batch_lanes": (C.c_int, [_vp]),
     "rebvio_hip_batch_lane": (_vp, [_vp, C.c_int]),
     "rebvio_hip_batch_push_u8_device": (C.c_int, [_vp, C.POINTER(_vp), C.c_uint64, C.POINTER(PairOut), _ip]),
+    "rebvio_hip_batch_next_records": (C.c_int, [_vp, C.POINTER(PairOut), _ip]),
     "rebvio_hip_batch_flush": (C.c_int, [_vp]),
     "rebvio_hip_profile_enable": (C.c_int, [_vp, C.c_int]),
     "rebvio_hip_profile_select": (C.c_int, [_vp, C.c_char_p]),
@@ -391,6 +393,18 @@ class Context:
     def reset_state(self):
         lib().rebvio_hip_reset_state(self.h)
 
+    def gyro_state(self):
+        """(Bg[3], W_Bg[3, 3]) of the pair glue's gyro-bias filter (types/imu.hpp:180-182)."""
+        bg = np.zeros(3, np.float32)
+        w = np.zeros(9, np.float32)
+        _chk(lib().rebvio_hip_get_gyro_state(self.h, bg.ctypes.data_as(_fp), w.ctypes.data_as(_fp)))
+        return bg, w.reshape(3, 3)
+
+    def set_gyro_state(self, bg, w_bg):
+        bg, pb = _f(np.asarray(bg).reshape(3))
+        w, pw = _f(np.asarray(w_bg).reshape(9))
+        _chk(lib().rebvio_hip_set_gyro_state(self.h, pb, pw))
+
     def track_pair(self, old: Map, new: Map, R_prior=None, frame_dt=0.05) -> PairOut:
         out = PairOut()
         pr = None
@@ -433,8 +447,24 @@ class Context:
         _chk(lib().rebvio_hip_push_frame_u8_device(self.h, _vp(dev_addr), ts_us, C.byref(out), C.byref(n)))
         return out, n.value
 
+    def next_record(self):
+        """The oldest complete pair record not handed out yet, or None."""
+        out = PairOut()
+        n = C.c_int()
+        k = lib().rebvio_hip_next_record(self.h, C.byref(out), C.byref(n))
+        if k < 0:
+            _chk(k)
+        return (out, n.value) if k == 1 else None
+
     def flush(self):
+        """Finishes every pair in flight; returns the records that were still waiting to be handed out, oldest first."""
         _chk(lib().rebvio_hip_flush(self.h))
+        rest = []
+        while True:
+            r = self.next_record()
+            if r is None:
+                return rest
+            rest.append(r)
 
     # profiling
     def profile(self, on: bool, only: str | None = None, stride: int = 1):
@@ -474,7 +504,19 @@ class Batch:
         return self._out, self._n
 
     def flush(self):
+        """Finishes every step in flight; returns the steps' records that were still waiting, oldest first, as
+        (list of PairOut per lane, list of keyline counts per lane)."""
         _chk(lib().rebvio_hip_batch_flush(self.h))
+        rest = []
+        while True:
+            out = (PairOut * self.B)()
+            n = (C.c_int * self.B)()
+            k = lib().rebvio_hip_batch_next_records(self.h, out, n)
+            if k < 0:
+                _chk(k)
+            if k != 1:
+                return rest
+            rest.append((list(out), list(n)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "glue.hpp"
 #include "hostmath.hpp"
 
 using namespace rh;
@@ -190,11 +191,10 @@ struct rebvio_hip_ctx {
   rebvio_hip_params P{};
   KParams K{};
   int device = 0;
-  hipStream_t s_det{}, s_key{}, s_df{}, s_trk{}, s_cpy{};
+  hipStream_t s_det{}, s_key{}, s_trk{};  // scans | keylines + distance field (+ the synchronous API's copies) | tracking
   double t_begin_enq = 0, t_begin_wait = 0;  // REBVIO_HIP_DEBUG: host time of track_pair_begin (enqueue / wait for the first half)
   uint64_t t_begin_n = 0;
   std::mutex dl_mu;             // aos_dev / scratch_i users (map_download, map_upload, render, field decode) and trk_touched
-  bool scan_split = true;       // last column pass + k_dog_mag on s_key (detect_launch)
   float* sa2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [frame parity][filter]: sb.a per parity ([0] aliases sb.a)
   // scale-space outputs (DoG, squared gradient, per-row counts) are double buffered: the scans of frame f+1 (s_det)
   // overlap the keyline extraction of frame f (s_key)
@@ -258,34 +258,32 @@ struct rebvio_hip_ctx {
   float Bg[3]{};
   hm::M3 W_Bg{}, RGBias{}, RGyro{};
   LmState* lm_zero = nullptr;  // constant start state of minimizeVel (Vg = 0, rebvio.cpp:167)
-  // streaming pipeline (rebvio_hip_push_frame_u8_device)
-  static constexpr int kSlots = 4;
-  PairSlot* slot[kSlots]{};    // pinned, written by the A-chain's last kernel
-  hipEvent_t slot_ev[kSlots]{};
-  // release of the second half (streaming driver): the B-chain is queued behind a hipStreamWaitValue32 on glue_flag[slot]
-  // BEFORE the host waits for the A-chain; the host glue writes glue_host[slot] and then the flag
-  GlueDev* glue_host[kSlots]{};   // pinned, or (glue_vram) host-visible device memory
-  unsigned* glue_flag = nullptr;  // [kSlots], same kind of memory
-  void* glue_vram = nullptr;      // one fine-grained device allocation holding both (REBVIO_HIP_GLUE=vram, large-BAR hosts)
-  GlueDev* glue_dev = nullptr;    // [kSlots], device copies made by the first kernel behind the wait
-  bool prelaunch_b = true;        // REBVIO_HIP_PRELAUNCH=0: enqueue the B-chain after the glue (kernel arguments)
-  bool slim_ops = true;           // REBVIO_HIP_SLIM_OPS=0: event waits / map release between B(k) and A(k+1), as enqueued
+  int lm_threads = 512;        // workgroup size of the persistent LM kernels (REBVIO_HIP_LM_THREADS: 256 | 512 | 1024)
+  int dm_head_form = 0;        // directedMatch head: 0 by map size, 1 thread per keyline, 2 eight lanes per keyline (REBVIO_HIP_DM_HEAD)
+  // Result slots. slot[0] also serves the per-pair API. The streaming driver (rebvio_hip_push_frame_u8_device) keeps the
+  // WHOLE pair step on the device - the glue between the halves runs in front of the directedMatch head (glue.hpp) - and the
+  // host reads a pair's records kSlots - 1 pairs late at most.
+  static constexpr int kSlots = kPairSlots;
+  PairSlot* slot[kSlots]{};    // pinned: LM state + map state records, written by the pair's first kernel
+  hipEvent_t slot_ev[kSlots]{};  // recorded behind the pair's last kernel
+  GlueRec* rec[kSlots]{};      // pinned: what the device glue of the pair reports
+  GlueDev* glue_dev = nullptr;    // [kSlots] second-half inputs left by the directedMatch head for the kernels behind it
+  GlueState* gstate = nullptr;    // [2] device: gyro-bias filter state + prior rotation, by pair parity
+  GlueState* h_gstate = nullptr;  // [2] pinned staging for the upload in front of a stream's first pair
+  hm::M3 gs_R{};                  // host mirror of the device state's prior rotation (with Bg / W_Bg above)
   int lead = 5;                   // detected frames queued when a pair is started (REBVIO_HIP_LEAD 3..12, see push_frame)
-  struct PendingPair {
-    rebvio_hip_map* om = nullptr;
+  struct InFlight {               // a pair whose kernels are queued and whose record has not been read yet
     rebvio_hip_map* nm = nullptr;
     int slot = -1;
-    bool a_enqueued = false;
-    hm::M3 R;          // prior rotation used for the first rotate
     float frame_dt = 0.f;
-    rebvio_hip_pair_out out{};
-    bool b_enqueued = false;
-    unsigned seq = 0;  // value that releases this pair's B-chain
+  };
+  struct Done {                   // a complete record waiting to be handed to the caller
+    rebvio_hip_pair_out out;
+    int keylines;
   };
   std::vector<rebvio_hip_map*> frames;  // detected maps not yet consumed as "old"
-  PendingPair cur{};                    // pair whose A-chain is in flight
-  PendingPair prev{};                   // pair whose B-chain is in flight (counters arrive with cur's slot)
-  bool has_cur = false, has_prev = false;
+  std::deque<InFlight> inflight;
+  std::deque<Done> done;
   uint64_t pair_seq = 0;
   // detect-enqueue worker (the reference's data-acquisition thread, rebvio.cpp:28): launches the detect kernels so
   // that the caller thread's launches (track chains) and the detect launches proceed in parallel on the host
@@ -307,17 +305,13 @@ struct rebvio_hip_ctx {
   bool det_stop = false;
   std::string det_error;
   // host-side phase timing of the streaming driver (printed by flush when REBVIO_HIP_DEBUG is set)
-  double t_detect_enq = 0, t_wait = 0, t_glue = 0, t_b_enq = 0, t_a_enq = 0, t_queued = 0;
+  double t_detect_enq = 0, t_wait = 0, t_enq = 0, t_queued = 0;
   bool dbg = false;
   uint64_t t_frames = 0;
   bool owns_streams = true;  // false for the lanes of a batch (rebvio_hip_batch_*)
-  // track_pair_begin / _finish with the second half parked behind a wait on glue_flag[kSlots - 1] (see track_pair_begin)
-  std::atomic<bool> bf_parked{false};
-  std::thread::id bf_park_thread;             // the thread whose _begin parked the second half (it must not wait for the track stream)
   rebvio_hip_map* bf_map[2] = {nullptr, nullptr};  // new map of the pair whose counters result slot r will report
   bool bf_have[2] = {false, false};           // h_bf[r] already holds them (taken from the next pair's slot, or copied)
   bool bf_copy_queued[2] = {false, false};    // a device-to-host copy + bf_done[r] are queued for them
-  unsigned bf_seq = 0, bf_counter = 0;
   // two result slots: the next pair's first half (and its parked second half) may be queued before the caller fetches the
   // previous pair's counters (rebvio_hip_track_pair_finish_async / _result)
   hipEvent_t bf_done[2]{};
@@ -347,33 +341,9 @@ inline void wait_enqueued(rebvio_hip_map* m) {
 
 size_t part_call_stride(const rebvio_hip_ctx* c) { return (size_t)c->maxblocks * kPartStride; }
 
-// Glue record, then the value a parked second half waits for. Word stores only: the destination may be write-combined device
-// memory behind the BAR (REBVIO_HIP_GLUE=vram), which must never be read and needs explicit fences to leave the CPU in order.
-void write_glue_and_flag(rebvio_hip_ctx* c, int slot, unsigned seq, const GlueDev& g) {
-  volatile unsigned* dst = reinterpret_cast<volatile unsigned*>(c->glue_host[slot]);
-  unsigned words[sizeof(GlueDev) / sizeof(unsigned)];
-  std::memcpy(words, &g, sizeof(g));
-  for (size_t i = 0; i < sizeof(GlueDev) / sizeof(unsigned); ++i) dst[i] = words[i];
-  if (c->glue_vram) __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  __atomic_store_n(c->glue_flag + slot, seq, __ATOMIC_RELEASE);
-  if (c->glue_vram) __atomic_thread_fence(__ATOMIC_SEQ_CST);
-}
-// a begin without its finish (caller error, or a context torn down mid-pair): let the parked kernels fall through
-void release_parked_pair(rebvio_hip_ctx* c) {
-  if (!c->bf_parked) return;
-  GlueDev gl{};
-  gl.nan_v = 1;
-  write_glue_and_flag(c, rebvio_hip_ctx::kSlots - 1, c->bf_seq, gl);
-  c->bf_parked = false;
-}
-
-// Wait for the track stream by polling. A thread sitting inside hipStreamSynchronize on a stream that holds a parked second
-// half (track_pair_begin) blocked the fusion thread's next runtime call and with it the release of that second half
-// (observed with rebvio::Rebvio's two workers); hipStreamQuery holds nothing while it waits. The thread that parked the
-// pair must finish it first: waiting here would be waiting for itself.
+// Wait for the track stream by polling: hipStreamQuery holds no runtime lock while it waits, so launches of other threads
+// of the process (rebvio::Rebvio's acquisition thread) are not held up behind a blocked hipStreamSynchronize.
 int trk_sync(rebvio_hip_ctx* c) {
-  if (c->bf_parked.load(std::memory_order_acquire) && c->bf_park_thread == std::this_thread::get_id())
-    return fail_msg("a pair is in flight on this thread (track_pair_begin): call track_pair_finish before anything that waits for the track stream", -7);
   for (;;) {
     const hipError_t e = hipStreamQuery(c->s_trk);
     if (e == hipSuccess) return 0;
@@ -481,16 +451,16 @@ int fetch_map_state(rebvio_hip_map* m, MapState* out, hipStream_t after) {
   // copy stream: wait for the producer, copy, block the host only on this small transfer
   rebvio_hip_ctx* c = m->ctx;
   wait_enqueued(m);
-  HIPCHK(hipStreamWaitEvent(c->s_cpy, m->ready, 0));
+  HIPCHK(hipStreamWaitEvent(c->s_key, m->ready, 0));
   if (after) {
     hipEvent_t e;
     HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventRecord(e, after));
-    HIPCHK(hipStreamWaitEvent(c->s_cpy, e, 0));
+    HIPCHK(hipStreamWaitEvent(c->s_key, e, 0));
     (void)hipEventDestroy(e);
   }
-  HIPCHK(hipMemcpyAsync(c->h_st, m->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_cpy));
-  HIPCHK(hipStreamSynchronize(c->s_cpy));
+  HIPCHK(hipMemcpyAsync(c->h_st, m->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_key));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   *out = *c->h_st;
   m->n_host = out->n;
   m->thr_host = out->threshold;
@@ -529,10 +499,8 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   sb.scale0 = sb.scale1 = nullptr;
   sb.dog = c->dog2[b];
   sb.mag = c->mag2[b];
-  if (c->scan_split) {  // the third filter's integral images change streams: one pair per frame parity
-    sb.a[0] = c->sa2[b][0];
-    sb.a[1] = c->sa2[b][1];
-  }
+  sb.a[0] = c->sa2[b][0];  // the third filter's integral images change streams (below): one pair per frame parity
+  sb.a[1] = c->sa2[b][1];
   DetectBufs db = c->db;
   db.rowcount = c->rowcount2[b];
   if (j.pin_slot >= 0) {  // host frame: pinned slot -> device staging frame, read by this stream's own kernels only
@@ -550,27 +518,23 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
     is_u8 = 0;
   }
   // The scan stream is the busiest of the three: it hands the frame over after the last ROW pass, the last column pass and
-  // the DoG / gradient kernel run at the head of the keyline stream (REBVIO_HIP_SCAN_SPLIT=0: all seven on the scan stream).
+  // the DoG / gradient kernel run at the head of the keyline stream.
   // Their inputs sb.a[] are then read while the scan stream already works on the next frame, hence the pair per parity;
   // the frame after next waits for ev_flag[b] (recorded behind them) above.
-  launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount, c->scan_split ? 1 : 3);
+  launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount, 1);
   HIPCHK(hipEventRecord(c->ev_scan[b], c->s_det));
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
   HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
-  if (c->scan_split) launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2);
+  launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2);
   if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done, 0));
   launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev_flag[b], c->s_key));  // (after join: coarser than needed, same stream order)
   c->ev_flag_used[b] = true;
-  // distance field of this map on its own stream
-  if (c->s_df != c->s_key) {  // (the default shares the stream: stream order is the dependency, two runtime calls less per frame)
-    HIPCHK(hipEventRecord(m->detected, c->s_key));
-    HIPCHK(hipStreamWaitEvent(c->s_df, m->detected, 0));
-  }
-  launch_df_build(c->s_df, c->K, m->d, j.det_out, true);
+  // distance field of this map, behind its keylines on the same stream (stream order is the dependency)
+  launch_df_build(c->s_key, c->K, m->d, j.det_out, true);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(m->ready, c->s_df));
+  HIPCHK(hipEventRecord(m->ready, c->s_key));
   m->enqueued.store(1, std::memory_order_release);
   return 0;
 }
@@ -712,12 +676,14 @@ void enqueue_lm_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm,
 // minimizeVel + forwardMatch + extRotVel of one pair on the track stream (rebvio.cpp:167-177); results land in `slot`.
 // Default: the persistent kernel (one launch); REBVIO_HIP_LM=percall selects the per-evaluation kernels, which compute
 // identical bits (same per-keyline code, same record order).
-int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3], PairSlot* slot) {
+// xrv_dst: where the extRotVel block records go - the pinned slot's tail (per-pair API: the host sums them) or device
+// memory (streaming driver: the device glue sums them).
+int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3], PairSlot* slot, float* xrv_dst) {
   const int calls = (int)c->P.iterations + 1;
   if (!c->lm_persistent) {
     enqueue_lm_chain(c, om, nm, vel0);
     launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
-                       c->part + (size_t)(calls - 1) * part_call_stride(c), slot->xrv, vel0, slot, c->hist);
+                       c->part + (size_t)(calls - 1) * part_call_stride(c), xrv_dst, vel0, slot, c->hist);
     return 0;
   }
   if (*c->lm_bar_err) {
@@ -756,7 +722,7 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
   }
   const bool spec_now = c->lm_spec && (c->lm_spec_forced || c->lm_miss_ema < 0.17f);
   launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, spec_now ? 2 : 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
-                  slot->xrv, slot, c->hist, c->lm_stamps);
+                  xrv_dst, slot, c->hist, c->lm_stamps, c->lm_threads);
   c->lm_tag_base += 2u * ((unsigned)calls + 1u);  // (the speculative kernel numbers repeated evaluations in a second range)
   if (c->lm_tag_base > 0xFFFFFF00u) {  // tags must stay unique and non-zero: restart the sequence on clean exchange words
     (void)hipMemsetAsync(c->lm_xch, 0, lm_xch_words(c->maxblocks) * sizeof(unsigned long long), c->s_trk);
@@ -794,15 +760,11 @@ int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, siz
   return 0;
 }
 
-// Detection of a host frame: staged here and launched by the caller, or (REBVIO_HIP_DETECT_ASYNC=1) by the context's detect
-// worker, so that the ~20 runtime calls of a frame's detection do not sit on the thread that stages the frames. Measured
-// with rebvio::Rebvio (tools/host_class_probe.py): the acquisition thread drops from 58-107 to 23-30 us per frame, but the
-// fusion thread's own launches slow down by as much (runtime calls of different threads largely serialise: its second half
-// 12 -> 26 us) and the class's rate stays where it was (7.7-8.4k frames/s either way) - hence opt-in. Everything that reads
-// the map waits for the launch (wait_enqueued); a worker-side error surfaces at the next detect call.
+// Detection of a host frame: staged through the pinned ring and launched by the caller. (Handing the launch to the context's
+// detect worker was measured with rebvio::Rebvio in round 2: the acquisition thread's time per frame dropped, the fusion
+// thread's own launches slowed down by as much - runtime calls of different threads largely serialise - no gain, removed.)
 int detect_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, size_t row_bytes, void* dst_dev, int is_u8, uint64_t ts,
                       rebvio_hip_map** out) {
-  static const bool sync_mode = !(std::getenv("REBVIO_HIP_DETECT_ASYNC") && std::atoi(std::getenv("REBVIO_HIP_DETECT_ASYNC")) != 0);
   {
     std::lock_guard<std::mutex> lk(c->det_mu);
     if (!c->det_error.empty()) return fail_msg(c->det_error.c_str(), -8);
@@ -815,20 +777,9 @@ int detect_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, si
     c->pin_staged[job.pin_slot].store(0, std::memory_order_release);
     return rc;
   }
-  if (sync_mode) {
-    while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
-    rc = detect_launch(c, job);
-    if (rc) return rc;
-  } else {
-    if (!c->det_thread.joinable()) c->det_thread = std::thread(det_worker_main, c);
-    job.m->enqueued.store(0, std::memory_order_relaxed);
-    c->det_pending.fetch_add(1, std::memory_order_release);
-    {
-      std::lock_guard<std::mutex> lk(c->det_mu);
-      c->det_jobs.push_back(job);
-    }
-    c->det_cv.notify_one();
-  }
+  while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();  // (a streaming push's detection goes first)
+  rc = detect_launch(c, job);
+  if (rc) return rc;
   *out = job.m;
   return 0;
 }
@@ -872,6 +823,10 @@ int rebvio_hip_get_gyro_state(rebvio_hip_ctx* c, float Bg[3], float W_Bg[9]) {
 }
 
 int rebvio_hip_set_gyro_state(rebvio_hip_ctx* c, const float Bg[3], const float W_Bg[9]) {
+  // While the streaming driver has pairs or frames in flight the filter state lives on the device (and the next pair's first
+  // rotation has already been applied with it): it can only be replaced between streams.
+  if (!c->inflight.empty() || !c->frames.empty())
+    return fail_msg("set_gyro_state: the streaming driver has frames in flight (rebvio_hip_flush first)", -7);
   for (int i = 0; i < 3; ++i) c->Bg[i] = Bg[i];
   c->W_Bg = hm::load3(W_Bg);
   return 0;
@@ -946,7 +901,6 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     c->s_det = t_adopt_streams->s_det;
     c->s_key = t_adopt_streams->s_key;
     c->s_trk = t_adopt_streams->s_trk;
-    c->s_df = c->s_key;
     c->owns_streams = false;
   } else {
     HIPCHK(hipStreamCreateWithPriority(&c->s_det, hipStreamNonBlocking, prio_mid));
@@ -957,14 +911,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     HIPCHK(hipStreamCreateWithPriority(&c->s_trk, hipStreamNonBlocking, prio_greatest));
     // Three streams per context (scans | keylines + distance field | tracking), deliberately not more: on this runtime every
     // additional stream of the process slowed the whole pipeline (measured, same code: 3 streams 9.3k frames/s, 4 streams
-    // 9.2k, 5 streams 9.1k; creating a sixth, even unused, 2.6k). REBVIO_HIP_DF_STREAM=own restores a separate
-    // low-priority distance-field stream; the copy stream of the synchronous API is the distance-field stream.
-    if (std::getenv("REBVIO_HIP_DF_STREAM") && std::strcmp(std::getenv("REBVIO_HIP_DF_STREAM"), "own") == 0)
-      HIPCHK(hipStreamCreateWithPriority(&c->s_df, hipStreamNonBlocking, prio_least));
-    else
-      c->s_df = c->s_key;
+    // 9.2k, 5 streams 9.1k; creating a sixth, even unused, 2.6k). The rare copies of the synchronous API ride on the keyline stream.
   }
-  c->s_cpy = c->s_df;
   const size_t Pn = (size_t)p->rows * p->cols;
   // the integral-image buffers have a row pitch of cols rounded up to 4 floats (the scans move 16-byte vectors); every
   // other per-pixel array is dense
@@ -986,7 +934,6 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_flag[i], hipEventDisableTiming));
   }
-  c->scan_split = !(std::getenv("REBVIO_HIP_SCAN_SPLIT") && std::atoi(std::getenv("REBVIO_HIP_SCAN_SPLIT")) == 0);
   for (int f = 0; f < 2; ++f) {
     c->sa2[0][f] = c->sb.a[f];
     HIPCHK(hipMalloc(&c->sa2[1][f], Pp * sizeof(float)));
@@ -1043,62 +990,23 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     const size_t sz = sizeof(PairSlot) + (size_t)c->maxblocks * kXrvStride * sizeof(float);
     HIPCHK(hipHostMalloc(&c->slot[i], sz, hipHostMallocDefault));
     std::memset(c->slot[i], 0, sz);
+    HIPCHK(hipHostMalloc(&c->rec[i], sizeof(GlueRec), hipHostMallocDefault));
+    std::memset(c->rec[i], 0, sizeof(GlueRec));
     HIPCHK(hipEventCreateWithFlags(&c->slot_ev[i], hipEventDisableTiming));
   }
   HIPCHK(hipMalloc(&c->fscratch, 64 * sizeof(float)));
-  {
-    // Where the host leaves a pair's glue for the pre-enqueued B-chain. Default: pinned host memory (the first kernel's
-    // read is a PCIe round trip, ~1.7 us). REBVIO_HIP_GLUE=vram (explicit opt-in, large-BAR hosts only): fine-grained
-    // DEVICE memory that the host stores into through the BAR (posted writes) and the GPU reads locally
-    // (tools/hostvram_probe.hip; measured +1.5 % frames/s). The placement is decided from the device attribute alone:
-    // the library installs no signal handlers and never probes a mapping with a faulting store.
-    const char* e = std::getenv("REBVIO_HIP_GLUE");
-    hipDeviceProp_t prop{};
-    const bool want_vram = e && std::strcmp(e, "vram") == 0 && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.isLargeBar;
-    if (e && std::strcmp(e, "vram") == 0 && !want_vram)
-      std::fprintf(stderr, "[rebvio_hip] REBVIO_HIP_GLUE=vram ignored: device %d does not report a large BAR\n", c->device);
-    constexpr size_t kStride = 256;  // one slot per 256 bytes, flags in their own 256 bytes
-    static_assert(sizeof(GlueDev) <= kStride, "slot stride");
-    const size_t vram_bytes = (rebvio_hip_ctx::kSlots + 1) * kStride;
-    bool vram_ok = false;
-    if (want_vram && hipExtMallocWithFlags(&c->glue_vram, vram_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
-      vram_ok = hipMemset(c->glue_vram, 0, vram_bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-      if (vram_ok) {  // a large-BAR device maps its allocations into the host address space: store, copy back, compare
-        unsigned back = 0;
-        volatile unsigned* probe = reinterpret_cast<volatile unsigned*>((char*)c->glue_vram + vram_bytes - sizeof(unsigned));
-        *probe = 0xA5C3F00Du;
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);
-        vram_ok = hipMemcpy(&back, (const void*)probe, sizeof(back), hipMemcpyDeviceToHost) == hipSuccess && back == 0xA5C3F00Du;
-      }
-      if (!vram_ok) {
-        (void)hipFree(c->glue_vram);
-        c->glue_vram = nullptr;
-      }
-    }
-    if (vram_ok) {
-      HIPCHK(hipMemset(c->glue_vram, 0, vram_bytes));
-      for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) c->glue_host[i] = reinterpret_cast<GlueDev*>((char*)c->glue_vram + i * kStride);
-      c->glue_flag = reinterpret_cast<unsigned*>((char*)c->glue_vram + rebvio_hip_ctx::kSlots * kStride);
-    } else {
-      c->glue_vram = nullptr;
-      for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
-        HIPCHK(hipHostMalloc(&c->glue_host[i], sizeof(GlueDev), hipHostMallocDefault));
-        std::memset(c->glue_host[i], 0, sizeof(GlueDev));
-      }
-      HIPCHK(hipHostMalloc(&c->glue_flag, rebvio_hip_ctx::kSlots * sizeof(unsigned), hipHostMallocDefault));
-      std::memset(c->glue_flag, 0, rebvio_hip_ctx::kSlots * sizeof(unsigned));
-    }
-  }
   HIPCHK(hipMalloc(&c->glue_dev, rebvio_hip_ctx::kSlots * sizeof(GlueDev)));
   HIPCHK(hipMemset(c->glue_dev, 0, rebvio_hip_ctx::kSlots * sizeof(GlueDev)));
-  {
-    int can = 0;
-    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
-    const char* e = std::getenv("REBVIO_HIP_PRELAUNCH");
-    c->prelaunch_b = can != 0 && !(e && std::atoi(e) == 0);
-    if (const char* so = std::getenv("REBVIO_HIP_SLIM_OPS")) c->slim_ops = std::atoi(so) != 0;
-    if (const char* l = std::getenv("REBVIO_HIP_LEAD")) c->lead = std::min(12, std::max(3, std::atoi(l)));
+  HIPCHK(hipMalloc(&c->gstate, 2 * sizeof(GlueState)));
+  HIPCHK(hipMemset(c->gstate, 0, 2 * sizeof(GlueState)));
+  HIPCHK(hipHostMalloc(&c->h_gstate, 2 * sizeof(GlueState), hipHostMallocDefault));
+  if (const char* l = std::getenv("REBVIO_HIP_LEAD")) c->lead = std::min(12, std::max(3, std::atoi(l)));
+  if (const char* e = std::getenv("REBVIO_HIP_LM_THREADS")) {
+    const int v = std::atoi(e);
+    if (v == 256 || v == 512 || v == 1024) c->lm_threads = v;
   }
+  if (const char* e = std::getenv("REBVIO_HIP_DM_HEAD"))  // directedMatch head form (track.hip, dm_head_wide): thread | wide; default by map size
+    c->dm_head_form = std::strcmp(e, "thread") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
   HIPCHK(hipHostMalloc(&c->h_lm, 2 * sizeof(LmState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_part, part_call_stride(c) * sizeof(float), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_xrv, (size_t)c->maxblocks * kXrvStride * sizeof(float), hipHostMallocDefault));
@@ -1117,7 +1025,6 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   }
   rebvio_hip_reset_state(c);
   c->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
-  if (c->dbg) std::fprintf(stderr, "[rebvio_hip] glue slots in %s\n", c->glue_vram ? "host-visible device memory" : "pinned host memory");
   HIPCHK(hipDeviceSynchronize());
   guard.c = nullptr;
   *out = c;
@@ -1131,7 +1038,6 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   const std::shared_ptr<LifeBlock> life = c->life;
   std::lock_guard<std::mutex> life_lk(life->mu);
   (void)hipSetDevice(c->device);
-  release_parked_pair(c);
   if (std::getenv("REBVIO_HIP_DEBUG") && c->t_begin_n)
     std::fprintf(stderr, "[rebvio_hip] track_pair_begin over %llu pairs (us): enqueue %.1f  wait for the first half %.1f\n",
                  (unsigned long long)c->t_begin_n, c->t_begin_enq / c->t_begin_n, c->t_begin_wait / c->t_begin_n);
@@ -1150,8 +1056,6 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   }
   // maps the streaming driver still holds are the library's own, not the caller's
   for (auto* m : c->frames) m->in_use = false;
-  if (c->has_cur) c->cur.om->in_use = c->cur.nm->in_use = false;
-  if (c->has_prev) c->prev.nm->in_use = false;
   life->dead.store(true, std::memory_order_release);
   for (auto* m : c->pool) {
     free_map_device(m);
@@ -1171,7 +1075,6 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->owns_streams) {
     if (c->s_det) (void)hipStreamDestroy(c->s_det);
     if (c->s_trk) (void)hipStreamDestroy(c->s_trk);
-    if (c->s_df && c->s_df != c->s_key) (void)hipStreamDestroy(c->s_df);
     if (c->s_key) (void)hipStreamDestroy(c->s_key);
   }
   for (int i = 0; i < 2; ++i) {
@@ -1183,8 +1086,11 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->rowcount2[1]) (void)hipFree(c->rowcount2[1]);
   for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
     if (c->slot[i]) (void)hipHostFree(c->slot[i]);
+    if (c->rec[i]) (void)hipHostFree(c->rec[i]);
     if (c->slot_ev[i]) (void)hipEventDestroy(c->slot_ev[i]);
   }
+  if (c->gstate) (void)hipFree(c->gstate);
+  if (c->h_gstate) (void)hipHostFree(c->h_gstate);
   if (c->undist_map) (void)hipFree(c->undist_map);
   for (int i = 0; i < 2; ++i)
     if (c->undist_img[i]) (void)hipFree(c->undist_img[i]);
@@ -1192,13 +1098,6 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   for (int i = 0; i < rebvio_hip_ctx::kPin; ++i) {
     if (c->pin[i]) (void)hipHostFree(c->pin[i]);
     if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
-  }
-  if (c->glue_vram) {
-    (void)hipFree(c->glue_vram);
-  } else {
-    for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i)
-      if (c->glue_host[i]) (void)hipHostFree(c->glue_host[i]);
-    if (c->glue_flag) (void)hipHostFree(c->glue_flag);
   }
   if (c->glue_dev) (void)hipFree(c->glue_dev);
   if (c->lm_bar_err) (void)hipHostFree(c->lm_bar_err);
@@ -1209,7 +1108,6 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->lm_zero) (void)hipFree(c->lm_zero);
   if (c->dm_work) (void)hipFree(c->dm_work);
   if (c->dm_work_n) (void)hipFree(c->dm_work_n);
-  // (s_cpy aliases s_df)
   delete c;
 }
 
@@ -1338,19 +1236,19 @@ int rebvio_hip_map_download(rebvio_hip_map* m, rebvio_hip_keyline* keylines, int
   if (m->trk_touched.load(std::memory_order_acquire) || !c->owns_streams) {
     HIPCHK(hipStreamSynchronize(c->s_det));
     HIPCHK(hipStreamSynchronize(c->s_key));
-    HIPCHK(hipStreamSynchronize(c->s_df));
+    HIPCHK(hipStreamSynchronize(c->s_key));
     { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   } else {
     wait_enqueued(m);
     HIPCHK(hipEventSynchronize(m->ready));
   }
   if (keylines && m->n_host > 0) {
-    launch_map_pack(c->s_cpy, c->K, m->d, c->aos_dev);
-    HIPCHK(hipMemcpyAsync(keylines, c->aos_dev, (size_t)m->n_host * sizeof(rebvio_hip_keyline), hipMemcpyDeviceToHost, c->s_cpy));
+    launch_map_pack(c->s_key, c->K, m->d, c->aos_dev);
+    HIPCHK(hipMemcpyAsync(keylines, c->aos_dev, (size_t)m->n_host * sizeof(rebvio_hip_keyline), hipMemcpyDeviceToHost, c->s_key));
   }
   if (mask)
-    HIPCHK(hipMemcpyAsync(mask, m->d.mask, (size_t)c->P.rows * c->P.cols * sizeof(int), hipMemcpyDeviceToHost, c->s_cpy));
-  HIPCHK(hipStreamSynchronize(c->s_cpy));
+    HIPCHK(hipMemcpyAsync(mask, m->d.mask, (size_t)c->P.rows * c->P.cols * sizeof(int), hipMemcpyDeviceToHost, c->s_key));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   return 0;
 }
 
@@ -1361,15 +1259,15 @@ int rebvio_hip_render_edge_image(rebvio_hip_map* m, const uint8_t* gray, uint8_t
   std::lock_guard<std::mutex> dl(c->dl_mu);
   HIPCHK(hipStreamSynchronize(c->s_det));  // the staging frame and the scratch are shared with the detect path
   HIPCHK(hipStreamSynchronize(c->s_key));
-  HIPCHK(hipStreamSynchronize(c->s_df));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   const size_t Pn = (size_t)c->P.rows * c->P.cols;
   uint8_t* rgb = reinterpret_cast<uint8_t*>(c->scratch_i);  // 8 bytes/pixel available, 3 used
-  if (gray) HIPCHK(hipMemcpyAsync(c->img8_dev, gray, Pn, hipMemcpyHostToDevice, c->s_cpy));
-  launch_render_edge_image(c->s_cpy, c->K, m->d, gray ? c->img8_dev : nullptr, rgb);
+  if (gray) HIPCHK(hipMemcpyAsync(c->img8_dev, gray, Pn, hipMemcpyHostToDevice, c->s_key));
+  launch_render_edge_image(c->s_key, c->K, m->d, gray ? c->img8_dev : nullptr, rgb);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(rgb_out, rgb, 3 * Pn, hipMemcpyDeviceToHost, c->s_cpy));
-  HIPCHK(hipStreamSynchronize(c->s_cpy));
+  HIPCHK(hipMemcpyAsync(rgb_out, rgb, 3 * Pn, hipMemcpyDeviceToHost, c->s_key));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   return 0;
 }
 
@@ -1381,15 +1279,15 @@ int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines,
   if (rc) return rc;
   if (n != m->n_host) return fail_msg("map_upload: count differs from map size", -6);
   std::lock_guard<std::mutex> dl(c->dl_mu);
-  HIPCHK(hipStreamSynchronize(c->s_df));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   HIPCHK(hipStreamSynchronize(c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_key));
   { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(c->aos_dev, keylines, (size_t)n * sizeof(rebvio_hip_keyline), hipMemcpyHostToDevice, c->s_cpy));
-    launch_map_unpack(c->s_cpy, c->K, m->d, c->aos_dev, n);
+    HIPCHK(hipMemcpyAsync(c->aos_dev, keylines, (size_t)n * sizeof(rebvio_hip_keyline), hipMemcpyHostToDevice, c->s_key));
+    launch_map_unpack(c->s_key, c->K, m->d, c->aos_dev, n);
   }
-  HIPCHK(hipStreamSynchronize(c->s_cpy));
+  HIPCHK(hipStreamSynchronize(c->s_key));
   m->df_built = false;
   m->raster_order = false;  // arbitrary keylines: the rebuild goes through the scatter kernel
   return 0;
@@ -1438,8 +1336,7 @@ int rebvio_hip_build_distance_field(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipSetDevice(c->device));
   wait_enqueued(m);
   HIPCHK(trk_wait_ready_once(c, m));
-  static const bool force = std::getenv("REBVIO_HIP_DF_FORCE") != nullptr;  // diagnostic: rebuild on every call (tools/df_probe.py)
-  if (!m->df_built || force) {
+  if (!m->df_built) {
     if (!m->raster_order) HIPCHK(hipMemsetAsync(m->d.df, 0xFF, (size_t)c->P.rows * c->P.cols * sizeof(unsigned), c->s_trk));
     launch_df_build(c->s_trk, c->K, m->d, c->det + (c->frame_index % kDetRing), m->raster_order);  // keylines may have been uploaded
     HIPCHK(hipGetLastError());
@@ -1639,7 +1536,7 @@ int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, vel, Rvel, Rback, vel_r, Rvel_r);
   HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 3 * sizeof(int), c->s_trk));
-  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, c->dm_work, c->dm_work_n, nullptr);
+  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, c->dm_work, c->dm_work_n, nullptr, c->dm_head_form);
   HIPCHK(hipMemsetAsync(c->dm_work_n, 0, sizeof(int), c->s_trk));
   HIPCHK(hipGetLastError());
   MapState st;
@@ -1673,56 +1570,38 @@ int rebvio_hip_update_inverse_depth(rebvio_hip_ctx* c, const float vel[3]) {
 }
 
 namespace {
-// Host glue between extRotVel and directedMatch (rebvio.cpp:177-233, accelerometer/SAB branch excluded): 6x6 solve,
-// gyroBiasCorrection, SO3 correction, covariance. R is the prior rotation used for the first rotateKeylines.
+// Host glue between extRotVel and directedMatch (rebvio.cpp:177-233, accelerometer/SAB branch excluded) for the per-pair
+// API: the shared core of glue.hpp (the streaming and batch drivers run the same statements on the device). R is the prior
+// rotation used for the first rotateKeylines.
 struct GlueOut {
   float R0a[9], Rgva[9], V[3], P_V[9];
   bool nan_v;
 };
+GlueParams glue_params(const rebvio_hip_ctx* c, float frame_dt) {
+  GlueParams gp;
+  gp.frame_dt = frame_dt;
+  gp.gyro_std_dev = c->P.gyro_std_dev;
+  gp.gyro_bias_std_dev = c->P.gyro_bias_std_dev;
+  return gp;
+}
 GlueOut pair_glue(rebvio_hip_ctx* c, const LmState& lm, const float* xrv, int n_new, float frame_dt, hm::M3 R,
                   rebvio_hip_pair_out* out) {
-  GlueOut g;
-  float Vg[3], P_Vg[9];
-  lm_to_out(lm, Vg, P_Vg, &out->F, &out->lm_accept_mask, &out->sigma_rho_min);
+  GlueState st;
+  for (int i = 0; i < 3; ++i) st.Bg[i] = c->Bg[i];
+  hm::store3(c->W_Bg, st.W_Bg);
+  hm::store3(R, st.R);
+  st.pad = 0.f;
+  GlueDev gl;
+  hm::pair_glue_core(lm, xrv, n_new, glue_params(c, frame_dt), st, gl, *out);
+  for (int i = 0; i < 3; ++i) c->Bg[i] = st.Bg[i];
+  c->W_Bg = hm::load3(st.W_Bg);
   note_accept_mask(c, out->lm_accept_mask);
-  float Xv[6], W_Xv[36], JtF6[6];
-  sum_xrv(xrv, div_up(n_new, 256), W_Xv, JtF6, nullptr);
-  hm::sym6_solve(W_Xv, JtF6, Xv);
-  out->ext_ok = 1;
-  for (int i = 0; i < 6; ++i)
-    if (std::isnan(Xv[i])) out->ext_ok = 0;
-  float Xgv[6], W_Xgv[36];
-  std::memcpy(Xgv, Xv, sizeof(Xv));
-  std::memcpy(W_Xgv, W_Xv, sizeof(W_Xv));
-  // rebvio.cpp:186-191
-  const float s_b = c->P.gyro_bias_std_dev * c->P.gyro_bias_std_dev * frame_dt * frame_dt;
-  const float s_g = c->P.gyro_std_dev * c->P.gyro_std_dev * frame_dt * frame_dt;
-  c->RGBias = hm::diag3(s_b);
-  c->RGyro = hm::diag3(s_g);
-  float dg[3];
-  hm::gyro_bias_correction(Xgv, W_Xgv, c->W_Bg, c->RGyro, c->RGBias, dg);
-  for (int i = 0; i < 3; ++i) c->Bg[i] += dg[i];
-  const float dVgv[3] = {Xgv[0], Xgv[1], Xgv[2]};
-  const float dWgv[3] = {Xgv[3], Xgv[4], Xgv[5]};
-  // rebvio.cpp:195-203
-  const hm::M3 R0 = hm::so3_exp(dWgv);
-  R = hm::transpose(hm::mul(R0, hm::transpose(R)));
-  hm::mulv(R0, Vg, g.V);
-  for (int i = 0; i < 3; ++i) g.V[i] += dVgv[i];
-  float R_Xgv[36];
-  hm::cholesky6_inverse(W_Xgv, R_Xgv);
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) g.P_V[i * 3 + j] = R_Xgv[i * 6 + j];
-  hm::store3(R, g.Rgva);  // rebvio.cpp:228
-  hm::store3(R0, g.R0a);
-  for (int i = 0; i < 3; ++i) { out->Vg[i] = Vg[i]; out->V[i] = g.V[i]; }
-  std::memcpy(out->P_Vg, P_Vg, sizeof(P_Vg));
-  std::memcpy(out->Xv, Xv, sizeof(Xv));
-  std::memcpy(out->W_Xv, W_Xv, sizeof(W_Xv));
-  std::memcpy(out->Xgv, Xgv, sizeof(Xgv));
-  std::memcpy(out->R, g.Rgva, sizeof(g.Rgva));
-  std::memcpy(out->P_V, g.P_V, sizeof(g.P_V));
-  g.nan_v = std::isnan(g.V[0]) || std::isnan(g.V[1]) || std::isnan(g.V[2]);
+  GlueOut g;
+  std::memcpy(g.R0a, gl.R0a, sizeof(g.R0a));
+  std::memcpy(g.Rgva, gl.Rgva, sizeof(g.Rgva));
+  std::memcpy(g.V, gl.V, sizeof(g.V));
+  std::memcpy(g.P_V, out->P_V, sizeof(g.P_V));
+  g.nan_v = gl.nan_v != 0;
   return g;
 }
 
@@ -1741,7 +1620,7 @@ void enqueue_b_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, 
   }
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, g.V, g.P_V, g.Rgva, vel_r, Rvel_r);
-  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, g.Rgva, c->P.search_range, c->dm_work, c->dm_work_n, g.R0a);
+  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, g.Rgva, c->P.search_range, c->dm_work, c->dm_work_n, g.R0a, c->dm_head_form);
   const int gate = (int)c->P.global_min_matches_threshold;
   launch_regularize_ekf(s, c->K, nm->d, g.V, gate > 0 ? gate : 0, c->dm_work_n, RT_next, c->hist);  // rebvio.cpp:256-259
   std::swap(nm->d.rs, nm->d.rs_tmp);
@@ -1753,8 +1632,7 @@ void enqueue_b_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, 
 
 hm::M3 prior_rotation(rebvio_hip_ctx* c, const float* R_prior) {
   // R = imu.R(); R.T() = SO3(Bg) * R.T()  (rebvio.cpp:163-164)
-  hm::M3 R = R_prior ? hm::load3(R_prior) : hm::identity3();
-  return hm::transpose(hm::mul(hm::so3_exp(c->Bg), hm::transpose(R)));
+  return hm::prior_rotation(c->Bg, R_prior ? hm::load3(R_prior) : hm::identity3());
 }
 }  // namespace
 
@@ -1774,7 +1652,7 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   const float v0[3] = {0, 0, 0};                  // imu_state_.Vg = Zeros (rebvio.cpp:167)
   // minimizeVel, forwardMatch + extRotVel (rebvio.cpp:169-177); results land in slot 0
   PairSlot* slot = c->slot[0];
-  rc = enqueue_pair_lm(c, om, nm, v0, slot);
+  rc = enqueue_pair_lm(c, om, nm, v0, slot, slot->xrv);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
@@ -1802,7 +1680,6 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   const auto tb0 = std::chrono::steady_clock::now();
   std::memset(mid, 0, sizeof(*mid));
   hipStream_t s = c->s_trk;
-  release_parked_pair(c);  // (a previous begin that never saw its finish)
   if (!c->h_bf) {
     HIPCHK(hipHostMalloc(&c->h_bf, 2 * sizeof(MapState), hipHostMallocDefault));
     for (auto& e : c->bf_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1837,31 +1714,10 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   }
   const float v0[3] = {0, 0, 0};
   PairSlot* slot = c->slot[0];
-  rc = enqueue_pair_lm(c, om, nm, v0, slot);
+  rc = enqueue_pair_lm(c, om, nm, v0, slot, slot->xrv);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->slot_ev[0], s));
-  static const bool park_pairs = std::getenv("REBVIO_HIP_PAIR_PRELAUNCH") && std::atoi(std::getenv("REBVIO_HIP_PAIR_PRELAUNCH")) != 0;
-  if (c->prelaunch_b && park_pairs) {
-    // OPT-IN (REBVIO_HIP_PAIR_PRELAUNCH=1): the second half is queued NOW, parked behind a wait on a pinned flag, and reads what
-    // the caller passes to _finish from memory at run time: no kernel launch sits between the caller's inertial fusion and the
-    // matching kernels (the streaming driver's scheme, see enqueue_a_chain). Measured with rebvio::Rebvio (tools/
-    // host_class_probe.py, 4000 frames, two runs each): 7.97k / 8.36k frames/s parked, 8.40k / 9.16k with _finish_async
-    // launching the second half itself - the command processor takes as long to notice the flag as a launch takes to reach
-    // the GPU, and the parked kernels' launches only move into _begin. So the default stays off. While a pair is parked nobody
-    // may sit inside hipStreamSynchronize on the track stream: the library's own waits poll (trk_sync), and a download of a
-    // map the tracker has not touched yet does not look at the track stream at all.
-    constexpr int ks = rebvio_hip_ctx::kSlots - 1;
-    c->bf_seq = 0x80000000u | (++c->bf_counter & 0x7FFFFFFFu);
-    HIPCHK(hipStreamWaitValue32(s, c->glue_flag + ks, c->bf_seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
-    c->bf_park_thread = std::this_thread::get_id();
-    c->bf_parked.store(true, std::memory_order_release);
-    launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_host[ks], c->glue_dev + ks, c->P.search_range, c->dm_work, c->dm_work_n);
-    const int gate = (int)c->P.global_min_matches_threshold;
-    launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + ks, gate > 0 ? gate : 0, c->dm_work_n, c->hist);
-    std::swap(nm->d.rs, nm->d.rs_tmp);
-    HIPCHK(hipGetLastError());
-  }
   const auto tb1 = std::chrono::steady_clock::now();
   HIPCHK(hipEventSynchronize(c->slot_ev[0]));
   const auto tb2 = std::chrono::steady_clock::now();
@@ -1916,25 +1772,6 @@ int rebvio_hip_track_pair_finish_async(rebvio_hip_ctx* c, rebvio_hip_map* om, re
     nm->pre_R = prior_rotation(c, R_prior_next);
     hm::store3(hm::transpose(nm->pre_R), RT_next);
   }
-  if (c->bf_parked.load(std::memory_order_acquire)) {
-    // the second half is already queued (see _begin): hand it the fusion's results and let it go. No runtime call from here
-    // to the flag.
-    GlueDev gl{};
-    rotate_inputs(c, g.V, g.P_V, g.Rgva, gl.vel_r, gl.Rvel_r);
-    std::memcpy(gl.Rgva, g.Rgva, sizeof(g.Rgva));
-    std::memcpy(gl.R0a, g.R0a, sizeof(g.R0a));
-    std::memcpy(gl.V, g.V, sizeof(g.V));
-    gl.nan_v = g.nan_v ? 1 : 0;
-    gl.has_next = R_prior_next ? 1 : 0;  // read by the last kernel at run time
-    if (R_prior_next) {
-      std::memcpy(gl.RT_next, RT_next, sizeof(RT_next));
-      std::swap(nm->d.grad, nm->d.grad_tmp);  // (host-side handles: they only shape LATER launches)
-      nm->pre_rotated = true;
-    }
-    write_glue_and_flag(c, rebvio_hip_ctx::kSlots - 1, c->bf_seq, gl);
-    c->bf_parked.store(false, std::memory_order_release);
-    return 0;
-  }
   enqueue_b_chain(c, om, nm, g, R_prior_next ? RT_next : nullptr);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1942,7 +1779,6 @@ int rebvio_hip_track_pair_finish_async(rebvio_hip_ctx* c, rebvio_hip_map* om, re
 
 int rebvio_hip_track_pair_hint_next(rebvio_hip_ctx* c, rebvio_hip_map* next_new_map) {
   if (!c || !next_new_map || next_new_map->ctx != c) return fail_msg("track_pair_hint_next: map of another context", -3);
-  if (c->bf_parked.load(std::memory_order_acquire)) return 0;  // (would queue behind the parked second half: nothing gained)
   HIPCHK(hipSetDevice(c->device));
   wait_enqueued(next_new_map);
   HIPCHK(trk_wait_ready_once(c, next_new_map));
@@ -1987,245 +1823,200 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_h
 
 namespace {
 // ---- streaming driver -------------------------------------------------------------------------------------------------
-// Per pair, on the track stream:   A = [rotate] + persistent minimizeVel/forwardMatch/extRotVel   (results -> pinned slot)
-//                                  W = hipStreamWaitValue32(glue_flag[slot] == seq)               (command processor waits)
-//                                  B = directedMatch (2 launches) + regularize/EKF/next rotate, parameters read from
-//                                      glue_host[slot] by the first kernel (which leaves a device copy for the others)
-// Within one push the caller enqueues W(k), B(k) and A(k+1) BEFORE it waits for A(k); then it waits for A(k)'s event, runs
-// the O(1) glue (rebvio.cpp:186-233), writes glue_host[slot] and the flag. No kernel launch sits between the end of A(k)
-// and the start of B(k), and no wait is ever left un-released when the call returns (a guard releases it on every error
-// path with nan_v = 1, so that the queued kernels fall through).
-// Cross-stream dependencies of a pair's first half (its two maps detected). Every stream operation between two kernels
-// of the track stream is a packet of its own for the command processor (the kernel trace shows ~7 us between the end of
-// k_regularize_ekf(k) and the start of k_lm_chain(k+1), filled by an event record and two event waits). So a map is waited
-// for once (the old map of a pair was the new map of the previous one), and with slim_ops the streaming driver enqueues the
-// waits of pair k+1 BEFORE the parked second half of pair k, where they are absorbed by the host glue's bubble (the detect
-// stage leads by `lead` frames, so they are long satisfied).
-int enqueue_a_waits(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
-  hipStream_t s = c->s_trk;
-  for (rebvio_hip_map* m : {pp.om, pp.nm}) {
-    if (m->trk_waited && c->slim_ops) continue;
+// Per pair, on the track stream, four launches and one event, nothing else:
+//   [rotate]  persistent minimizeVel / forwardMatch / extRotVel   (LM state, map state records -> pinned slot; sums -> device)
+//   directedMatch head, with the pair's GLUE evaluated on the device in its prologue (glue.hpp: 6x6 solve, gyroBiasCorrection,
+//             SO3, Cholesky; inputs from the LM kernel's records, filter state in device memory, results for the host in a
+//             pinned record) -> directedMatch tail -> regularize / depth EKF / next pair's first rotation
+//   event
+// The host never stands between a pair's halves (round 2: kernel end -> event -> host glue -> flag -> wait kernel, 8-10 us
+// of an ~80 us frame, and the reason the rate moved with the box's host): it queues pair k as soon as frame k + lead - 2 has
+// been handed to the detect worker and reads the pairs' records up to kSlots - 1 pairs later. A pair's match counters are
+// read from the NEXT pair's slot (its first kernel copies its old map's state record), so pair k is reported once pair
+// k + 1's event has fired; rebvio_hip_flush() fetches the last pair's counters itself.
+
+// Every stream operation between two kernels of the track stream is a packet of its own for the command processor, so a map
+// is waited for once (the old map of a pair was the new map of the previous one).
+int stream_wait_maps(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm) {
+  for (rebvio_hip_map* m : {om, nm}) {
+    if (m->trk_waited) continue;
     wait_enqueued(m);
-    HIPCHK(trk_wait_ready(s, m));
+    HIPCHK(trk_wait_ready(c->s_trk, m));
     m->trk_waited = true;
   }
   return 0;
 }
 
-int enqueue_a_chain(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp) {
+void stream_finish_record(rebvio_hip_ctx* c, const rebvio_hip_ctx::InFlight& a, const MapState& st) {
+  const GlueRec* r = c->rec[a.slot];
+  rebvio_hip_ctx::Done d;
+  d.out = r->out;
+  if (d.out.status != 1) {
+    d.out.klm_num = st.dm_matches;
+    d.out.kf_matches = st.dm_kf;
+    d.out.reg_num = st.reg_count;
+    if ((unsigned)d.out.klm_num < c->P.global_min_matches_threshold) d.out.status = 2;  // rebvio.cpp:247-252
+  }
+  d.keylines = st.n;
+  // host mirror of the filter state (rebvio_hip_get_gyro_state; authoritative again after a flush)
+  for (int i = 0; i < 3; ++i) c->Bg[i] = r->gs.Bg[i];
+  c->W_Bg = hm::load3(r->gs.W_Bg);
+  c->gs_R = hm::load3(r->gs.R);
+  note_accept_mask(c, d.out.lm_accept_mask);
+  c->t_queued += (double)st.dm_queued;
+  c->done.push_back(d);
+}
+
+// Reports the pairs whose successor has completed; `need` > 0: blocks until at least that many have been reported.
+int stream_harvest(rebvio_hip_ctx* c, int need) {
+  while (c->inflight.size() >= 2) {
+    const rebvio_hip_ctx::InFlight& a = c->inflight[0];
+    const rebvio_hip_ctx::InFlight& b = c->inflight[1];
+    if (need > 0) {
+      const auto t0 = std::chrono::steady_clock::now();
+      HIPCHK(hipEventSynchronize(c->slot_ev[b.slot]));
+      c->t_wait += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+      const hipError_t q = hipEventQuery(c->slot_ev[b.slot]);
+      if (q == hipErrorNotReady) break;
+      HIPCHK(q);
+    }
+    if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
+    stream_finish_record(c, a, c->slot[b.slot]->old_st);
+    c->inflight.pop_front();
+    --need;
+  }
+  return 0;
+}
+
+int stream_enqueue_pair(rebvio_hip_ctx* c) {
+  // the slot of pair k is reused by pair k + kSlots: its record (and its successor's) must have been read
+  while ((int)c->inflight.size() >= rebvio_hip_ctx::kSlots - 1) {
+    const int rc = stream_harvest(c, 1);
+    if (rc) return rc;
+  }
+  rebvio_hip_map *om = c->frames[0], *nm = c->frames[1];
   hipStream_t s = c->s_trk;
-  int rcw = enqueue_a_waits(c, pp);
-  if (rcw) return rcw;
-  c->df_map = pp.nm;
-  if (!pp.om->pre_rotated) {  // first pair of a stream: no B-chain has applied the prior rotation yet
-    pp.R = prior_rotation(c, nullptr);
-    float RT[9];
-    hm::store3(hm::transpose(pp.R), RT);
-    launch_rotate(s, c->K, pp.om->d, RT, c->hist, 0);
-  }  // else pp.R is set by the caller once the previous pair's glue has updated the gyro bias
-  const float v0[3] = {0, 0, 0};
-  PairSlot* slot = c->slot[pp.slot];
-  int rc = enqueue_pair_lm(c, pp.om, pp.nm, v0, slot);
+  int rc = stream_wait_maps(c, om, nm);
   if (rc) return rc;
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->slot_ev[pp.slot], s));
-  pp.a_enqueued = true;
-  return 0;
-}
-
-// W + B of a pair whose A-chain is already queued; everything that depends on the glue is read from memory at run time.
-int enqueue_b_chain_pre(rebvio_hip_ctx* c, rebvio_hip_ctx::PendingPair& pp, bool defer_release = false) {
-  hipStream_t s = c->s_trk;
-  HIPCHK(hipStreamWaitValue32(s, c->glue_flag + pp.slot, pp.seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
-  pp.b_enqueued = true;  // from here on the flag MUST be written, whatever happens
-  GlueDev* gd = c->glue_dev + pp.slot;
-  launch_directed_match_dev(s, c->K, pp.nm->d, pp.om->d, c->glue_host[pp.slot], gd, c->P.search_range, c->dm_work, c->dm_work_n);
+  c->df_map = nm;
+  const int slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
+  const int gpar = (int)(c->pair_seq & 1);
+  if (!om->pre_rotated) {
+    // first pair of a stream (or after a flush): no second half has applied the prior rotation yet, and the filter state the
+    // device works on is the host's
+    const hm::M3 R = prior_rotation(c, nullptr);
+    GlueState& gs = c->h_gstate[gpar];
+    for (int i = 0; i < 3; ++i) gs.Bg[i] = c->Bg[i];
+    hm::store3(c->W_Bg, gs.W_Bg);
+    hm::store3(R, gs.R);
+    gs.pad = 0.f;
+    HIPCHK(hipMemcpyAsync(c->gstate + gpar, &gs, sizeof(GlueState), hipMemcpyHostToDevice, s));
+    float RT[9];
+    hm::store3(hm::transpose(R), RT);
+    launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+  }
+  const float v0[3] = {0, 0, 0};
+  rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part);  // rebvio.cpp:167-177
+  if (rc) return rc;
+  const float frame_dt = (float)((double)(float)(nm->ts - om->ts) / 1000000.0);  // rebvio.cpp:183
+  const int calls = (int)c->P.iterations + 1;
+  GlueArgs ga;
+  ga.lm = c->lm + calls + 1;
+  ga.xrv = c->xrv_part;
+  ga.st_in = c->gstate + gpar;
+  ga.st_out = c->gstate + (gpar ^ 1);
+  ga.rec = c->rec[slot];
+  ga.gd_copy = c->glue_dev + slot;
+  ga.gp = glue_params(c, frame_dt);
+  launch_directed_match_glue(s, c->K, nm->d, om->d, ga, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
   const int gate = (int)c->P.global_min_matches_threshold;
-  launch_regularize_ekf_dev(s, c->K, pp.nm->d, gd, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
-  std::swap(pp.nm->d.rs, pp.nm->d.rs_tmp);
-  std::swap(pp.nm->d.grad, pp.nm->d.grad_tmp);
-  pp.nm->pre_rotated = true;
-  if (!defer_release) release_map(pp.om);  // stream-ordered: reusable once the B-chain has drained
+  launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
+  std::swap(nm->d.rs, nm->d.rs_tmp);
+  std::swap(nm->d.grad, nm->d.grad_tmp);
+  nm->pre_rotated = true;
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->slot_ev[slot], s));
+  release_map(om);  // stream-ordered: reusable once this pair has drained
+  rebvio_hip_ctx::InFlight f;
+  f.nm = nm;
+  f.slot = slot;
+  f.frame_dt = frame_dt;
+  c->inflight.push_back(f);
+  c->frames.erase(c->frames.begin());
+  c->pair_seq++;
   return 0;
 }
 
-// The record is composed on the stack and stored in one go: word stores only (the destination may be write-combined device
-// memory behind the BAR, which must never be read and whose stores need explicit fences to leave the CPU in order).
-void release_b_chain(rebvio_hip_ctx* c, const rebvio_hip_ctx::PendingPair& pp, const GlueDev& g) {
-  volatile unsigned* dst = reinterpret_cast<volatile unsigned*>(c->glue_host[pp.slot]);
-  unsigned words[sizeof(GlueDev) / sizeof(unsigned)];
-  std::memcpy(words, &g, sizeof(g));
-  for (size_t i = 0; i < sizeof(GlueDev) / sizeof(unsigned); ++i) dst[i] = words[i];
-  if (c->glue_vram) __atomic_thread_fence(__ATOMIC_SEQ_CST);  // mfence: drains write-combining buffers, record before flag
-  __atomic_store_n(c->glue_flag + pp.slot, pp.seq, __ATOMIC_RELEASE);
-  if (c->glue_vram) __atomic_thread_fence(__ATOMIC_SEQ_CST);  // push the flag out now
-}
-
-// Completes the pair whose A-chain is in flight: waits for its slot and runs the glue; then either releases the
-// pre-enqueued B-chain or (REBVIO_HIP_PRELAUNCH=0 / per-pair API style) enqueues it with the results as kernel arguments.
-// The directedMatch / regularize counters of the PREVIOUS pair arrive with this slot (old map of this pair).
-int finish_current(rebvio_hip_ctx* c, rebvio_hip_pair_out* completed, int* completed_keylines, bool* have_completed) {
-  rebvio_hip_ctx::PendingPair& cur = c->cur;
-  struct Guard {  // never leave the stream parked behind an un-released wait
-    rebvio_hip_ctx* c;
-    rebvio_hip_ctx::PendingPair* pp;
-    bool armed;
-    ~Guard() {
-      if (armed && pp->b_enqueued) {
-        GlueDev gl{};
-        gl.nan_v = 1;
-        release_b_chain(c, *pp, gl);
-      }
-    }
-  } guard{c, &cur, true};
-  const auto tw0 = std::chrono::steady_clock::now();
-  HIPCHK(hipEventSynchronize(c->slot_ev[cur.slot]));
-  const auto tw1 = std::chrono::steady_clock::now();
-  c->t_wait += std::chrono::duration<double, std::micro>(tw1 - tw0).count();
-  PairSlot* slot = c->slot[cur.slot];
-  if (c->has_prev) {
-    rebvio_hip_pair_out& po = c->prev.out;
-    if (po.status != 1) {
-      po.klm_num = slot->old_st.dm_matches;
-      po.kf_matches = slot->old_st.dm_kf;
-      po.reg_num = slot->old_st.reg_count;
-      if ((unsigned)po.klm_num < c->P.global_min_matches_threshold) po.status = 2;
-    }
-    c->t_queued += (double)slot->old_st.dm_queued;
-    if (completed) *completed = po;
-    if (completed_keylines) *completed_keylines = slot->old_st.n;
-    if (have_completed) *have_completed = true;
-    c->has_prev = false;
+// everything queued completes; every pair's record ends in c->done
+int stream_drain(rebvio_hip_ctx* c) {
+  int rc = stream_harvest(c, (int)c->inflight.size());
+  if (rc) return rc;
+  if (c->inflight.size() == 1) {  // the last pair has no successor to carry its counters
+    const rebvio_hip_ctx::InFlight a = c->inflight[0];
+    HIPCHK(hipEventSynchronize(c->slot_ev[a.slot]));
+    if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
+    HIPCHK(hipMemcpyAsync(&c->h_st[1], a.nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
+    HIPCHK(hipStreamSynchronize(c->s_trk));
+    stream_finish_record(c, a, c->h_st[1]);
+    c->inflight.pop_front();
   }
-  cur.nm->n_host = slot->new_st.n;
-  cur.nm->thr_host = slot->new_st.threshold;
-  std::memset(&cur.out, 0, sizeof(cur.out));
-  const GlueOut g = pair_glue(c, slot->lm, slot->xrv, cur.nm->n_host, cur.frame_dt, cur.R, &cur.out);
-  // the new map becomes the next pair's old map: its first rotation (prior after this glue's bias update) rides along
-  float RT_next[9];
-  hm::store3(hm::transpose(prior_rotation(c, nullptr)), RT_next);
-  if (cur.b_enqueued) {
-    GlueDev gl{};
-    rotate_inputs(c, g.V, g.P_V, g.Rgva, gl.vel_r, gl.Rvel_r);
-    std::memcpy(gl.Rgva, g.Rgva, sizeof(g.Rgva));
-    std::memcpy(gl.R0a, g.R0a, sizeof(g.R0a));
-    std::memcpy(gl.V, g.V, sizeof(g.V));
-    std::memcpy(gl.RT_next, RT_next, sizeof(RT_next));
-    gl.nan_v = g.nan_v ? 1 : 0;
-    gl.has_next = 1;
-    release_b_chain(c, cur, gl);
-    guard.armed = false;
-    c->t_glue += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw1).count();
-  } else {
-    const auto tg1 = std::chrono::steady_clock::now();
-    c->t_glue += std::chrono::duration<double, std::micro>(tg1 - tw1).count();
-    enqueue_b_chain(c, cur.om, cur.nm, g, RT_next);
-    c->t_b_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tg1).count();
-    HIPCHK(hipGetLastError());
-    release_map(cur.om);  // stream-ordered: reusable once the B-chain has drained
-    guard.armed = false;
-  }
-  if (g.nan_v) cur.out.status = 1;
-  c->prev = cur;
-  c->has_prev = true;
-  c->has_cur = false;
   return 0;
 }
 }  // namespace
 
 int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
                                     int* keylines) {
-  // Software pipeline over the three HIP streams of the context (one host synchronisation per frame):
+  // Software pipeline over the three HIP streams of the context:
   //   scan / keyline streams : frame f (this call, through the detect worker)
-  //   track stream           : see the comment above enqueue_a_chain
-  // The returned record is the most recent COMPLETE pair (its match counters travel with the next pair's slot), a few
-  // frames behind f in steady state; status -1 while the pipeline fills.
+  //   track stream           : see the comment above stream_wait_maps
+  // The returned record is the oldest COMPLETE pair not yet handed out, several frames behind f in steady state; status -1
+  // while there is none.
   // Lead: pair (k-1, k) is started once frame k+lead-2 has been queued for detection. A frame's detection takes ~130 us
-  // from enqueue to its distance field (scan chain, then keyline chain) while the tracker needs a new map every ~90 us: with
-  // the minimum lead of 3 the kernel trace showed k_lm_chain starting 11-12 us after the previous pair's last kernel,
-  // waiting for that map; lead 5 keeps two more detections in flight (10.7 k -> 11.3 k frames/s; 4 and 6+ measured no
-  // better). Costs latency of the returned records, not throughput; flush() drops the pairs not yet started.
+  // from enqueue to its distance field (scan chain, then keyline chain) while the tracker needs a new map every ~70-80 us: with
+  // the minimum lead of 3 the kernel trace showed the LM kernel starting 11-12 us after the previous pair's last kernel,
+  // waiting for that map; lead 5 keeps two more detections in flight. Costs latency of the returned records, not throughput;
+  // flush() drops the frames no pair was started for.
   rebvio_hip_map* m = nullptr;
   const auto td0 = std::chrono::steady_clock::now();
   HIPCHK(hipSetDevice(c->device));
+  if (out) {
+    std::memset(out, 0, sizeof(*out));
+    out->status = -1;
+  }
+  if (keylines) *keylines = -1;
   int rc = detect_async(c, frame_dev, 1, ts_us, &m);
   if (rc) return rc;
   {
     std::lock_guard<std::mutex> lk(c->det_mu);  // written by the detect worker
     if (!c->det_error.empty()) return fail_msg(c->det_error.c_str(), -8);
   }
-  c->t_detect_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td0).count();
+  const auto td1 = std::chrono::steady_clock::now();
+  c->t_detect_enq += std::chrono::duration<double, std::micro>(td1 - td0).count();
   c->t_frames++;
   c->frames.push_back(m);
-  if (out) {
-    std::memset(out, 0, sizeof(*out));
-    out->status = -1;
-  }
-  if (keylines) *keylines = -1;
-  // 1. second half of the pair in flight, parked behind its wait; 2. first half of the next pair behind that
-  int rc_pre = 0;
-  const auto tb0 = std::chrono::steady_clock::now();
-  rebvio_hip_ctx::PendingPair pp;
-  bool have_next = false;
-  const bool next_ready = (int)c->frames.size() >= c->lead && (!c->has_cur || c->prelaunch_b);
-  if (next_ready) {
+  if ((int)c->frames.size() >= c->lead) {
     // frames[1] was detected at least lead - 2 calls ago: the track stream will not stall on it
-    pp.om = c->frames[0];
-    pp.nm = c->frames[1];
-    if (c->slim_ops) rc_pre = enqueue_a_waits(c, pp);  // ahead of the parked second half (see enqueue_a_waits)
-  }
-  const bool defer_release = c->slim_ops && next_ready && rc_pre == 0;
-  rebvio_hip_map* deferred = nullptr;
-  if (rc_pre == 0 && c->has_cur && c->prelaunch_b) {
-    rc_pre = enqueue_b_chain_pre(c, c->cur, defer_release);
-    if (defer_release) deferred = c->cur.om;
-  }
-  const auto ta0 = std::chrono::steady_clock::now();
-  c->t_b_enq += std::chrono::duration<double, std::micro>(ta0 - tb0).count();
-  if (rc_pre == 0 && next_ready) {
-    pp.slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
-    pp.seq = (unsigned)(++c->pair_seq);
-    if (pp.seq == 0) pp.seq = (unsigned)(++c->pair_seq);  // 0 is the idle value of the flags
-    pp.frame_dt = (float)((double)(float)(pp.nm->ts - pp.om->ts) / 1000000.0);  // rebvio.cpp:183
-    rc_pre = enqueue_a_chain(c, pp);
-    have_next = rc_pre == 0;
-    if (have_next) c->frames.erase(c->frames.begin());
-  }
-  // the old map of the pair in flight: its release (an event record) goes behind the next first half, off the path between
-  // k_regularize_ekf(k) and k_lm_chain(k+1)
-  if (deferred) release_map(deferred);
-  c->t_a_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta0).count();
-  // 3. wait for the pair in flight, glue, release (also on the error paths above: finish_current's guard releases)
-  if (c->has_cur) {
-    bool have = false;
-    rebvio_hip_pair_out done;
-    int nk = -1;
-    rc = finish_current(c, &done, &nk, &have);
+    rc = stream_enqueue_pair(c);
     if (rc) return rc;
-    if (have) {
-      if (out) *out = done;
-      if (keylines) *keylines = nk;
-    }
   }
-  if (rc_pre) return rc_pre;
-  if (!c->prelaunch_b && (int)c->frames.size() >= c->lead) {  // classic order: the next first half goes behind the B-chain just enqueued
-    pp.om = c->frames[0];
-    pp.nm = c->frames[1];
-    pp.slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
-    pp.seq = (unsigned)(++c->pair_seq);
-    pp.frame_dt = (float)((double)(float)(pp.nm->ts - pp.om->ts) / 1000000.0);
-    rc = enqueue_a_chain(c, pp);
-    if (rc) return rc;
-    have_next = true;
-    c->frames.erase(c->frames.begin());
-  }
-  if (have_next) {
-    if (pp.om->pre_rotated) pp.R = prior_rotation(c, nullptr);  // what the previous B-chain applies (gyro bias as of now)
-    c->cur = pp;
-    c->has_cur = true;
+  c->t_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td1).count();
+  rc = stream_harvest(c, 0);
+  if (rc) return rc;
+  if (!c->done.empty()) {
+    if (out) *out = c->done.front().out;
+    if (keylines) *keylines = c->done.front().keylines;
+    c->done.pop_front();
   }
   return 0;
+}
+
+int rebvio_hip_next_record(rebvio_hip_ctx* c, rebvio_hip_pair_out* out, int* keylines) {
+  if (c->done.empty()) return 0;
+  if (out) *out = c->done.front().out;
+  if (keylines) *keylines = c->done.front().keylines;
+  c->done.pop_front();
+  return 1;
 }
 
 int rebvio_hip_flush(rebvio_hip_ctx* c) {
@@ -2255,22 +2046,12 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
   if (std::getenv("REBVIO_HIP_DEBUG") && c->t_frames) {
     const double n = (double)c->t_frames;
     std::fprintf(stderr,
-                 "[rebvio_hip] per frame (us): detect-enqueue %.1f  wait %.1f  glue %.1f  B-enqueue %.1f  A-enqueue %.1f | long "
+                 "[rebvio_hip] host time per frame (us): detect hand-over %.1f  pair enqueue %.1f  waiting for result slots %.1f | long "
                  "directedMatch searches per pair %.0f\n",
-                 c->t_detect_enq / n, c->t_wait / n, c->t_glue / n, c->t_b_enq / n, c->t_a_enq / n, c->t_queued / n);
+                 c->t_detect_enq / n, c->t_enq / n, c->t_wait / n, c->t_queued / n);
   }
   while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
-  if (c->has_cur) {
-    int rc = 0;
-    if (c->prelaunch_b) rc = enqueue_b_chain_pre(c, c->cur);
-    const int rc2 = finish_current(c, nullptr, nullptr, nullptr);  // releases the wait in every case
-    if (rc) return rc;
-    if (rc2) return rc2;
-  }
-  if (c->has_prev) {
-    release_map(c->prev.nm);
-    c->has_prev = false;
-  }
+  int rc = stream_drain(c);
   for (auto* m : c->frames)
     if (m->in_use) release_map(m);
   c->frames.clear();
@@ -2280,9 +2061,8 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
   HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), c->s_trk));
   HIPCHK(hipStreamSynchronize(c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_key));
-  HIPCHK(hipStreamSynchronize(c->s_df));
   { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
-  return 0;
+  return rc;
 }
 
 int rebvio_hip_profile_enable(rebvio_hip_ctx* c, int on) {
@@ -2373,14 +2153,11 @@ struct rebvio_hip_batch {
   SharedStreams st{};
   std::vector<rebvio_hip_ctx*> lane;
   LaneStatic* ls_dev = nullptr;
+  std::vector<LaneStatic> ls_host;  // what ls_dev holds (re-uploaded when a lane's lens model changes)
+  bool lens = false;                // every lane has a lens model: the batched front end runs ahead of the scans
   MapDev* maptab_dev = nullptr;
   hipEvent_t ev_scan[2]{}, ev_flag[2]{};
   bool ev_flag_used[2] = {false, false};
-  // second scan stream: with >= 4 lanes the scale space of the upper half of the lanes runs beside that of the lower half
-  // (a lane's seven scan kernels depend on each other only; two half-sized chains overlap where one full-sized chain cannot)
-  hipStream_t s_det2{};
-  hipEvent_t ev_scan2[2]{};
-  int split = 0;  // lanes on the first scan stream (0: one stream)
   static constexpr int kReadyRing = 16;
   hipEvent_t ev_ready[kReadyRing]{};  // keylines + distance fields of a step finished (keyline stream)
   hipEvent_t slot_ev[rebvio_hip_ctx::kSlots]{};
@@ -2390,32 +2167,29 @@ struct rebvio_hip_batch {
     uint64_t step;
   };
   std::deque<Frame> frames;
-  struct Pair {
-    Frame of, nf;
+  struct InFlight {  // a step's pairs (one per lane) whose kernels are queued and whose records have not been read yet
+    Frame nf;
     int slot = -1;
-    std::vector<hm::M3> R;
-    float frame_dt = 0.f;
-    std::vector<rebvio_hip_pair_out> out;
   };
-  Pair cur, prev;
-  bool has_cur = false, has_prev = false;
+  struct Done {
+    std::vector<rebvio_hip_pair_out> out;
+    std::vector<int> keylines;
+  };
+  std::deque<InFlight> inflight;
+  std::deque<Done> done;
   uint64_t pair_seq = 0;
   int lead = 4;
-  // second halves are queued BEFORE the host has the glue: parked behind a hipStreamWaitValue32 on this pinned word (one for
-  // the whole batch), released with the pair's sequence number once every lane's glue record is written (as in the
-  // single-stream driver, see enqueue_a_chain)
-  unsigned* glue_flag = nullptr;
-  bool prelaunch_b = true;
-  bool cur_b_enqueued = false;
-  unsigned cur_seq = 0;
-  // detect-enqueue worker: launches the detect stage of a step while the caller thread runs the glue and launches the
-  // track stage (the reference's data-acquisition thread, rebvio.cpp:28; same split as the single-stream driver)
+  int dm_head_form = 0;   // REBVIO_HIP_BATCH_DM_HEAD: 0 by lane count, 1 thread per keyline, 2 eight lanes per keyline
+  bool poisoned = false;  // a step failed half way (some lanes prepared, others not): every later call is refused
+  // detect-enqueue worker: launches the detect stage of a step while the caller thread launches the track stage (the
+  // reference's data-acquisition thread, rebvio.cpp:28; same split as the single-stream driver)
   struct DetStep {
     LaneDynB dyn;
     int par;
     uint64_t step;
     hipEvent_t reuse_done;  // last consumer of the maps this step reuses (null: fresh maps)
     std::vector<rebvio_hip_map*> maps;
+    bool lens;
   };
   std::thread det_thread;
   std::mutex det_mu;
@@ -2440,120 +2214,27 @@ int batch_upload_map_entry(rebvio_hip_batch* b, int lane, rebvio_hip_map* m) {
 }
 inline unsigned map_swap_bits(const rebvio_hip_map* m) { return (m->d.rs != m->canon.rs ? 1u : 0u) | (m->d.grad != m->canon.grad ? 2u : 0u); }
 
-void batch_release_map(rebvio_hip_map* m, bool record_done);
-
-// second half of the pair in flight for every lane (batched); with `parked` it sits behind the wait on the batch's flag and
-// reads the glue records the host writes later. The old maps go back to their pools (stream-ordered).
-int batch_enqueue_b(rebvio_hip_batch* b, bool parked) {
-  rebvio_hip_batch::Pair& cur = b->cur;
-  hipStream_t s = b->st.s_trk;
-  if (parked) {
-    HIPCHK(hipStreamWaitValue32(s, b->glue_flag, b->cur_seq, hipStreamWaitValueEq, 0xFFFFFFFFu));
-    b->cur_b_enqueued = true;  // from here on the flag MUST be written, whatever happens
+// a map of a batch goes back to its lane's pool; only the last lane's release is marked in the stream (the releases of a
+// step sit at one point of the track stream, and the detect stage waits for that one event)
+void batch_release_map(rebvio_hip_map* m, bool record_done) {
+  if (!m || !m->in_use) return;
+  rebvio_hip_ctx* c = m->ctx;
+  wait_enqueued(m);
+  if (record_done) {
+    (void)hipEventRecord(m->done, c->s_trk);
+    m->has_done = true;
   }
-  LaneDynB dyn{};
-  for (int l = 0; l < b->B; ++l) {
-    LaneDyn& d = dyn.v[l];
-    d.nm = (short)cur.nf.m[l]->tab_idx;
-    d.om = (short)cur.of.m[l]->tab_idx;
-    d.nm_swap = (unsigned char)map_swap_bits(cur.nf.m[l]);
-    d.om_swap = (unsigned char)map_swap_bits(cur.of.m[l]);
-    d.slot = (unsigned char)cur.slot;
-  }
-  const int gate = (int)b->P.global_min_matches_threshold;
-  launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0);
-  HIPCHK(hipGetLastError());
-  for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
-    rebvio_hip_map* nm = cur.nf.m[l];
-    std::swap(nm->d.rs, nm->d.rs_tmp);
-    std::swap(nm->d.grad, nm->d.grad_tmp);
-    nm->pre_rotated = true;
-    batch_release_map(cur.of.m[l], l == b->B - 1);
-  }
-  return 0;
-}
-
-void batch_release_flag(rebvio_hip_batch* b) {
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // every lane's record before the flag
-  __atomic_store_n(b->glue_flag, b->cur_seq, __ATOMIC_RELEASE);
-}
-
-// waits for the first half of the pair in flight, runs every lane's glue (rebvio.cpp:186-233) and leaves the records where
-// the second half reads them; the counters of the PREVIOUS pair arrive with this pair's slot (its old maps)
-int batch_glue_current(rebvio_hip_batch* b, rebvio_hip_pair_out* completed, int* completed_keylines) {
-  rebvio_hip_batch::Pair& cur = b->cur;
-  struct Guard {  // never leave the stream parked behind an un-released wait
-    rebvio_hip_batch* b;
-    bool armed;
-    ~Guard() {
-      if (armed && b->cur_b_enqueued) {
-        for (int l = 0; l < b->B; ++l) {
-          GlueDev gl{};
-          gl.nan_v = 1;
-          std::memcpy(b->lane[l]->glue_host[b->cur.slot], &gl, sizeof(gl));
-        }
-        batch_release_flag(b);
-      }
-    }
-  } guard{b, true};
-  HIPCHK(hipEventSynchronize(b->slot_ev[cur.slot]));
-  for (int l = 0; l < b->B; ++l) {
-    rebvio_hip_ctx* c = b->lane[l];
-    PairSlot* slot = c->slot[cur.slot];
-    if (*c->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
-    if (b->has_prev) {
-      rebvio_hip_pair_out& po = b->prev.out[l];
-      if (po.status != 1) {
-        po.klm_num = slot->old_st.dm_matches;
-        po.kf_matches = slot->old_st.dm_kf;
-        po.reg_num = slot->old_st.reg_count;
-        if ((unsigned)po.klm_num < c->P.global_min_matches_threshold) po.status = 2;
-      }
-      if (completed) completed[l] = po;
-      if (completed_keylines) completed_keylines[l] = slot->old_st.n;
-    }
-    rebvio_hip_map* nm = cur.nf.m[l];
-    nm->n_host = slot->new_st.n;
-    nm->thr_host = slot->new_st.threshold;
-    std::memset(&cur.out[l], 0, sizeof(cur.out[l]));
-    const GlueOut g = pair_glue(c, slot->lm, slot->xrv, nm->n_host, cur.frame_dt, cur.R[l], &cur.out[l]);
-    float RT_next[9];
-    hm::store3(hm::transpose(prior_rotation(c, nullptr)), RT_next);
-    GlueDev gl{};
-    rotate_inputs(c, g.V, g.P_V, g.Rgva, gl.vel_r, gl.Rvel_r);
-    std::memcpy(gl.Rgva, g.Rgva, sizeof(g.Rgva));
-    std::memcpy(gl.R0a, g.R0a, sizeof(g.R0a));
-    std::memcpy(gl.V, g.V, sizeof(g.V));
-    std::memcpy(gl.RT_next, RT_next, sizeof(RT_next));
-    gl.nan_v = g.nan_v ? 1 : 0;
-    gl.has_next = 1;
-    {  // plain word stores: the destination may be write-combined device memory behind the BAR (REBVIO_HIP_GLUE=vram)
-      volatile unsigned* dst = reinterpret_cast<volatile unsigned*>(c->glue_host[cur.slot]);
-      unsigned words[sizeof(GlueDev) / sizeof(unsigned)];
-      std::memcpy(words, &gl, sizeof(gl));
-      for (size_t i = 0; i < sizeof(GlueDev) / sizeof(unsigned); ++i) dst[i] = words[i];
-    }
-    if (g.nan_v) cur.out[l].status = 1;
-  }
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  if (b->cur_b_enqueued) batch_release_flag(b);
-  guard.armed = false;
-  return 0;
+  if (c->df_map == m) c->df_map = nullptr;
+  m->release_seq = ++c->release_counter;
+  m->in_use = false;
 }
 
 int batch_detect_launch(rebvio_hip_batch* b, const rebvio_hip_batch::DetStep& j) {
   const int B = b->B, par = j.par;
   if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->st.s_det, b->ev_flag[par], 0));
-  const int n0 = b->split > 0 ? b->split : B;
-  launch_scale_space_b(b->st.s_det, b->K, 0, n0, b->ls_dev, j.dyn, b->lane[0]->widths);
+  launch_scale_space_b(b->st.s_det, b->K, 0, B, b->ls_dev, j.dyn, b->lane[0]->widths, j.lens);
   HIPCHK(hipEventRecord(b->ev_scan[par], b->st.s_det));
   HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan[par], 0));
-  if (n0 < B) {
-    if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->s_det2, b->ev_flag[par], 0));
-    launch_scale_space_b(b->s_det2, b->K, n0, B - n0, b->ls_dev, j.dyn, b->lane[0]->widths);
-    HIPCHK(hipEventRecord(b->ev_scan2[par], b->s_det2));
-    HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan2[par], 0));
-  }
   if (j.reuse_done) HIPCHK(hipStreamWaitEvent(b->st.s_key, j.reuse_done, 0));
   launch_keylines_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
   HIPCHK(hipGetLastError());
@@ -2589,35 +2270,84 @@ void batch_det_worker(rebvio_hip_batch* b) {
   }
 }
 
-// a map of a batch goes back to its lane's pool; only the last lane's release is marked in the stream (the releases of a
-// step sit at one point of the track stream, and the detect stage waits for that one event)
-void batch_release_map(rebvio_hip_map* m, bool record_done) {
-  if (!m || !m->in_use) return;
-  rebvio_hip_ctx* c = m->ctx;
-  wait_enqueued(m);
-  if (record_done) {
-    (void)hipEventRecord(m->done, c->s_trk);
-    m->has_done = true;
+void batch_finish_records(rebvio_hip_batch* b, const rebvio_hip_batch::InFlight& a, const MapState* st_of_lane /*[B]*/) {
+  rebvio_hip_batch::Done d;
+  d.out.resize((size_t)b->B);
+  d.keylines.resize((size_t)b->B);
+  for (int l = 0; l < b->B; ++l) {
+    rebvio_hip_ctx* c = b->lane[l];
+    const GlueRec* r = c->rec[a.slot];
+    const MapState& st = st_of_lane[l];
+    rebvio_hip_pair_out o = r->out;
+    if (o.status != 1) {
+      o.klm_num = st.dm_matches;
+      o.kf_matches = st.dm_kf;
+      o.reg_num = st.reg_count;
+      if ((unsigned)o.klm_num < c->P.global_min_matches_threshold) o.status = 2;
+    }
+    d.out[(size_t)l] = o;
+    d.keylines[(size_t)l] = st.n;
+    for (int i = 0; i < 3; ++i) c->Bg[i] = r->gs.Bg[i];
+    c->W_Bg = hm::load3(r->gs.W_Bg);
+    c->gs_R = hm::load3(r->gs.R);
+    note_accept_mask(c, o.lm_accept_mask);
   }
-  if (c->df_map == m) c->df_map = nullptr;
-  m->release_seq = ++c->release_counter;
-  m->in_use = false;
+  b->done.push_back(std::move(d));
 }
 
-int batch_enqueue_a(rebvio_hip_batch* b, rebvio_hip_batch::Pair& pp) {
+// as stream_harvest, for all lanes of a step at once (one event per step)
+int batch_harvest(rebvio_hip_batch* b, int need) {
+  std::vector<MapState> st((size_t)b->B);
+  while (b->inflight.size() >= 2) {
+    const rebvio_hip_batch::InFlight& a = b->inflight[0];
+    const rebvio_hip_batch::InFlight& n = b->inflight[1];
+    if (need > 0) {
+      HIPCHK(hipEventSynchronize(b->slot_ev[n.slot]));
+    } else {
+      const hipError_t q = hipEventQuery(b->slot_ev[n.slot]);
+      if (q == hipErrorNotReady) break;
+      HIPCHK(q);
+    }
+    for (int l = 0; l < b->B; ++l) {
+      if (*b->lane[l]->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
+      st[(size_t)l] = b->lane[l]->slot[n.slot]->old_st;
+    }
+    batch_finish_records(b, a, st.data());
+    b->inflight.pop_front();
+    --need;
+  }
+  return 0;
+}
+
+// one step's pairs, all lanes: [rotate +] LM kernel, directedMatch head with every lane's glue in its prologue, tail,
+// regularize / EKF / next rotation, one event
+int batch_enqueue_pair(rebvio_hip_batch* b) {
+  while ((int)b->inflight.size() >= rebvio_hip_ctx::kSlots - 1) {
+    const int rc = batch_harvest(b, 1);
+    if (rc) return rc;
+  }
   hipStream_t s = b->st.s_trk;
-  while (b->det_done_steps.load(std::memory_order_acquire) <= pp.nf.step) std::this_thread::yield();  // its event has been recorded
-  HIPCHK(hipStreamWaitEvent(s, b->ev_ready[pp.nf.step % rebvio_hip_batch::kReadyRing], 0));  // (the old frame's step is earlier: same stream order)
+  const rebvio_hip_batch::Frame of = b->frames[0], nf = b->frames[1];
+  while (b->det_done_steps.load(std::memory_order_acquire) <= nf.step) std::this_thread::yield();  // its event has been recorded
+  HIPCHK(hipStreamWaitEvent(s, b->ev_ready[nf.step % rebvio_hip_batch::kReadyRing], 0));  // (the old frame's step is earlier: same stream order)
+  const int slot = (int)(b->pair_seq % rebvio_hip_ctx::kSlots);
+  const int gpar = (int)(b->pair_seq & 1);
   LaneDynB dyn{};
   const int calls = (int)b->P.iterations + 1;
   for (int l = 0; l < b->B; ++l) {
     rebvio_hip_ctx* c = b->lane[l];
-    rebvio_hip_map *om = pp.of.m[l], *nm = pp.nf.m[l];
+    rebvio_hip_map *om = of.m[l], *nm = nf.m[l];
     c->df_map = nm;
-    pp.R[l] = prior_rotation(c, nullptr);
-    if (!om->pre_rotated) {  // first pair of the lane: no second half has applied the prior rotation yet
+    if (!om->pre_rotated) {  // first pair of the lane: no second half has applied the prior rotation yet; the host's state goes up
+      const hm::M3 R = prior_rotation(c, nullptr);
+      GlueState& gs = c->h_gstate[gpar];
+      for (int i = 0; i < 3; ++i) gs.Bg[i] = c->Bg[i];
+      hm::store3(c->W_Bg, gs.W_Bg);
+      hm::store3(R, gs.R);
+      gs.pad = 0.f;
+      HIPCHK(hipMemcpyAsync(c->gstate + gpar, &gs, sizeof(GlueState), hipMemcpyHostToDevice, s));
       float RT[9];
-      hm::store3(hm::transpose(pp.R[l]), RT);
+      hm::store3(hm::transpose(R), RT);
       launch_rotate(s, c->K, om->d, RT, c->hist, 0);
     }
     LaneDyn& d = dyn.v[l];
@@ -2625,7 +2355,8 @@ int batch_enqueue_a(rebvio_hip_batch* b, rebvio_hip_batch::Pair& pp) {
     d.om = (short)om->tab_idx;
     d.nm_swap = (unsigned char)map_swap_bits(nm);
     d.om_swap = (unsigned char)map_swap_bits(om);
-    d.slot = (unsigned char)pp.slot;
+    d.slot = (unsigned char)slot;
+    d.gpar = (unsigned char)gpar;
     d.tag_base = c->lm_tag_base;
     c->lm_tag_base += 2u * ((unsigned)calls + 1u);
     if (c->lm_tag_base > 0xFFFFFF00u) {
@@ -2637,9 +2368,54 @@ int batch_enqueue_a(rebvio_hip_batch* b, rebvio_hip_batch::Pair& pp) {
   if (spec_now && !b->lane[0]->lm_spec_forced)
     for (auto* c : b->lane) spec_now = spec_now && c->lm_miss_ema < 0.17f;
   launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0);
+  const int gate = (int)b->P.global_min_matches_threshold;
+  const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
+  launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, calls,
+                   glue_params(b->lane[0], frame_dt), b->dm_head_form);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b->slot_ev[pp.slot], s));
+  for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
+    rebvio_hip_map* nm = nf.m[l];
+    std::swap(nm->d.rs, nm->d.rs_tmp);
+    std::swap(nm->d.grad, nm->d.grad_tmp);
+    nm->pre_rotated = true;
+    batch_release_map(of.m[l], l == b->B - 1);
+  }
+  HIPCHK(hipEventRecord(b->slot_ev[slot], s));
+  rebvio_hip_batch::InFlight f;
+  f.nf = nf;
+  f.slot = slot;
+  b->inflight.push_back(f);
+  b->frames.pop_front();
+  b->pair_seq++;
   return 0;
+}
+
+int batch_drain(rebvio_hip_batch* b) {
+  int rc = batch_harvest(b, (int)b->inflight.size());
+  if (rc) return rc;
+  if (b->inflight.size() == 1) {  // the last step has no successor to carry its counters
+    const rebvio_hip_batch::InFlight a = b->inflight[0];
+    HIPCHK(hipEventSynchronize(b->slot_ev[a.slot]));
+    std::vector<MapState> st((size_t)b->B);
+    for (int l = 0; l < b->B; ++l) {
+      if (*b->lane[l]->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
+      HIPCHK(hipMemcpy(&st[(size_t)l], a.nf.m[l]->d.st, sizeof(MapState), hipMemcpyDeviceToHost));
+    }
+    batch_finish_records(b, a, st.data());
+    b->inflight.pop_front();
+  }
+  return 0;
+}
+
+int batch_pop(rebvio_hip_batch* b, rebvio_hip_pair_out* out, int* keylines) {
+  if (b->done.empty()) return 0;
+  const rebvio_hip_batch::Done& d = b->done.front();
+  for (int l = 0; l < b->B; ++l) {
+    if (out) out[l] = d.out[(size_t)l];
+    if (keylines) keylines[l] = d.keylines[(size_t)l];
+  }
+  b->done.pop_front();
+  return 1;
 }
 }  // namespace
 
@@ -2660,11 +2436,8 @@ void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
   // the maps of queued steps and of the pairs in flight are the batch's own, not handles a caller holds
   for (auto& f : b->frames)
     for (auto* m : f.m) m->in_use = false;
-  if (b->has_cur)
-    for (auto* fr : {&b->cur.of, &b->cur.nf})
-      for (auto* m : fr->m) m->in_use = false;
-  if (b->has_prev)
-    for (auto* m : b->prev.nf.m) m->in_use = false;
+  for (auto& f : b->inflight)
+    for (auto* m : f.nf.m) m->in_use = false;
   for (auto* c : b->lane) rebvio_hip_destroy(c);
   if (b->ls_dev) (void)hipFree(b->ls_dev);
   if (b->maptab_dev) (void)hipFree(b->maptab_dev);
@@ -2676,10 +2449,6 @@ void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : b->slot_ev)
     if (e) (void)hipEventDestroy(e);
-  if (b->glue_flag) (void)hipHostFree(b->glue_flag);
-  for (auto& ev : b->ev_scan2)
-    if (ev) (void)hipEventDestroy(ev);
-  if (b->s_det2) (void)hipStreamDestroy(b->s_det2);
   if (b->st.s_det) (void)hipStreamDestroy(b->st.s_det);
   if (b->st.s_key) (void)hipStreamDestroy(b->st.s_key);
   if (b->st.s_trk) (void)hipStreamDestroy(b->st.s_trk);
@@ -2688,13 +2457,24 @@ void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
 
 int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_batch** out) {
   *out = nullptr;
-  if (lanes < 1 || lanes > kMaxLanes) return fail_msg("batch: lanes must be in 1..8", -3);
-  if (p->keylines_max > 32768) return fail_msg("batch: keylines_max <= 32768 (the batched directedMatch head is the eight-lanes-per-keyline form)", -3);
+  if (lanes < 1 || lanes > kMaxLanes) return fail_msg("batch: lanes must be in 1..16", -3);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) return fail_msg("no HIP device present: the gfx950 backend has no CPU fallback", -4);
   if (p->device_id < 0 || p->device_id >= ndev) return fail_msg("device_id out of range", -3);
   HIPCHK(hipSetDevice(p->device_id));
+  {
+    // The persistent LM kernel exchanges records among the workgroups of a lane: all of a launch's workgroups (lanes x
+    // ceil(keylines_max / 512)) must be resident at once. Checked here against what the device admits, instead of finding out
+    // from an exchange time-out (-9) under load.
+    const int max_lanes = lm_chain_b_max_lanes(p->device_id, p->keylines_max, (int)p->iterations + 1);
+    if (lanes > max_lanes) {
+      char msg[200];
+      std::snprintf(msg, sizeof(msg), "batch: %d lanes of %d keylines do not fit the device at once (the persistent LM kernel needs all "
+                    "its workgroups resident): at most %d lanes", lanes, p->keylines_max, max_lanes);
+      return fail_msg(msg, -3);
+    }
+  }
   rebvio_hip_batch* b = new rebvio_hip_batch;
   struct Guard {
     rebvio_hip_batch* b;
@@ -2746,9 +2526,14 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
     L.dm_work_n = c->dm_work_n;
     for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
       L.slot[i] = c->slot[i];
-      L.glue_host[i] = c->glue_host[i];
+      L.rec[i] = c->rec[i];
     }
     L.glue_dev = c->glue_dev;
+    L.gstate = c->gstate;
+    L.xrv_part = c->xrv_part;
+    L.undist_map = c->undist_map;
+    L.undist_img[0] = c->undist_img[0];
+    L.undist_img[1] = c->undist_img[1];
     for (auto* m : c->pool) {
       const int rc = batch_upload_map_entry(b, l, m);
       if (rc) return rc;
@@ -2756,30 +2541,16 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   }
   HIPCHK(hipMalloc(&b->ls_dev, ls.size() * sizeof(LaneStatic)));
   HIPCHK(hipMemcpy(b->ls_dev, ls.data(), ls.size() * sizeof(LaneStatic), hipMemcpyHostToDevice));
+  b->ls_host = ls;
   for (int i = 0; i < 2; ++i) {
     HIPCHK(hipEventCreateWithFlags(&b->ev_scan[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&b->ev_flag[i], hipEventDisableTiming));
   }
   for (auto& e : b->ev_ready) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : b->slot_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  {
-    const char* e = std::getenv("REBVIO_HIP_BATCH_SPLIT");  // 1: two scan streams (lower / upper half of the lanes); default one
-    const bool want = e ? std::atoi(e) != 0 : false;  // measured at 4 and 8 lanes: no gain (the chip, not the chain, is the limit there)
-    if (want && lanes >= 2) {
-      b->split = (lanes + 1) / 2;
-      HIPCHK(hipStreamCreateWithFlags(&b->s_det2, hipStreamNonBlocking));
-      for (auto& ev : b->ev_scan2) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
-  }
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_LEAD")) b->lead = std::min(8, std::max(3, std::atoi(e)));
-  HIPCHK(hipHostMalloc(&b->glue_flag, 64, hipHostMallocDefault));
-  std::memset(b->glue_flag, 0, 64);
-  {
-    int can = 0;
-    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, b->device);
-    const char* e = std::getenv("REBVIO_HIP_PRELAUNCH");
-    b->prelaunch_b = can != 0 && !(e && std::atoi(e) == 0);
-  }
+  if (const char* e = std::getenv("REBVIO_HIP_BATCH_DM_HEAD"))
+    b->dm_head_form = std::strcmp(e, "thread") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
   HIPCHK(hipDeviceSynchronize());
   guard.b = nullptr;
   *out = b;
@@ -2792,6 +2563,7 @@ rebvio_hip_ctx* rebvio_hip_batch_lane(rebvio_hip_batch* b, int lane) { return (l
 int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* frames_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
                                     int* keylines) {
   HIPCHK(hipSetDevice(b->device));
+  if (b->poisoned) return fail_msg("batch: an earlier step failed half way; the lanes are out of lock-step (destroy the batch)", -11);
   const int B = b->B;
   for (int l = 0; l < B; ++l) {
     if (out) {
@@ -2799,6 +2571,34 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
       out[l].status = -1;
     }
     if (keylines) keylines[l] = -1;
+  }
+  {
+    std::lock_guard<std::mutex> lk(b->det_mu);
+    if (!b->det_error.empty()) return fail_msg(b->det_error.c_str(), -8);
+  }
+  {
+    // lens models (rebvio_hip_set_undistort on a lane's context, camera.hpp:39-40,54-58): all lanes or none; a change is
+    // picked up here (set_undistort has synchronised the device)
+    int with = 0;
+    bool changed = false;
+    for (int l = 0; l < B; ++l) {
+      rebvio_hip_ctx* c = b->lane[l];
+      with += c->undist_map ? 1 : 0;
+      LaneStatic& L = b->ls_host[(size_t)l];
+      if (L.undist_map != c->undist_map || L.undist_img[0] != c->undist_img[0] || L.undist_img[1] != c->undist_img[1]) {
+        L.undist_map = c->undist_map;
+        L.undist_img[0] = c->undist_img[0];
+        L.undist_img[1] = c->undist_img[1];
+        changed = true;
+      }
+    }
+    if (with != 0 && with != B) return fail_msg("batch: set the lens model on every lane or on none", -3);
+    if (changed) {
+      while (b->det_done_steps.load(std::memory_order_acquire) < b->step) std::this_thread::yield();
+      HIPCHK(hipStreamSynchronize(b->st.s_det));
+      HIPCHK(hipMemcpy(b->ls_dev, b->ls_host.data(), b->ls_host.size() * sizeof(LaneStatic), hipMemcpyHostToDevice));
+    }
+    b->lens = with == B;
   }
   // ---- detect stage of this step (detect_launch for every lane at once) ----
   rebvio_hip_batch::Frame fr;
@@ -2809,15 +2609,20 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   rebvio_hip_map* last_reused = nullptr;
   for (int l = 0; l < B; ++l) {
     rebvio_hip_ctx* c = b->lane[l];
-    if (c->undist_map) return fail_msg("batch: the device front end (lens model) is not part of the batched path", -3);
     rebvio_hip_ctx::DetJob job;
     int rc = detect_prepare(c, frames_dev[l], 1, ts_us, &job);
-    if (rc) return rc;
-    rebvio_hip_map* m = job.m;
-    if (m->tab_idx < 0 || std::memcmp(&m->canon.pos, &m->d.pos, sizeof(void*)) != 0) {  // a map the pool has just grown by
-      rc = batch_upload_map_entry(b, l, m);
-      if (rc) return rc;
+    if (rc == 0) {
+      rebvio_hip_map* m = job.m;
+      if (m->tab_idx < 0 || std::memcmp(&m->canon.pos, &m->d.pos, sizeof(void*)) != 0)  // a map the pool has just grown by
+        rc = batch_upload_map_entry(b, l, m);
     }
+    if (rc) {
+      // lanes 0 .. l-1 have taken maps and advanced their servo rings for a step that will not run: the batch cannot
+      // continue in lock-step
+      if (l > 0) b->poisoned = true;
+      return rc;
+    }
+    rebvio_hip_map* m = job.m;
     // a pooled map comes back with whatever ping-pong state its last pair left: the detector writes the canonical arrays
     m->d = m->canon;
     fr.m[l] = m;
@@ -2834,10 +2639,6 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
     d.det_in = (unsigned char)(job.det_in - c->det);
     d.det_out = (unsigned char)(job.det_out - c->det);
   }
-  {
-    std::lock_guard<std::mutex> lk(b->det_mu);
-    if (!b->det_error.empty()) return fail_msg(b->det_error.c_str(), -8);
-  }
   rebvio_hip_batch::DetStep job;
   job.dyn = dyn;
   job.par = par;
@@ -2845,6 +2646,7 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   // maps are released in lane order at one point of the track stream: the last lane's event covers all of them
   job.reuse_done = (last_reused && last_reused->has_done) ? last_reused->done : nullptr;
   job.maps = fr.m;
+  job.lens = b->lens;
   for (auto* m : fr.m) m->enqueued.store(0, std::memory_order_relaxed);
   if (!b->det_thread.joinable()) b->det_thread = std::thread(batch_det_worker, b);
   {
@@ -2855,88 +2657,35 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   b->frames.push_back(fr);
   b->step++;
 
-  // ---- track stage. With the second half parked behind the flag: W + B of the pair in flight, then A of the next pair, are
-  // queued BEFORE the host waits for the pair in flight; then glue for every lane, then the flag. Otherwise B follows the glue.
-  const bool start_next = (int)b->frames.size() >= b->lead;
-  int rc_pre = 0;
-  b->cur_b_enqueued = false;
-  if (b->has_cur && b->prelaunch_b) rc_pre = batch_enqueue_b(b, true);
-  rebvio_hip_batch::Pair pp;
-  bool have_next = false;
-  auto enqueue_next = [&]() -> int {
-    pp.of = b->frames[0];
-    pp.nf = b->frames[1];
-    pp.slot = (int)(b->pair_seq % rebvio_hip_ctx::kSlots);
-    b->pair_seq++;
-    pp.R.resize((size_t)B);
-    pp.out.resize((size_t)B);
-    pp.frame_dt = (float)((double)(float)(pp.nf.m[0]->ts - pp.of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
-    int rc = batch_enqueue_a(b, pp);
-    if (rc) return rc;
-    b->frames.pop_front();
-    have_next = true;
-    return 0;
-  };
-  if (rc_pre == 0 && start_next && (!b->has_cur || b->prelaunch_b)) rc_pre = enqueue_next();
-  if (b->has_cur) {
-    const bool had_prev = b->has_prev;
-    int rc = batch_glue_current(b, out, keylines);  // (releases the flag on every path once the second half is parked)
-    if (rc) return rc;
-    (void)had_prev;
-    if (!b->prelaunch_b) {
-      rc = batch_enqueue_b(b, false);
-      if (rc) return rc;
+  // ---- track stage: the step's pairs, whole, for every lane; then whatever records have become complete ----
+  if ((int)b->frames.size() >= b->lead) {
+    const int rc = batch_enqueue_pair(b);
+    if (rc) {
+      b->poisoned = true;
+      return rc;
     }
-    b->prev = b->cur;
-    b->has_prev = true;
-    b->has_cur = false;
   }
-  if (rc_pre) return rc_pre;
-  if (!have_next && start_next && !b->prelaunch_b) {
-    int rc = enqueue_next();
-    if (rc) return rc;
-  }
-  if (have_next) {
-    for (int l = 0; l < B; ++l)
-      if (pp.of.m[l]->pre_rotated) pp.R[l] = prior_rotation(b->lane[l], nullptr);  // what the parked second half applies (bias as of now)
-    b->cur = pp;
-    b->has_cur = true;
-    b->cur_seq = (unsigned)b->pair_seq;  // never 0 (the idle value of the flag): pair_seq was incremented above
-  }
+  int rc = batch_harvest(b, 0);
+  if (rc) return rc;
+  (void)batch_pop(b, out, keylines);
   return 0;
 }
+
+int rebvio_hip_batch_next_records(rebvio_hip_batch* b, rebvio_hip_pair_out* out, int* keylines) { return batch_pop(b, out, keylines); }
 
 int rebvio_hip_batch_flush(rebvio_hip_batch* b) {
   HIPCHK(hipSetDevice(b->device));
   while (b->det_done_steps.load(std::memory_order_acquire) < b->step) std::this_thread::yield();
-  if (b->has_cur) {
-    b->cur_b_enqueued = false;
-    int rc = b->prelaunch_b ? batch_enqueue_b(b, true) : 0;
-    const int rc2 = batch_glue_current(b, nullptr, nullptr);  // releases the wait in every case
-    if (rc) return rc;
-    if (rc2) return rc2;
-    if (!b->prelaunch_b) {
-      rc = batch_enqueue_b(b, false);
-      if (rc) return rc;
-    }
-    b->prev = b->cur;
-    b->has_prev = true;
-    b->has_cur = false;
-  }
-  if (b->has_prev) {
-    for (size_t l = 0; l < b->prev.nf.m.size(); ++l) batch_release_map(b->prev.nf.m[l], l + 1 == b->prev.nf.m.size());
-    b->has_prev = false;
-  }
+  const int rc = batch_drain(b);
   for (auto& f : b->frames)
     for (size_t l = 0; l < f.m.size(); ++l) batch_release_map(f.m[l], l + 1 == f.m.size());
   b->frames.clear();
   for (auto* c : b->lane)  // as rebvio_hip_flush: no histogram counts of a pair that will not come
     HIPCHK(hipMemsetAsync(c->hist, 0, 128 * sizeof(int), b->st.s_trk));
   HIPCHK(hipStreamSynchronize(b->st.s_det));
-  if (b->s_det2) HIPCHK(hipStreamSynchronize(b->s_det2));
   HIPCHK(hipStreamSynchronize(b->st.s_key));
   HIPCHK(hipStreamSynchronize(b->st.s_trk));
-  return 0;
+  return rc;
 }
 
 }  // extern "C"

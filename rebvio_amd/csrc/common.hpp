@@ -143,14 +143,6 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
                         const int widths[2][3], int* rowcount_to_zero, int part = 3);
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
                      const DetState* det_in, DetState* det_out, const MapState* prev_st);
-// Distance-field build: LDS tiles (default) or the global-atomic scatter kernel (REBVIO_HIP_DF=scatter, kept as a reference).
-inline bool df_scatter_mode() {
-  static const bool v = [] {
-    const char* e = std::getenv("REBVIO_HIP_DF");
-    return e && std::string(e) == "scatter";
-  }();
-  return v;
-}
 // Tile grid of the keyline-driven distance-field build (shared by the binning pass in k_join_edges and the tile kernel).
 struct DfGrid {
   int T, ntx, nty;
@@ -163,15 +155,8 @@ inline DfGrid df_grid(int rows, int cols) {
   g.nty = (rows + g.T - 1) / g.T;
   return g;
 }
-inline bool df_tiles_mode() {  // REBVIO_HIP_DF=tiles: the mask-driven 32x32 tile kernel of round 1 (kept for A/B runs)
-  static const bool v = [] {
-    const char* e = std::getenv("REBVIO_HIP_DF");
-    return e && std::string(e) == "tiles";
-  }();
-  return v;
-}
-// mask_is_current: the map's dense mask describes its keylines (true right after detection, not after map_upload); the
-// tiled build finds the keylines through the mask, the scatter build (which needs a cleared field) through the arrays.
+// mask_is_current: the map is as detection left it (raster order, tile lists from k_join_edges): the tile kernel builds the
+// field; after rebvio_hip_map_upload the scatter kernel rebuilds it from the keyline arrays (it needs a cleared field).
 void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, bool mask_is_current);
 void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out);
 
@@ -201,33 +186,56 @@ struct GlueDev {
   int nan_v;         // rebvio.cpp:236: no matching / regularisation / depth update for this pair
   int has_next;      // RT_next valid
 };
+// Gyro-bias filter state of the glue (types/imu.hpp:180-183) plus the prior rotation the pair's first rotateKeylines applied.
+struct GlueState {
+  float Bg[3];
+  float W_Bg[9];
+  float R[9];
+  float pad;
+};
+
+// Everything the glue of one pair produces for the host (pinned record, read a few pairs later).
+struct GlueRec {
+  rebvio_hip_pair_out out;  // counters / status are filled in by the host from the map state records
+  GlueState gs;             // state AFTER this pair (the host mirrors it: rebvio_hip_get_gyro_state)
+};
+
+struct GlueParams {
+  float frame_dt;
+  float gyro_std_dev, gyro_bias_std_dev;
+};
+
+// Device glue of a pair, run in the prologue of the directedMatch head kernel (glue.hpp, track.hip: glue_prologue). lm == null:
+// no device glue - the kernel takes the second half's inputs from its arguments (per-pair API: the host ran the glue).
+struct GlueArgs {
+  const LmState* lm;       // final minimizeVel state of this pair (device memory)
+  const float* xrv;        // extRotVel block records of this pair (device memory, kXrvStride floats per record group)
+  const GlueState* st_in;  // filter state before this pair ...
+  GlueState* st_out;       // ... and after it (the other parity slot: late workgroups still read st_in)
+  GlueRec* rec;            // pinned host record of this pair
+  GlueDev* gd_copy;        // device copy of the second half's inputs for the kernels queued behind the head
+  GlueParams gp;
+};
 void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
                         float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero);
 void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm);
 // Persistent minimizeVel (+ forwardMatch + extRotVel when do_ext): one launch; the workgroups exchange their records
 // through `xch` ([2][record groups][kPartStride] 64-bit words {tag, value}). The caller passes tag_base = tags consumed so
-// far and advances it by calls + 1 per launch. Workgroup size 256 / 512 / 1024 threads (REBVIO_HIP_LM_THREADS).
-inline int lm_chain_threads() {
-  static const int t = [] {
-    const char* e = std::getenv("REBVIO_HIP_LM_THREADS");
-    const int v = e ? std::atoi(e) : 0;
-    return (v == 256 || v == 512 || v == 1024) ? v : 512;
-  }();
-  return t;
-}
-inline int lm_chain_grid(int kmax) { return (kmax + lm_chain_threads() - 1) / lm_chain_threads(); }
+// far and advances it by 2 * (calls + 1) per launch. threads = workgroup size 256 / 512 / 1024 (REBVIO_HIP_LM_THREADS, read when
+// the context is created; default 512).
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
                      LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
-                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps);
+                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps, int threads);
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
+// lanes whose persistent LM workgroups (512 threads, ceil(kmax / 512) per lane) the device holds resident at once
+int lm_chain_b_max_lanes(int device, int kmax, int calls);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
-                           const float* R0_on_the_fly);
-// the same two launches with vel / Rvel / Rback / R0 taken from memory at run time: the first kernel reads *g_pinned and
-// copies it to *g_dev, the second reads *g_dev
-void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* g_pinned,
-                               GlueDev* g_dev, float max_radius, int* work, int* work_n);
+                           const float* R0_on_the_fly, int head_form);
+// the same two launches with the pair's glue evaluated on the device in front of the head; the tail reads *ga.gd_copy
+void launch_directed_match_glue(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueArgs& ga,
+                                float max_radius, int* work, int* work_n, int head_form);
 void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* work_n_reset,
                                int* hist);
 // fused regularize1Iter + depth EKF: reads m.rs, writes m.rs_tmp (caller swaps the pointers); Rnext != null also
@@ -249,7 +257,8 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // A batched kernel is the single-stream kernel body run for lane = blockIdx.z; what differs between lanes comes from two
 // tables: LaneStatic (device memory, fixed for the life of the lane: its scratch buffers) and the lane's map table
 // (device memory, one MapDev per pooled edge map), plus a small by-value LaneDyn per launch (which maps, which ring slots).
-constexpr int kMaxLanes = 8;
+constexpr int kMaxLanes = 16;
+constexpr int kPairSlots = 8;  // result slots of the streaming / batch drivers: pairs in flight between the device and the host
 constexpr int kLaneMaps = 24;  // map-table entries per lane (the batch driver bounds its pool by this)
 struct LaneStatic {
   float* sa[2];   // scan buffer A per filter
@@ -267,15 +276,20 @@ struct LaneStatic {
   int* hist;
   int* dm_work;
   int* dm_work_n;
-  PairSlot* slot[4];
-  GlueDev* glue_host[4];
-  GlueDev* glue_dev;  // [4]
+  PairSlot* slot[kPairSlots];  // pinned: LM state + map state records of a pair, written by the LM kernel
+  GlueRec* rec[kPairSlots];    // pinned: what the device glue of a pair reports
+  GlueDev* glue_dev;           // [kPairSlots] second-half inputs left by the directedMatch head
+  GlueState* gstate;           // [2] gyro-bias filter state + prior rotation, by pair parity
+  float* xrv_part;             // extRotVel block records of the pair in flight
+  const int2* undist_map;      // the lane's lens model (fixed-point source coordinates), null without one
+  float* undist_img[2];        // x3 + undistorted fp32 frame by step parity
 };
 struct LaneDyn {
   const void* img;              // u8 frame of this step (device memory)
   short nm, om, prev;           // map-table indices: detected / new map, old map, previously detected map (-1: none)
   unsigned char nm_swap, om_swap;  // bit 0: rs <-> rs_tmp, bit 1: grad <-> grad_tmp relative to the table entry
   unsigned char parity, det_in, det_out, slot;
+  unsigned char gpar;           // parity slot of the glue state this pair reads (it writes the other one)
   unsigned tag_base;
 };
 struct LaneDynB {
@@ -296,13 +310,13 @@ __host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int l
   return m;
 }
 void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
-                          const int widths[2][3]);
+                          const int widths[2][3], bool lens);
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
                        int spec);
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
-                      float max_radius, int gate);
+                      float max_radius, int gate, int calls, const GlueParams& gp, int head_form);
 
 // Optional per-kernel timing with HIP events recorded on the launching stream (api.hip).
 void prof_begin(hipStream_t s, const char* name);

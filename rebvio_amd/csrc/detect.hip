@@ -261,8 +261,7 @@ __device__ __forceinline__ bool wave_chain_any(float* __restrict__ arr, int n4) 
 template <int MODE>  // 0: u8 image * 3.0f, 1: fp32 image, 2: box average (width d) of an integral image
 __device__ __forceinline__ void rowscan_body(const void* __restrict__ src0, const void* __restrict__ src1,
                                                  float* __restrict__ dst0, float* __restrict__ dst1, int R, int Cimg, int d0,
-                                                 int d1, int ldw_signed) {
-  const int ldw = abs(ldw_signed);  // (negative: the caller asks for the one-lane chain, REBVIO_HIP_ROWSCAN=lane)
+                                                 int d1, int ldw) {
   // C = row pitch of the integral images = the image width rounded up to a multiple of 4; the chain also runs over the
   // padding columns (they follow the image's columns, so the image's prefix values do not depend on them)
   const int C = (Cimg + 3) & ~3;
@@ -298,7 +297,7 @@ __device__ __forceinline__ void rowscan_body(const void* __restrict__ src0, cons
 #undef RH_RS_ST
   }
   __syncthreads();
-  const bool wide = ldw_signed > 0 && C4 <= 512;  // wave lr chains strip row lr in registers (wave_chain); else one lane per row below
+  const bool wide = C4 <= 512;  // wave lr chains strip row lr in registers (wave_chain); rows of more than 2048 columns: one lane per row below
   if (wide && rvalid) {
     if (MODE == 0)
       (void)wave_prefix_exact_any(tile + lr * ldw, C4);  // integer-valued sums: order free (see wave_prefix_exact)
@@ -378,10 +377,13 @@ __global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict_
                                                    int d0, int d1, int ldw) {
   const int lane = lane0 + blockIdx.z;
   const LaneStatic& L = ls[lane];
-  const void* s0 = stage == 0 ? dyn.v[lane].img : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[0]);
-  const void* s1 = stage == 0 ? s0 : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[1]);
+  // stage 0: first pass on the lane's u8 frame; 3: first pass on the fp32 frame its front end left (lens model set)
+  const bool first = stage == 0 || stage == 3;
+  const void* s0 = stage == 0 ? dyn.v[lane].img
+                              : (stage == 3 ? (const void*)L.undist_img[dyn.v[lane].parity] : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[0]));
+  const void* s1 = first ? s0 : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[1]);
   float* o0 = stage == 1 ? L.sb[0] : L.sa[0];
-  float* o1 = stage == 0 ? L.sa[0] : (stage == 1 ? L.sb[1] : L.sa[1]);
+  float* o1 = first ? L.sa[0] : (stage == 1 ? L.sb[1] : L.sa[1]);
   rowscan_body<MODE>(s0, s1, o0, o1, R, Cimg, d0, d1, ldw);
 }
 
@@ -497,67 +499,6 @@ __device__ __forceinline__ void colscan_body(float* __restrict__ buf0, float* __
   }
 }
 
-// Column accumulation with the chain on whole waves (wave_chain): a workgroup of COLS waves owns COLS columns (COLS / 4
-// 16-byte chunks per row), stages them transposed in LDS (tile[col][row]) exactly as colscan_body does and wave w runs
-// column w. For images of at most 2048 rows. COLS = 16: 1024 threads, the strip geometry of colscan_body with four times
-// the loads in flight per workgroup; COLS = 4: 256 threads and one chunk per row (more workgroups, 16-byte rows).
-template <int COLS>
-__device__ __forceinline__ void colscanw_body(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh) {
-  constexpr int Q = COLS / 4;  // chunks per strip row
-  extern __shared__ float4 smem4[];
-  float* tile = reinterpret_cast<float*>(smem4);  // [COLS][ldh]
-  float* __restrict__ buf = blockIdx.y ? buf1 : buf0;
-  const int c0 = blockIdx.x * COLS;
-  const int ncols = min(COLS, C - c0);  // multiple of 4
-  const int t = (int)threadIdx.x;
-  const int c4 = t & (Q - 1);
-  const bool cvalid = c4 * 4 < ncols;
-  const int rb = t / Q;  // 256 rows per pass
-  float* g = buf + c0 + min(c4 * 4, ncols - 4);
-  for (int base = 0; base < R; base += 512) {
-#define RH_CW_LD(k) *reinterpret_cast<const float4*>(g + (size_t)min(base + (k) * 256 + rb, R - 1) * C)
-    const float4 v0 = RH_CW_LD(0), v1 = RH_CW_LD(1);
-#undef RH_CW_LD
-    __builtin_amdgcn_sched_barrier(0);  // both loads are in flight before the first LDS write
-#define RH_CW_ST(k, v)                            \
-    {                                             \
-      const int r = base + (k) * 256 + rb;        \
-      if (r < R && cvalid) {                      \
-        float* tp = tile + (c4 * 4) * ldh + r;    \
-        tp[0] = v.x;                              \
-        tp[ldh] = v.y;                            \
-        tp[2 * ldh] = v.z;                        \
-        tp[3 * ldh] = v.w;                        \
-      }                                           \
-    }
-    RH_CW_ST(0, v0) RH_CW_ST(1, v1)
-#undef RH_CW_ST
-  }
-  __syncthreads();
-  if ((t >> 6) < ncols) {
-    float* colp = tile + (t >> 6) * ldh;
-    const int R4 = R >> 2;
-    (void)wave_chain_any(colp, R4);
-    if ((R & 3) && (t & 63) == 0) {  // rows % 4 tail (the wave's own LDS writes above are visible to it in program order)
-      float sacc = colp[R4 * 4 - 1];
-      for (int r = R4 * 4; r < R; ++r) {
-        sacc = sacc + colp[r];
-        colp[r] = sacc;
-      }
-    }
-  }
-  __syncthreads();
-  if (cvalid)
-    for (int r = rb; r < R; r += 256) {
-      const float* tp = tile + (c4 * 4) * ldh + r;
-      *reinterpret_cast<float4*>(g + (size_t)r * C) = make_float4(tp[0], tp[ldh], tp[2 * ldh], tp[3 * ldh]);
-    }
-}
-template <int COLS>
-__global__ __launch_bounds__(COLS * 64) void k_colscanw(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
-  colscanw_body<COLS>(buf0, buf1, R, C, ldh);
-}
-
 __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
   colscan_body(buf0, buf1, R, C, ldh);
 }
@@ -565,11 +506,6 @@ __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float
 __global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh) {
   const LaneStatic& L = ls[lane0 + blockIdx.z];
   colscan_body(which == 1 ? L.sb[0] : L.sa[0], which == 0 ? L.sa[0] : (which == 1 ? L.sb[1] : L.sa[1]), R, C, ldh);
-}
-template <int COLS>
-__global__ __launch_bounds__(COLS * 64) void k_colscanw_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh) {
-  const LaneStatic& L = ls[lane0 + blockIdx.z];
-  colscanw_body<COLS>(which == 1 ? L.sb[0] : L.sa[0], which == 0 ? L.sa[0] : (which == 1 ? L.sb[1] : L.sa[1]), R, C, ldh);
 }
 
 // ---- last box pass of both filters fused with DoG and squared gradient (scale_space.cpp:210-233) ------
@@ -981,173 +917,6 @@ __global__ __launch_bounds__(256) void k_df_build(KParams p, MapDev m, const Det
   }
 }
 
-// ---- DistanceField::build, tiled (core.hpp:37-59) ----------------------------------------------------------------
-// Same field, no global atomics: a workgroup owns a 64x64 tile of the field in LDS. It scans the dense keyline mask of
-// the tile grown by the reach of a keyline (nr/2 + 1 pixels) in chunks of <= kDfChunk pixels, compacts the keylines it
-// finds into an LDS list (id, position, unit gradient - the divisions are done once per keyline), drops those whose
-// probe segment cannot touch the tile, and lets its threads walk the (keyline, r) pairs of the list with LDS atomicMin
-// on the same key as k_df_build. The finished tile is written with coalesced stores, empty cells included, so the
-// field needs no clearing pass. HBM traffic: mask reads of the grown tiles (L2 hits after the first tile row) + one
-// 4-byte store per cell, instead of one memory-side atomic per (keyline, r).
-constexpr int kDfChunk = 2048;  // work-list capacity = pixels per chunk of the fallback scan
-constexpr int kDfHits = 4096;   // hit-list capacity of the one-pass scan
-constexpr int kDfThreads = 512;
-
-template <int kDfTile>
-__global__ __launch_bounds__(kDfThreads) void k_df_tiles(KParams p, MapDev m, const DetState* __restrict__ det_prev) {
-  __shared__ unsigned tile[kDfTile * kDfTile];
-  __shared__ int l_idx[kDfChunk];
-  __shared__ float4 l_geo[kDfChunk];  // pos.x, pos.y, g.x/gn, g.y/gn
-  __shared__ int2 l_rr[kDfChunk];     // range of r that can reach the tile
-  __shared__ int l_hits[kDfHits];
-  __shared__ int l_n, l_nh;
-  const int tid = threadIdx.x, lane = threadIdx.x & 63;
-  const int n = m.st->n;
-  const float thr = auto_threshold_from(*m.st, det_prev->auto_threshold);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
-  const int nr = p.df_nr, half = nr >> 1;
-  const int x0 = blockIdx.x * kDfTile, y0 = blockIdx.y * kDfTile;
-  const int x1 = min(x0 + kDfTile, p.cols), y1 = min(y0 + kDfTile, p.rows);
-  for (int i = tid; i < kDfTile * kDfTile; i += kDfThreads) tile[i] = kDfEmpty;
-  const int reach = half + 1;
-  const int ex0 = max(x0 - reach, 0), ex1 = min(x1 + reach, p.cols);
-  const int ey0 = max(y0 - reach, 0), ey1 = min(y1 + reach, p.rows);
-  const int ew = ex1 - ex0;
-  const float inv_ew = 1.0f / (float)ew;
-  const float fx0 = (float)x0 - 1.0f, fx1 = (float)x1, fy0 = (float)y0 - 1.0f, fy1 = (float)y1;
-  // First try: the whole grown tile in one pass (its keylines that survive the reach test almost always fit the list);
-  // if they do not, nothing has touched the tile yet and the scan is redone in chunks of <= kDfChunk pixels.
-  int rows_per_chunk = ey1 - ey0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    bool overflow = false;
-    for (int cy = ey0; cy < ey1 && !overflow; cy += rows_per_chunk) {
-      if (tid == 0) {
-        l_n = 0;
-        l_nh = 0;
-      }
-      __syncthreads();
-      const int ch = min(rows_per_chunk, ey1 - cy);
-      const int px_total = ch * ew;
-      // (a) mask scan, eight independent loads per thread and trip; the keyline ids go to the hit list
-      for (int i0 = 0; i0 < px_total; i0 += kDfThreads * 8) {
-        int ids[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = i0 + j * kDfThreads + tid;
-          int id = -1;
-          if (i < px_total) {
-            // row = floor(i / ew) without an integer division: (i + 0.5) / ew is at least 0.5 / ew away from an integer,
-            // far more than the rounding error of the fp32 product for i < 2^16
-            const int ry = (int)(((float)i + 0.5f) * inv_ew), rx = i - ry * ew;
-            id = m.mask[(size_t)(cy + ry) * p.cols + ex0 + rx];
-          }
-          ids[j] = id;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {  // wave-aggregated append: one LDS atomic per wave and slot j
-          const bool hit = ids[j] >= 0 && ids[j] < n;
-          const unsigned long long hm = __ballot(hit);
-          if (hm) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&l_nh, __popcll(hm));
-            base = __shfl(base, 0);
-            const int slot = base + __popcll(hm & ((1ull << lane) - 1ull));
-            if (hit && slot < kDfHits) l_hits[slot] = ids[j];
-          }
-        }
-      }
-      __syncthreads();
-      const int nh = l_nh;
-      if (nh > kDfHits) {
-        overflow = true;
-      } else {
-        // (b) geometry of the hits (one gather round trip), reach test, compaction into the work list
-        for (int h0 = 0; h0 < nh; h0 += kDfThreads) {
-          const int h = h0 + tid;
-          bool keep = false;
-          int id = 0, r_lo = 0, r_hi = -1;
-          float2 pos = make_float2(0.f, 0.f);
-          float ux = 0.f, uy = 0.f;
-          if (h < nh) {
-            id = l_hits[h];
-            const float gn = m.gnorm[id];
-            const float2 g = m.grad[id];
-            pos = m.pos[id];
-            if (!(thr > 0.0f && gn < thr)) {
-              ux = g.x / gn;
-              uy = g.y / gn;
-              // range of r whose cell can lie inside the tile (one pixel of slack on each side for the rounding; the
-              // exact in-tile test per cell stays): intersect the x and the y constraint with [-half, half)
-              float lo = -(float)half, hi = (float)(half - 1);
-              if (fabsf(ux) > 1e-6f) {
-                const float a = (fx0 - pos.x) / ux, b = (fx1 - pos.x) / ux;
-                lo = fmaxf(lo, fminf(a, b));
-                hi = fminf(hi, fmaxf(a, b));
-              } else if (pos.x < fx0 || pos.x > fx1) {
-                hi = lo - 1.0f;
-              }
-              if (fabsf(uy) > 1e-6f) {
-                const float a = (fy0 - pos.y) / uy, b = (fy1 - pos.y) / uy;
-                lo = fmaxf(lo, fminf(a, b));
-                hi = fminf(hi, fmaxf(a, b));
-              } else if (pos.y < fy0 || pos.y > fy1) {
-                hi = lo - 1.0f;
-              }
-              r_lo = (int)floorf(lo) - 1;
-              r_hi = (int)ceilf(hi) + 1;
-              r_lo = max(r_lo, -half);
-              r_hi = min(r_hi, half - 1);
-              keep = hi >= lo && r_hi >= r_lo;
-            }
-          }
-          const unsigned long long km = __ballot(keep);
-          if (km) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&l_n, __popcll(km));
-            base = __shfl(base, 0);
-            const int slot = base + __popcll(km & ((1ull << lane) - 1ull));
-            if (keep && slot < kDfChunk) {
-              l_idx[slot] = id;
-              l_geo[slot] = make_float4(pos.x, pos.y, ux, uy);
-              l_rr[slot] = make_int2(r_lo, r_hi);
-            }
-          }
-        }
-        __syncthreads();
-        const int ln = l_n;
-        if (ln > kDfChunk) {
-          overflow = true;
-        } else {
-          // (c) the (keyline, r) pairs of the list: a wave per keyline, its lanes over r
-          for (int k = tid >> 6; k < ln; k += kDfThreads / 64) {
-            const float4 q = l_geo[k];
-            const int2 rr = l_rr[k];
-            const unsigned seq0 = (unsigned)(l_idx[k] * nr);
-            for (int r = rr.x + lane; r <= rr.y; r += 64) {
-              const int ri = r + half;
-              const float fr = q.w * float(r) + q.y;
-              const float fc = q.z * float(r) + q.x;
-              const int row = cvtt_f32(roundf(fr));
-              const int col = cvtt_f32(roundf(fc));
-              if (row < y0 || row >= y1 || col < x0 || col >= x1) continue;
-              const unsigned key = ((unsigned)abs(r) << kDfSeqBits) | (kDfSeqMask - (seq0 + (unsigned)ri));
-              atomicMin(&tile[(row - y0) * kDfTile + (col - x0)], key);
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-    if (!overflow) break;
-    rows_per_chunk = max(1, kDfChunk / ew);  // a chunk of <= kDfChunk pixels cannot overflow either list
-  }
-  const int tw = x1 - x0;
-  for (int i = tid; i < kDfTile * kDfTile; i += kDfThreads) {
-    const int ty = i / kDfTile, tx = i - ty * kDfTile;
-    if (tx < tw && y0 + ty < y1) m.df[(size_t)(y0 + ty) * p.cols + x0 + tx] = tile[i];
-  }
-}
-
 // ---- DistanceField::build, keyline driven (core.hpp:37-59) ----------------------------------------------------------
 // The keylines of a detected map are in raster order (their index IS the raster rank, edge_detector.cpp:109-113) and a
 // keyline detected in pixel row r only reaches field rows r-41 .. r+41 (unit gradient, 40 steps, sub-pixel offset <= 0.5).
@@ -1174,7 +943,7 @@ constexpr int kDfsList = 1024;  // candidates staged per chunk (24 KB)
 constexpr int kDfsSub = 16;     // lanes that walk one keyline's r-range (four keylines per wave)
 
 // Field cells [y0, y1) x [x0, x1) from the row range: every keyline detected in the rows that can reach the box is a
-// candidate. Used by the strip kernel (REBVIO_HIP_DF_STRIP, A/B) and by the tile kernel for a tile whose list overflowed.
+// candidate. Used by the tile kernel for a tile whose list overflowed.
 // df_smem: S * W cells, then the staging list (kDfsList entries of 24 bytes).
 __device__ __forceinline__ void df_rowrange_body(const KParams& p, const MapDev& m, float thr, int n, int S, int W, int x0, int x1, int y0,
                                                  int y1, unsigned* df_smem, int* l_n_ptr RH_DFS_STAMP_ARG) {
@@ -1257,18 +1026,6 @@ __device__ __forceinline__ void df_rowrange_body(const KParams& p, const MapDev&
     }
   }
   RH_DFS_STAMP(stamp_i++);
-}
-
-__global__ __launch_bounds__(kDfsThreads) void k_df_strips(KParams p, MapDev m, const DetState* __restrict__ det_prev, int S, int W RH_DFS_STAMP_ARG) {
-  extern __shared__ __align__(16) unsigned df_smem[];
-  __shared__ int l_n;
-  const int tid = threadIdx.x;
-  RH_DFS_STAMP(0);
-  const int n = m.st->n;
-  const float thr = auto_threshold_from(*m.st, det_prev->auto_threshold);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
-  const int y0 = blockIdx.y * S, x0 = blockIdx.x * W;
-  df_rowrange_body(p, m, thr, n, S, W, x0, min(x0 + W, p.cols), y0, min(y0 + S, p.rows), df_smem, &l_n RH_DFS_STAMP_FWD);
 }
 
 // ---- DistanceField::build, one workgroup per T x T tile fed by the tile's list (the default) --------------------------------
@@ -1438,40 +1195,12 @@ static int lds_pitch(int cols) {
   if (((cols + pad) / 4) % 2 == 0) pad = 8;
   return cols + pad;
 }
-static bool rowscan_lane_chain() {  // REBVIO_HIP_ROWSCAN=lane: one lane per row walks the LDS row (A/B against wave_chain)
-  static const bool on = [] {
-    const char* e = std::getenv("REBVIO_HIP_ROWSCAN");
-    return e && std::strcmp(e, "lane") == 0;
-  }();
-  return on;
-}
-// column pass: 16-column strips with one lane per column (k_colscan). REBVIO_HIP_COLSCAN = w16 | w8 | w4 selects the form with
-// the chain on whole waves (that many columns per workgroup, up to 2048 rows) for A/B. Measured at 640x480 (rocprofv3, mean
-// of 3672 launches): lane 9.2 us, w16 10.4, w8 10.6, w4 12.0 - unlike the row pass (13.5 -> 11.4 us with wave_chain) the
-// column pass is bound by its transposing strip loads, not by the chain, and 16 waves per strip only add to that.
-static int colscan_waves(int R) {
-  static const int sel = [] {
-    const char* e = std::getenv("REBVIO_HIP_COLSCAN");
-    if (!e) return 0;
-    if (std::strcmp(e, "w4") == 0) return 4;
-    if (std::strcmp(e, "w8") == 0) return 8;
-    if (std::strcmp(e, "w16") == 0) return 16;
-    return 0;
-  }();
-  if (sel == 0) return 0;
-  if (R > 2048) return 0;
-  int cw = sel;
-  const int ldh = lds_pitch(R + (4 - R % 4) % 4);
-  while (cw > 4 && (size_t)cw * ldh * sizeof(float) > 60 * 1024) cw >>= 1;  // the strip stays inside the default 64 KB of LDS
-  return cw;
-}
-
 // ---- front end: convertTo(CV_32F, 3.0) + cv::undistort as one gather kernel (rebvio.cpp:43-47) -------
 // map = fixed-point source coordinates (1/32 px, hostmath.hpp undistort_fixed_map). Weights (1-a)(1-b) .. with a, b
 // multiples of 1/32 and 8-bit*3 sources make every product and the 4-term sum exact in fp32, so the result does not
 // depend on evaluation order; taps outside the image read the constant border 0 (BORDER_CONSTANT).
-__global__ __launch_bounds__(256) void k_front_end_u8(const uint8_t* __restrict__ src, const int2* __restrict__ map,
-                                                        float* __restrict__ dst, int rows, int cols) {
+__device__ __forceinline__ void front_end_body(const uint8_t* __restrict__ src, const int2* __restrict__ map, float* __restrict__ dst,
+                                               int rows, int cols) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * cols) return;
   const int2 m = map[i];
@@ -1488,6 +1217,16 @@ __global__ __launch_bounds__(256) void k_front_end_u8(const uint8_t* __restrict_
   const float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax, w10 = ay * (1.0f - ax), w11 = ay * ax;
   dst[i] = s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11;
 }
+__global__ __launch_bounds__(256) void k_front_end_u8(const uint8_t* __restrict__ src, const int2* __restrict__ map,
+                                                        float* __restrict__ dst, int rows, int cols) {
+  front_end_body(src, map, dst, rows, cols);
+}
+// batched form (lane = blockIdx.z): every lane gathers through ITS lens model into its own fp32 frame of this step's parity
+__global__ __launch_bounds__(256) void k_front_end_u8_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int lane0, int rows, int cols) {
+  const int lane = lane0 + blockIdx.z;
+  const LaneStatic& L = ls[lane];
+  front_end_body(static_cast<const uint8_t*>(dyn.v[lane].img), L.undist_map, L.undist_img[dyn.v[lane].parity], rows, cols);
+}
 
 void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, const int2* map, float* dst) {
   RH_LAUNCH(k_front_end_u8, dim3(div_up(p.rows * p.cols, 256)), dim3(256), 0, s, src, map, dst, p.rows, p.cols);
@@ -1501,7 +1240,7 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
   const int Cp = (C + 3) & ~3;  // pitch of the scan buffers sb.a / sb.b
   const int ldw_abs = lds_pitch(Cp);
   const size_t shm = (size_t)kStrip * ldw_abs * sizeof(float);
-  const int ldw = rowscan_lane_chain() ? -ldw_abs : ldw_abs;
+  const int ldw = ldw_abs;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1514,20 +1253,7 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
   const dim3 c1(div_up(Cp, kColStrip), 1), c2(div_up(Cp, kColStrip), 2);
   const int ldh = lds_pitch(R + (4 - R % 4) % 4);
   const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
-  const int cw = colscan_waves(R);
-  const size_t wshm = (size_t)ldh * (cw ? cw : 4) * sizeof(float);
-#define RH_COLSCAN(one, b0, b1)                                                                                          \
-  do {                                                                                                                   \
-    const dim3 wg(div_up(Cp, cw ? cw : 4), (one) ? 1 : 2);                                                               \
-    if (cw == 16)                                                                                                        \
-      RH_LAUNCH(k_colscanw<16>, wg, dim3(1024), wshm, s, b0, b1, R, Cp, ldh);                                            \
-    else if (cw == 8)                                                                                                    \
-      RH_LAUNCH(k_colscanw<8>, wg, dim3(512), wshm, s, b0, b1, R, Cp, ldh);                                              \
-    else if (cw == 4)                                                                                                    \
-      RH_LAUNCH(k_colscanw<4>, wg, dim3(256), wshm, s, b0, b1, R, Cp, ldh);                                              \
-    else                                                                                                                 \
-      RH_LAUNCH(k_colscan, (one) ? c1 : c2, dim3(256), cshm, s, b0, b1, R, Cp, ldh);                                     \
-  } while (0)
+#define RH_COLSCAN(one, b0, b1) RH_LAUNCH(k_colscan, (one) ? c1 : c2, dim3(256), cshm, s, b0, b1, R, Cp, ldh)
   if (part & 1) {
     // pass 1: both filters share the integral image of the input (scale_space.cpp:175)
     if (img_is_u8)
@@ -1554,17 +1280,18 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
 
 // ---- batched launchers (lane = blockIdx.z): the same grids with a third dimension ------------------------------------------
 void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
-                          const int widths[2][3]) {
+                          const int widths[2][3], bool lens) {
   const int R = p.rows, C = p.cols;
   const int Cp = (C + 3) & ~3;
   const int ldw_abs = lds_pitch(Cp);
   const size_t shm = (size_t)kStrip * ldw_abs * sizeof(float);
-  const int ldw = rowscan_lane_chain() ? -ldw_abs : ldw_abs;
+  const int ldw = ldw_abs;
   const int ldh = lds_pitch(R + (4 - R % 4) % 4);
   const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan_b<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan_b<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan_b<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colscan_b), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
@@ -1572,21 +1299,13 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
   const unsigned z = (unsigned)lanes;
   const dim3 g1(div_up(R, kStrip), 1, z), g2(div_up(R, kStrip), 2, z);
   const dim3 c1(div_up(Cp, kColStrip), 1, z), c2(div_up(Cp, kColStrip), 2, z);
-  const int cw = colscan_waves(R);
-  const size_t wshm = (size_t)ldh * (cw ? cw : 4) * sizeof(float);
-#define RH_COLSCAN_B(which)                                                                              \
-  do {                                                                                                   \
-    const dim3 wg(div_up(Cp, cw ? cw : 4), (which) == 0 ? 1 : 2, z);                                     \
-    if (cw == 16)                                                                                        \
-      RH_LAUNCH(k_colscanw_b<16>, wg, dim3(1024), wshm, s, ls, lane0, which, R, Cp, ldh);                \
-    else if (cw == 8)                                                                                    \
-      RH_LAUNCH(k_colscanw_b<8>, wg, dim3(512), wshm, s, ls, lane0, which, R, Cp, ldh);                  \
-    else if (cw == 4)                                                                                    \
-      RH_LAUNCH(k_colscanw_b<4>, wg, dim3(256), wshm, s, ls, lane0, which, R, Cp, ldh);                  \
-    else                                                                                                 \
-      RH_LAUNCH(k_colscan_b, (which) == 0 ? c1 : c2, dim3(256), cshm, s, ls, lane0, which, R, Cp, ldh);  \
-  } while (0)
-  RH_LAUNCH(k_rowscan_b<0>, g1, dim3(256), shm, s, ls, dyn, lane0, 0, R, C, 0, 0, ldw);
+#define RH_COLSCAN_B(which) RH_LAUNCH(k_colscan_b, (which) == 0 ? c1 : c2, dim3(256), cshm, s, ls, lane0, which, R, Cp, ldh)
+  if (lens) {  // x3 + undistort of every lane's frame (rebvio.cpp:43-47), then the first pass on the fp32 result
+    RH_LAUNCH(k_front_end_u8_b, dim3(div_up(R * C, 256), 1, z), dim3(256), 0, s, ls, dyn, lane0, R, C);
+    RH_LAUNCH(k_rowscan_b<1>, g1, dim3(256), shm, s, ls, dyn, lane0, 3, R, C, 0, 0, ldw);
+  } else {
+    RH_LAUNCH(k_rowscan_b<0>, g1, dim3(256), shm, s, ls, dyn, lane0, 0, R, C, 0, 0, ldw);
+  }
   RH_COLSCAN_B(0);
   RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 1, R, C, widths[0][0], widths[1][0], ldw);
   RH_COLSCAN_B(1);
@@ -1636,60 +1355,37 @@ void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const
   RH_LAUNCH(k_keyline_flag, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in,
                      db.stash, db.bits, db.rowcount);
   RH_LAUNCH(k_keyline_emit, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash,
-                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st, df_scatter_mode() ? 1 : 0, dg.ntx * dg.nty);
+                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st, 0, dg.ntx * dg.nty);
   RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, m, dg.T, dg.ntx, dg.nty);
 }
 
 void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, bool mask_is_current) {
-  const long long threads = (long long)p.kmax * p.df_nr;
-  // measured (MI355X, 640x480 pipeline): 16 workgroups -> 316 us/frame (the field itself becomes the bottleneck), 32 -> 172, 64..128 -> 132, 512 -> 156, 2048 -> 162: the kernel is bound by
-  // the memory-side atomic rate and a larger grid only takes CUs and memory queues from the latency-critical streams
-  if (mask_is_current && !df_scatter_mode() && !df_tiles_mode()) {
-    // default: one workgroup per tile of df_grid, fed by the per-tile keyline lists k_join_edges left with the map.
-    // REBVIO_HIP_DF_STRIP="S,XB" (A/B): strips of S rows x cols/XB columns fed by the raster-ordered row range instead.
-    static int envS = 0, envXB = 0;
-    static const bool parsed = [] {
-      if (const char* e = std::getenv("REBVIO_HIP_DF_STRIP")) std::sscanf(e, "%d,%d", &envS, &envXB);
-      return true;
-    }();
-    (void)parsed;
+  if (mask_is_current) {
+    // detection path: one workgroup per tile of df_grid, fed by the per-tile keyline lists k_join_edges left with the map
     const DfGrid dg = df_grid(p.rows, p.cols);
     const size_t list_bytes = (size_t)kDfsList * (sizeof(float4) + 2 * sizeof(int));  // (>= kDfTileCap entries of 32 bytes)
-    static size_t attr_shm[3] = {0, 0, 0};
+    static size_t attr_shm[2] = {0, 0};
     auto want = [](const void* f, size_t shm, size_t* have) {  // (the kernels also have static LDS: ask for what is needed)
       if (shm > *have) {
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) (void)hipGetLastError();
         *have = shm;
       }
     };
-    if (envS <= 0) {
-      const size_t shm = (((size_t)dg.T * (dg.T + 1) + 3) & ~(size_t)3) * sizeof(unsigned) + list_bytes;
-      if (dg.T == 32) {
-        want(reinterpret_cast<const void*>(&k_df_lists<32>), shm, &attr_shm[0]);
-        RH_LAUNCH(k_df_lists<32>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
-      } else {  // (cols <= 4096 and rows <= 2548 keep 64-pixel tiles below kDfMaxTiles)
-        want(reinterpret_cast<const void*>(&k_df_lists<64>), shm, &attr_shm[1]);
-        RH_LAUNCH(k_df_lists<64>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
-      }
-      return;
+    const size_t shm = (((size_t)dg.T * (dg.T + 1) + 3) & ~(size_t)3) * sizeof(unsigned) + list_bytes;
+    if (dg.T == 32) {
+      want(reinterpret_cast<const void*>(&k_df_lists<32>), shm, &attr_shm[0]);
+      RH_LAUNCH(k_df_lists<32>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
+    } else {  // (cols <= 4096 and rows <= 2548 keep 64-pixel tiles below kDfMaxTiles)
+      want(reinterpret_cast<const void*>(&k_df_lists<64>), shm, &attr_shm[1]);
+      RH_LAUNCH(k_df_lists<64>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
     }
-    int W = ((div_up(p.cols, envXB > 0 ? envXB : 1) + 3) / 4) * 4, S = envS;
-    while (S > 1 && (size_t)S * W * sizeof(unsigned) > 32 * 1024) S >>= 1;
-    const size_t shm = (size_t)S * W * sizeof(unsigned) + list_bytes;
-    want(reinterpret_cast<const void*>(&k_df_strips), shm, &attr_shm[2]);
-    RH_LAUNCH(k_df_strips, dim3(div_up(p.cols, W), div_up(p.rows, S)), dim3(kDfsThreads), shm, s, p, m, det_prev, S, W RH_DFS_STAMP_PASS);
     return;
   }
-  if (mask_is_current && !df_scatter_mode()) {  // REBVIO_HIP_DF=tiles: LDS tiles driven by the dense keyline mask
-    static const int kTile = (std::getenv("REBVIO_HIP_DF_TILE") && std::atoi(std::getenv("REBVIO_HIP_DF_TILE")) == 64) ? 64 : 32;
-    if (kTile == 64)
-      RH_LAUNCH(k_df_tiles<64>, dim3(div_up(p.cols, 64), div_up(p.rows, 64)), dim3(kDfThreads), 0, s, p, m, det_prev);
-    else
-      RH_LAUNCH(k_df_tiles<32>, dim3(div_up(p.cols, 32), div_up(p.rows, 32)), dim3(kDfThreads), 0, s, p, m, det_prev);
-    return;
-  }
-  static const int kDfBlocks = std::getenv("REBVIO_HIP_DF_BLOCKS") ? std::max(1, std::atoi(std::getenv("REBVIO_HIP_DF_BLOCKS"))) : 128;
-  const unsigned blocks = (unsigned)std::min<long long>((threads + 255) / 256, kDfBlocks);
+  // rebuild after rebvio_hip_map_upload (arbitrary keylines, no raster order, no tile lists): global-atomic scatter into a
+  // cleared field. Measured (MI355X, 640x480): 16 workgroups -> 316 us, 32 -> 172, 64..128 -> 132, 512 -> 156: bound by the
+  // memory-side atomic rate, a larger grid only takes CUs and memory queues from the latency-critical streams
+  const long long threads = (long long)p.kmax * p.df_nr;
+  const unsigned blocks = (unsigned)std::min<long long>((threads + 255) / 256, 128);
   RH_LAUNCH(k_df_build, dim3(blocks), dim3(256), 0, s, p, m, det_prev);
 }
 

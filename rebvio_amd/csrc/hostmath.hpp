@@ -11,6 +11,16 @@
 #include <cstring>
 #include <limits>
 
+// The 3x3 / 6x6 functions below also run on the device (the streaming and batch drivers keep the glue of a pair on the GPU,
+// glue.hpp): one source, the same operation order on both sides. RH_HD is empty for plain C++ translation units
+// (rebvio_amd/host/rebvio.cpp uses cholesky6_inverse).
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RH_HD __host__ __device__
+#else
+#define RH_HD
+#endif
+
 namespace rh {
 namespace hm {
 
@@ -18,25 +28,29 @@ struct M3 {
   float a[3][3];
 };
 
-inline M3 identity3() {
+RH_HD inline M3 identity3() {
   M3 r;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) r.a[i][j] = (i == j) ? 1.0f : 0.0f;
   return r;
 }
-inline M3 load3(const float* p) {
+RH_HD inline M3 load3(const float* p) {
   M3 r;
-  std::memcpy(r.a, p, sizeof(r.a));
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.a[i][j] = p[i * 3 + j];
   return r;
 }
-inline void store3(const M3& m, float* p) { std::memcpy(p, m.a, sizeof(m.a)); }
-inline M3 transpose(const M3& m) {
+RH_HD inline void store3(const M3& m, float* p) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) p[i * 3 + j] = m.a[i][j];
+}
+RH_HD inline M3 transpose(const M3& m) {
   M3 r;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) r.a[i][j] = m.a[j][i];
   return r;
 }
-inline M3 mul(const M3& x, const M3& y) {
+RH_HD inline M3 mul(const M3& x, const M3& y) {
   M3 r;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
@@ -46,7 +60,7 @@ inline M3 mul(const M3& x, const M3& y) {
     }
   return r;
 }
-inline void mulv(const M3& m, const float v[3], float out[3]) {
+RH_HD inline void mulv(const M3& m, const float v[3], float out[3]) {
   float t[3];
   for (int i = 0; i < 3; ++i) {
     float s = 0;
@@ -55,27 +69,28 @@ inline void mulv(const M3& m, const float v[3], float out[3]) {
   }
   out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
 }
-inline M3 add(const M3& x, const M3& y) {
+RH_HD inline M3 add(const M3& x, const M3& y) {
   M3 r;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) r.a[i][j] = x.a[i][j] + y.a[i][j];
   return r;
 }
-inline M3 sub(const M3& x, const M3& y) {
+RH_HD inline M3 sub(const M3& x, const M3& y) {
   M3 r;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) r.a[i][j] = x.a[i][j] - y.a[i][j];
   return r;
 }
-inline M3 diag3(float v) {
+RH_HD inline M3 diag3(float v) {
   M3 r = identity3();
   for (int i = 0; i < 3; ++i) r.a[i][i] = v;
   return r;
 }
 
-inline float det3(const M3& m) {
+RH_HD inline float det3(const M3& m) {
   float A[3][3];
-  std::memcpy(A, m.a, sizeof(A));
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) A[i][j] = m.a[i][j];
   float det = 1;
   for (int i = 0; i < 3; ++i) {
     int arg = i;
@@ -88,7 +103,11 @@ inline float det3(const M3& m) {
     const float pivot = A[arg][i];
     if (arg != i) {
       det *= -1;
-      for (int ii = i; ii < 3; ++ii) std::swap(A[i][ii], A[arg][ii]);
+      for (int ii = i; ii < 3; ++ii) {
+        const float t = A[i][ii];
+        A[i][ii] = A[arg][ii];
+        A[arg][ii] = t;
+      }
     }
     det *= A[i][i];
     if (det == 0) return 0;
@@ -101,7 +120,7 @@ inline float det3(const M3& m) {
 }
 
 // types::invert (types/definitions.hpp:40-53)
-inline M3 invert3(const M3& in) {
+RH_HD inline M3 invert3(const M3& in) {
   const float(*m)[3] = in.a;
   M3 o;
   o.a[0][0] = m[1][1] * m[2][2] - m[1][2] * m[2][1];
@@ -119,8 +138,59 @@ inline M3 invert3(const M3& in) {
   return o;
 }
 
+// sin / cos of a float argument, rounded from a double evaluation that uses +, -, * only (Cody-Waite reduction by pi/2,
+// Taylor polynomials on [-pi/4, pi/4], Horner form, no fused operations): the SAME bits on the host and on the device, where
+// libm's sinf and the device library's differ in the last place now and then. The double result is within ~2e-16 of the true
+// value, so the float is the correctly rounded one except on ~1e-9 of the arguments. Arguments beyond 1e5 (meaningless as
+// an inter-frame rotation) go to the platform's double sin / cos.
+RH_HD inline void sincos_det(float xf, float* s_out, float* c_out) {
+  const double x = (double)xf;
+  if (!(std::fabs(x) < 1.0e5)) {
+    *s_out = (float)std::sin(x);
+    *c_out = (float)std::cos(x);
+    return;
+  }
+  const double two_over_pi = 0.63661977236758134308;
+  const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;  // 33 bits of pi/2 (k * hi exact) + the rest
+  const double kd = std::nearbyint(x * two_over_pi);
+  const long long k = (long long)kd;
+  double r = x - kd * pio2_hi;
+  r = r - kd * pio2_lo;
+  const double r2 = r * r;
+  // sin r = r (1 - r2/3! + r2^2/5! - ... - r2^8/17!)
+  double ps = -1.0 / 355687428096000.0;
+  ps = ps * r2 + 1.0 / 1307674368000.0;
+  ps = ps * r2 - 1.0 / 6227020800.0;
+  ps = ps * r2 + 1.0 / 39916800.0;
+  ps = ps * r2 - 1.0 / 362880.0;
+  ps = ps * r2 + 1.0 / 5040.0;
+  ps = ps * r2 - 1.0 / 120.0;
+  ps = ps * r2 + 1.0 / 6.0;
+  const double sr = r - r * (r2 * ps);
+  // cos r = 1 - r2/2! + r2^2/4! - ... + r2^9/18!
+  double pc = -1.0 / 6402373705728000.0;
+  pc = pc * r2 + 1.0 / 20922789888000.0;
+  pc = pc * r2 - 1.0 / 87178291200.0;
+  pc = pc * r2 + 1.0 / 479001600.0;
+  pc = pc * r2 - 1.0 / 3628800.0;
+  pc = pc * r2 + 1.0 / 40320.0;
+  pc = pc * r2 - 1.0 / 720.0;
+  pc = pc * r2 + 1.0 / 24.0;
+  pc = pc * r2 - 1.0 / 2.0;
+  const double cr = 1.0 + r2 * pc;
+  double sv, cv;
+  switch ((int)(k & 3)) {
+    case 0: sv = sr; cv = cr; break;
+    case 1: sv = cr; cv = -sr; break;
+    case 2: sv = -sr; cv = -cr; break;
+    default: sv = -cr; cv = sr; break;
+  }
+  *s_out = (float)sv;
+  *c_out = (float)cv;
+}
+
 // TooN SO3<float>::exp
-inline M3 so3_exp(const float w[3]) {
+RH_HD inline M3 so3_exp(const float w[3]) {
   const float one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
   float tsq = 0;
   for (int i = 0; i < 3; ++i) tsq += w[i] * w[i];
@@ -133,8 +203,10 @@ inline M3 so3_exp(const float w[3]) {
     A = 1.0 - tsq * one_6th * (1.0 - one_20th * tsq);
   } else {
     const float th = std::sqrt(tsq), inv = 1.0 / th;
-    A = std::sin(th) * inv;
-    B = (1 - std::cos(th)) * (inv * inv);
+    float sn, cs;
+    sincos_det(th, &sn, &cs);  // TooN: sin(theta), cos(theta) of a float (libm); see sincos_det
+    A = sn * inv;
+    B = (1 - cs) * (inv * inv);
   }
   M3 R;
   const float wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
@@ -151,7 +223,7 @@ inline M3 so3_exp(const float w[3]) {
 }
 
 // TooN Cholesky<6,float>::get_inverse (LDL^T)
-inline void cholesky6_inverse(const float* A, float* inv) {
+RH_HD inline void cholesky6_inverse(const float* A, float* inv) {
   constexpr int N = 6;
   float L[N][N];
   for (int i = 0; i < N; ++i)
@@ -189,7 +261,7 @@ inline void cholesky6_inverse(const float* A, float* inv) {
 }
 
 // x = pinv(A) b for symmetric 6x6 A (stands in for SVD<6,6,float>(A).backsub(b), core.cpp:247-248)
-inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
+RH_HD inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
   constexpr int N = 6;
   double A[N][N], V[N][N];
   bool bad = false;
@@ -228,7 +300,7 @@ inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
       }
   }
   double dmax = 0, x[N] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs(A[i][i]));
+  for (int i = 0; i < N; ++i) dmax = (std::fabs(A[i][i]) > dmax) ? std::fabs(A[i][i]) : dmax;
   for (int k = 0; k < N && !bad; ++k) {
     const double lam = A[k][k];
     if (!(std::fabs(lam) * 1e9 > dmax)) continue;
@@ -243,11 +315,11 @@ inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
 // SVD<6>::backsub stand-in used by the pipeline: for a well-conditioned SPD JtJ (the normal case) the pseudo-inverse
 // IS the inverse, so solve by an LDL^T factorisation in double (~300 flops); if a pivot falls below the 1e9 condition
 // cut relative to the largest diagonal, use the Jacobi pseudo-inverse (minimum-norm solution like the SVD).
-inline void sym6_solve(const float* A_, const float* b_, float* x_) {
+RH_HD inline void sym6_solve(const float* A_, const float* b_, float* x_) {
   constexpr int N = 6;
   double L[N][N], d[N], dmax = 0;
   bool ok = true;
-  for (int i = 0; i < N; ++i) dmax = std::max(dmax, std::fabs((double)A_[i * N + i]));
+  for (int i = 0; i < N; ++i) dmax = (std::fabs((double)A_[i * N + i]) > dmax) ? std::fabs((double)A_[i * N + i]) : dmax;
   for (int j = 0; j < N && ok; ++j) {
     double v = 0.5 * ((double)A_[j * N + j] + (double)A_[j * N + j]);
     for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * d[k];
@@ -279,12 +351,12 @@ inline void sym6_solve(const float* A_, const float* b_, float* x_) {
 }
 
 // Core::gyroBiasCorrection (core.cpp:264-284); dgbias is zero on entry, as in the reference.
-inline void gyro_bias_correction(float X[6], float Wx[36], M3& Wb, const M3& Rg, const M3& Rb, float dgbias_out[3]) {
+RH_HD inline void gyro_bias_correction(float X[6], float Wx[36], M3& Wb, const M3& Rg, const M3& Rb, float dgbias_out[3]) {
   float dgbias[3] = {0, 0, 0};
   const M3 Wg = invert3(Rg);
   Wb = invert3(add(invert3(Wb), Rb));
   float Wxb[36];
-  std::memcpy(Wxb, Wx, sizeof(Wxb));
+  for (int i = 0; i < 36; ++i) Wxb[i] = Wx[i];
   const M3 iWgWb = invert3(add(Wg, Wb));
   const M3 upd = mul(Wg, sub(identity3(), mul(iWgWb, Wg)));
   for (int i = 0; i < 3; ++i)

@@ -9,6 +9,7 @@
 // Bound: HBM/L2 gather bandwidth (keyline SoA streams + distance-field / mask / matched-keyline gathers);
 // no dense contraction exists on this path (largest product is 6x6), so MFMA does not apply.
 #include "common.hpp"
+#include "glue.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -1640,7 +1641,7 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec_b(KParams p, co
   const LaneDyn d = dyn.v[blockIdx.z];
   PairSlot* slot = L.slot[d.slot];
   lm_chain_spec_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls,
-                                    L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, slot->xrv, slot, L.hist,
+                                    L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist,
                                     nullptr, slow_poll);
 }
 
@@ -1663,7 +1664,7 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain_b(KParams p, const L
   const LaneDyn d = dyn.v[blockIdx.z];
   PairSlot* slot = L.slot[d.slot];
   lm_chain_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls, 1,
-                               L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, slot->xrv, slot, L.hist, nullptr,
+                               L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist, nullptr,
                                slow_poll);
 }
 
@@ -1815,6 +1816,41 @@ constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-
 // queued for pass 2 (a wave with one such lane would otherwise idle 63 lanes for up to 40 more dependent steps).
 // vel / Rvel are already rotated by Rback on the host (:193-194).
 // gd != null: vel / Rvel / Rback / R0 come from *gd (uniform scalar loads) instead of the kernel arguments.
+// The glue of the pair (glue.hpp) in front of the directedMatch head, for the drivers that keep a pair's two halves on the
+// device: every workgroup evaluates it for itself from the LM kernel's records (a kernel boundary lies between them: plain
+// loads), so nothing has to be handed from one workgroup to the others; workgroup 0 also leaves the device copy for the
+// kernels queued behind the head, the filter state after this pair (other parity slot) and the host's record.
+// Returns the record the head reads its inputs from (LDS), or null when the host supplied them as kernel arguments.
+__device__ __forceinline__ const GlueDev* glue_prologue(const GlueArgs& ga, int n_new, GlueDev* s_gl) {
+  if (!ga.lm) return nullptr;
+  if (threadIdx.x == 0) {
+    GlueState st = *ga.st_in;
+    GlueDev gl;
+    rebvio_hip_pair_out out;
+    hm::pair_glue_core(*ga.lm, ga.xrv, n_new, ga.gp, st, gl, out);
+    *s_gl = gl;
+    if (blockIdx.x == 0) {
+      *ga.gd_copy = gl;
+      *ga.st_out = st;
+      ga.rec->out = out;
+      ga.rec->gs = st;
+    }
+  }
+  __syncthreads();
+  return s_gl;
+}
+__device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const LaneDyn& d, int calls, const GlueParams& gp) {
+  GlueArgs ga;
+  ga.lm = L.lm + calls + 1;
+  ga.xrv = L.xrv_part;
+  ga.st_in = L.gstate + (d.gpar & 1);
+  ga.st_out = L.gstate + ((d.gpar & 1) ^ 1);
+  ga.rec = L.rec[d.slot];
+  ga.gd_copy = L.glue_dev + d.slot;
+  ga.gp = gp;
+  return ga;
+}
+
 struct DmArgs {
   Vec3 vel;
   Mat3 Rvel, Rback, R0;
@@ -1848,23 +1884,20 @@ __device__ __forceinline__ DmArgs dm_args(const GlueDev* __restrict__ gd, const 
 
 __device__ __forceinline__ void directed_match_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
-                                                        GlueDev* __restrict__ gd_copy) {
-  if (gd && gd_copy && blockIdx.x == 0) {  // device copy for the kernels queued behind this one
-    constexpr int kWords = (int)(sizeof(GlueDev) / sizeof(int));
-    if ((int)threadIdx.x < kWords) reinterpret_cast<int*>(gd_copy)[threadIdx.x] = reinterpret_cast<const int*>(gd)[threadIdx.x];
-  }
+                                                        int rot_, Mat3 R0_, const GlueArgs ga) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid), in flight during the glue
+  const float2 rsq = nm.rs[idx];
+  const float2 gq = nm.grad[idx];
+  const float gnq = nm.gnorm[idx];
+  const int n = nm.st->n;
+  __shared__ GlueDev s_gl;
+  const GlueDev* gd = glue_prologue(ga, n, &s_gl);
   const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
   if (A.skip) return;
   const Vec3& vel = A.vel;
   const Mat3 &Rvel = A.Rvel, &Rback = A.Rback, &R0 = A.R0;
   const int rot = A.rot;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid)
-  const float2 rsq = nm.rs[idx];
-  const float2 gq = nm.grad[idx];
-  const float gnq = nm.gnorm[idx];
-  const int n = nm.st->n;
   int found = -1;
   int kf = 0;
   bool more = false;
@@ -1953,18 +1986,17 @@ __device__ __forceinline__ void directed_match_body(KParams p, MapDev nm, MapDev
 
 __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
-                                                        GlueDev* __restrict__ gd_copy) {
-  directed_match_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd, gd_copy);
+                                                        int rot_, Mat3 R0_, GlueArgs ga) {
+  directed_match_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, ga);
 }
 __global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
-                                                          LaneDynB dyn, float max_radius) {
+                                                          LaneDynB dyn, float max_radius, int calls, GlueParams gp) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
   directed_match_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
-                      L.dm_work, L.dm_work_n, 1, z9, L.glue_host[d.slot], L.glue_dev + d.slot);
+                      L.dm_work, L.dm_work_n, 1, z9, lane_glue_args(L, d, calls, gp));
 }
 
 // Pass 1, wide form: EIGHT lanes per keyline of the NEW map, one per probe slot of the head (2 * kHeadSteps == 8). The
@@ -1976,23 +2008,20 @@ __global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneS
 // hence the same bits; ~1/6 of the instructions per wave on eight times the waves.
 __device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                          float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
-                                                         GlueDev* __restrict__ gd_copy) {
+                                                         int rot_, Mat3 R0_, const GlueArgs ga) {
   static_assert(kHeadSteps == 4, "eight probe slots per keyline");
-  if (gd && gd_copy && blockIdx.x == 0) {  // device copy for the kernels queued behind this one
-    constexpr int kWords = (int)(sizeof(GlueDev) / sizeof(int));
-    if ((int)threadIdx.x < kWords) reinterpret_cast<int*>(gd_copy)[threadIdx.x] = reinterpret_cast<const int*>(gd)[threadIdx.x];
-  }
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int idx = gid >> 3, slot = gid & 7;  // keyline, probe slot (slot = 2 * step + side; side 0: tn, 1: tp)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024), issued before the parameter block is
-  // read: with gd that is a round trip to pinned host memory (~1.7 us), the longest single wait of this kernel
+  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024), issued before the glue of the pair runs
+  // (streaming / batch drivers: glue_prologue): they are in flight meanwhile
   const float2 pi = nm.pos_img[idx];
   const float2 rsq = nm.rs[idx];
   const float2 gq = nm.grad[idx];
   const float gnq = nm.gnorm[idx];
   const int n = nm.st->n;
+  __shared__ GlueDev s_gl;
+  const GlueDev* gd = glue_prologue(ga, n, &s_gl);
   const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
   if (A.skip) return;
   bool acc = false, more = false;
@@ -2061,18 +2090,17 @@ __device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDe
 
 __global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                          float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
-                                                         GlueDev* __restrict__ gd_copy) {
-  directed_match8_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd, gd_copy);
+                                                         int rot_, Mat3 R0_, GlueArgs ga) {
+  directed_match8_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, ga);
 }
 __global__ __launch_bounds__(256) void k_directed_match8_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
-                                                           LaneDynB dyn, float max_radius) {
+                                                           LaneDynB dyn, float max_radius, int calls, GlueParams gp) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
   directed_match8_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
-                       L.dm_work, L.dm_work_n, 1, z9, L.glue_host[d.slot], L.glue_dev + d.slot);
+                       L.dm_work, L.dm_work_n, 1, z9, lane_glue_args(L, d, calls, gp));
 }
 
 // Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
@@ -2521,10 +2549,10 @@ static bool lm_spec_usable(int kmax, int calls) {
 
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
                      LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
-                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps) {
-  const dim3 grid(lm_chain_grid(p.kmax));
-  if (do_ext == 2 && lm_chain_threads() <= 512 && lm_spec_usable(p.kmax, calls)) {
-    if (lm_chain_threads() == 256)
+                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps, int threads) {
+  const dim3 grid((p.kmax + threads - 1) / threads);
+  if (do_ext == 2 && threads <= 512 && lm_spec_usable(p.kmax, calls)) {
+    if (threads == 256)
       RH_LAUNCH(k_lm_chain_spec<256>, grid, dim3(256), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out,
                 xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
     else
@@ -2532,7 +2560,7 @@ void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const 
                 xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
     return;
   }
-  switch (lm_chain_threads()) {
+  switch (threads) {
     case 256:
       RH_LAUNCH(k_lm_chain<256>, grid, dim3(256), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
                 bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps);
@@ -2562,60 +2590,51 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
                      calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual), slot, hist_to_zero);
 }
 
-// grid of the wave-per-keyline pass (REBVIO_HIP_DM_TAIL_BLOCKS to experiment): the queue holds a few thousand long
-// searches, each a chain of dependent gathers - more waves in flight shorten the pass until the dispatch of the grid itself
-// shows (640x480 / 16k keylines: 512 workgroups beat 768, 1024 and 2048 by 3 %; 1280x960 / 64k: ~10k queue entries)
-static int dm_tail_blocks(int kmax) {
-  static const int env = [] {
-    const char* e = std::getenv("REBVIO_HIP_DM_TAIL_BLOCKS");
-    return e ? std::atoi(e) : 0;
-  }();
-  if (env > 0) return env;
-  return std::max(512, std::min(1024, kmax / 32));
-}
+// grid of the wave-per-keyline pass: the queue holds a few thousand long searches, each a chain of dependent gathers - more
+// waves in flight shorten the pass until the dispatch of the grid itself shows (640x480 / 16k keylines: 512 workgroups beat
+// 768, 1024 and 2048 by 3 %; 1280x960 / 64k: ~10k queue entries)
+static int dm_tail_blocks(int kmax) { return std::max(512, std::min(1024, kmax / 32)); }
 
 // Pass 1 form. Eight lanes per keyline shorten the dependent instruction chain of a wave sixfold and pay for it with an
 // eightfold redundant probe set-up: a win while the launch is latency-bound on a mostly idle chip (16k keylines: 11.6 vs
-// 13.8 us), a loss once the eight-fold grid fills it (64k keylines: 36 vs 24 us). REBVIO_HIP_DM_HEAD=thread|wide overrides.
-static bool dm_head_wide(int kmax) {
-  static const int env = [] {
-    const char* e = std::getenv("REBVIO_HIP_DM_HEAD");
-    if (e && std::strcmp(e, "thread") == 0) return 1;
-    if (e && std::strcmp(e, "wide") == 0) return 2;
-    return 0;
-  }();
-  if (env) return env == 2;
+// 13.8 us), a loss once the eight-fold grid fills it (64k keylines: 36 vs 24 us). head_form: 0 by map size, 1 thread per
+// keyline, 2 eight lanes per keyline (REBVIO_HIP_DM_HEAD, read when the context is created).
+static bool dm_head_wide(int kmax, int head_form) {
+  if (head_form) return head_form == 2;
   return kmax <= 32768;
 }
 
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
-                           const float* R0_on_the_fly) {
+                           const float* R0_on_the_fly, int head_form) {
   // *work_n is zero on entry (reset by the kernel that follows the tail, or by the caller)
   const int rot = R0_on_the_fly ? 1 : 0;
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
-  if (dm_head_wide(p.kmax))
+  const GlueArgs none{};
+  if (dm_head_wide(p.kmax, head_form))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback),
-              max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
+              max_radius, work, work_n, rot, R0, none);
   else
     RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
-                       mat3(Rback), max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr, (GlueDev*)nullptr);
+                       mat3(Rback), max_radius, work, work_n, rot, R0, none);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
             (const int*)work, (const int*)work_n, rot, R0, (const GlueDev*)nullptr);
 }
 
-void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* g_pinned,
-                               GlueDev* g_dev, float max_radius, int* work, int* work_n) {
+// the same two launches with the pair's glue evaluated on the device in front of the head (streaming driver): the head
+// leaves the second half's inputs in *ga.gd_copy, which the tail (and the kernels after it) read
+void launch_directed_match_glue(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueArgs& ga,
+                                float max_radius, int* work, int* work_n, int head_form) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-  if (dm_head_wide(p.kmax))
+  if (dm_head_wide(p.kmax, head_form))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
-              work, work_n, 1, mat3(I), g_pinned, g_dev);
+              work, work_n, 1, mat3(I), ga);
   else
     RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, work,
-              work_n, 1, mat3(I), g_pinned, g_dev);
+              work_n, 1, mat3(I), ga);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
-            (const int*)work, (const int*)work_n, 1, mat3(I), (const GlueDev*)g_dev);
+            (const int*)work, (const int*)work_n, 1, mat3(I), (const GlueDev*)ga.gd_copy);
 }
 
 void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& searched, const rebvio_hip_keyline& q, const float vel[3],
@@ -2646,9 +2665,8 @@ void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m,
 void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
                        int spec) {
   // 512-thread workgroups (the single-stream default); lanes x 30 workgroups at 16k keylines must all be resident: with one
-  // workgroup per CU that holds up to 8 lanes on 256 CUs
-  static const int slow = std::getenv("REBVIO_HIP_BATCH_POLL") ? std::atoi(std::getenv("REBVIO_HIP_BATCH_POLL")) : -1;
-  const int slow_poll = slow >= 0 ? slow : (lanes >= 3 ? 1 : 0);
+  // workgroup per CU that holds up to 8 lanes on 256 CUs (rebvio_hip_batch_create checks the bound)
+  const int slow_poll = lanes >= 3 ? 1 : 0;
   if (spec && lm_spec_usable(p.kmax, calls))
     RH_LAUNCH(k_lm_chain_spec_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), lm_spec_shm(p.kmax, calls), s, p, ls, maptab,
               dyn, calls, slow_poll);
@@ -2656,20 +2674,36 @@ void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneSta
     RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll);
 }
 
+// The batched persistent LM kernel needs every workgroup of the launch resident at once (they wait for each other's
+// records). One block per CU is taken off the occupancy query's answer where it admits several (MI355X_MICROARCH.md: the
+// query can read one block per CU high); kernels of the other streams only delay residency, they do not depend on this one.
+int lm_chain_b_max_lanes(int device, int kmax, int calls) {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 1;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lm_chain_b<512>, 512, 0) != hipSuccess) nb = 1;
+  if (lm_spec_usable(kmax, calls)) {
+    int nbs = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, k_lm_chain_spec_b<512>, 512, lm_spec_shm(kmax, calls)) != hipSuccess) nbs = 1;
+    nb = std::min(nb, nbs);
+  }
+  nb = nb > 1 ? nb - 1 : 1;
+  const int per_lane = (kmax + 511) / 512;
+  return std::max(1, std::min(kMaxLanes, nb * cus / per_lane));
+}
+
+// second half of a batched step: every lane's glue runs in front of its directedMatch head (glue_prologue)
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
-                      float max_radius, int gate) {
+                      float max_radius, int gate, int calls, const GlueParams& gp, int head_form) {
   const unsigned z = (unsigned)lanes;
   // head form: eight lanes per keyline is the low-latency form while the chip is mostly idle; from a few lanes on the chip is
-  // full and the thread-per-keyline form (an eighth of the waves) is the cheaper one (REBVIO_HIP_BATCH_DM_HEAD=wide|thread)
-  static const int env = [] {
-    const char* e = std::getenv("REBVIO_HIP_BATCH_DM_HEAD");
-    return (e && std::strcmp(e, "thread") == 0) ? 1 : ((e && std::strcmp(e, "wide") == 0) ? 2 : 0);
-  }();
-  const bool wide = env ? env == 2 : lanes < 4;
+  // full and the thread-per-keyline form (an eighth of the waves) is the cheaper one (REBVIO_HIP_BATCH_DM_HEAD=wide|thread,
+  // read when the batch is created)
+  const bool wide = head_form ? head_form == 2 : (lanes < 4 && p.kmax <= 32768);
   if (wide)
-    RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
+    RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius, calls, gp);
   else
-    RH_LAUNCH(k_directed_match_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
+    RH_LAUNCH(k_directed_match_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius, calls, gp);
   RH_LAUNCH(k_directed_match_tail_b, dim3(dm_tail_blocks(p.kmax), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
 }

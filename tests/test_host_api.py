@@ -127,9 +127,8 @@ def test_edge_maps_outlive_their_pipeline(host_lib, tmp_path):
 @pytest.mark.gpu
 def test_host_class_modes_publish_the_same_records(host_lib, tmp_path):
     """rebvio::Rebvio with its edge-image callback reading a keyline of every fresh map (as ros_rebvio.cpp:44 does), under the
-    backend's scheduling options: second halves parked behind a pinned flag (REBVIO_HIP_PAIR_PRELAUNCH=1; a callback's map
-    download used to dead-lock with this - the run is bounded by the timeout), host-frame detections launched by the detect
-    worker (REBVIO_HIP_DETECT_ASYNC=1), both, and the sequential LM kernel. None of them may change a digit of the output."""
+    backend's remaining switches: the sequential and the per-call LM kernels, the other workgroup sizes, the
+    thread-per-keyline directedMatch head, flat stream priorities. None of them may change a digit of the output."""
     from rebvio_amd import synth
     n = 40
     frames, cam = synth.render_stream(320, 240, n)
@@ -149,13 +148,11 @@ def test_host_class_modes_publish_the_same_records(host_lib, tmp_path):
         return lines
 
     base = run()
-    assert run(REBVIO_HIP_PAIR_PRELAUNCH="1") == base
-    assert run(REBVIO_HIP_DETECT_ASYNC="1") == base
-    assert run(REBVIO_HIP_PAIR_PRELAUNCH="1", REBVIO_HIP_DETECT_ASYNC="1") == base
     assert run(REBVIO_HIP_LM="seq") == base
-    assert run(REBVIO_HIP_SCAN_SPLIT="0", REBVIO_HIP_ROWSCAN="lane") == base
-    assert run(REBVIO_HIP_COLSCAN="w16") == base     # the wave-resident column pass kept for A/B
-    assert run(REBVIO_HIP_COLSCAN="w4") == base
+    assert run(REBVIO_HIP_LM="percall") == base
+    assert run(REBVIO_HIP_LM_THREADS="1024") == base
+    assert run(REBVIO_HIP_DM_HEAD="thread") == base
+    assert run(REBVIO_HIP_PRIO="flat") == base
 
 
 def _write_imu(path, ts, gyro, acc):

@@ -21,5 +21,5 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed (see p$i.log)"
 done
 python3 tools/pmc_table.py $OUT > $OUT/pmc_summary.txt 2>&1 || true
-rm -rf $OUT/p*/*/*kernel_trace.csv $OUT/p*/*/*agent_info.csv
+rm -rf $OUT/p[0-9]*/   # raw rocprofv3 output (tens of MB): only the summaries travel back
 tail -5 $OUT/pmc_summary.txt

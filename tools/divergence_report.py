@@ -12,13 +12,13 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def run(n, sid, W=640, H=480, kref=15000, kmax=16000):
+def run(n, sid, W=640, H=480, kref=15000, kmax=16000, density=1.0, **extra):
     import torch  # noqa: F401
     from oracle import oracle_py as O
     from rebvio_amd import backend as B, synth
-    frames, cam = synth.render_stream(W, H, 8, stream_id=sid)
+    frames, cam = synth.render_stream(W, H, 8, stream_id=sid, density=density)
     order = synth.pingpong_indices(8, n)
-    kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=kref, keylines_max=kmax)
+    kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=kref, keylines_max=kmax, **extra)
 
     def oracle(wide):
         orc = O.Oracle(O.default_params(H, W, **kw))
@@ -40,7 +40,8 @@ def run(n, sid, W=640, H=480, kref=15000, kmax=16000):
         out, _ = ctx.push_frame_u8_device(dev + int(i) * W * H, k * 50000)
         if out.status >= 0:
             got.append((np.array(out.Vg), out.lm_accept_mask, out.klm_num, out.status))
-    ctx.flush()
+    for out, _ in ctx.flush():  # the records still on their way when the input ended
+        got.append((np.array(out.Vg), out.lm_accept_mask, out.klm_num, out.status))
     ctx.close()
     return ref, wide, got
 
