@@ -295,6 +295,17 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
 int rebvio_hip_batch_next_records(rebvio_hip_batch* b, rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_batch_flush(rebvio_hip_batch* b);
 
+/* Test hook: the glue of one pair (rebvio.cpp:177-233 without the accelerometer branch: sum of the extRotVel block records, 6x6
+ * solve, gyroBiasCorrection, SO3 correction, covariance, next prior) evaluated on the device, as the streaming and batch drivers
+ * run it, AND on the host, as rebvio_hip_track_pair runs it, from the same inputs: final minimizeVel state (vel, the six
+ * unique JtJ entries (0,0) (1,1) (2,2) (0,1) (0,2) (1,2), F, sigma_rho_min, accept mask), ceil(n_new / 256) extRotVel records of
+ * 32 floats, frame_dt, filter state and prior rotation. Outputs per side: the pair record, the filter state after the pair
+ * (22 floats: Bg, W_Bg, next prior rotation, pad) and the second half's inputs (44 words). The two sides must agree bit for bit. */
+int rebvio_hip_test_glue(rebvio_hip_ctx* ctx, const float vel[3], const float JtJ6[6], float F, float sigma_rho_min, int accept_mask,
+                         const float* xrv, int n_new, float frame_dt, const float Bg[3], const float W_Bg[9], const float R_prior[9],
+                         rebvio_hip_pair_out* out_dev, float* state_dev, float* second_dev, rebvio_hip_pair_out* out_host,
+                         float* state_host, float* second_host);
+
 /* Per-kernel device timing of the last N launches of each kernel, measured with HIP events on the
  * stream the kernel runs on. names: '\n'-separated. Used by bench.py's roofline leg. */
 int rebvio_hip_profile_enable(rebvio_hip_ctx* ctx, int on); /* 0 off, 1 every launch, N>1 every N-th launch */

@@ -109,6 +109,8 @@ SIGNATURES = {
     "rebvio_hip_batch_push_u8_device": (C.c_int, [_vp, C.POINTER(_vp), C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_batch_next_records": (C.c_int, [_vp, C.POINTER(PairOut), _ip]),
     "rebvio_hip_batch_flush": (C.c_int, [_vp]),
+    "rebvio_hip_test_glue": (C.c_int, [_vp, _fp, _fp, C.c_float, C.c_float, C.c_int, _fp, C.c_int, C.c_float, _fp, _fp, _fp,
+                                      C.POINTER(PairOut), _fp, _fp, C.POINTER(PairOut), _fp, _fp]),
     "rebvio_hip_profile_enable": (C.c_int, [_vp, C.c_int]),
     "rebvio_hip_profile_select": (C.c_int, [_vp, C.c_char_p]),
     "rebvio_hip_profile_reset": (C.c_int, [_vp]),
@@ -446,6 +448,25 @@ class Context:
         n = C.c_int()
         _chk(lib().rebvio_hip_push_frame_u8_device(self.h, _vp(dev_addr), ts_us, C.byref(out), C.byref(n)))
         return out, n.value
+
+    def test_glue(self, vel, JtJ6, F, sigma_rho_min, accept_mask, xrv, n_new, frame_dt, Bg, W_Bg, R_prior):
+        """The pair glue on the device and on the host from the same inputs: ((out, state[22], second[44 words]) per side)."""
+        vel, pv = _f(vel)
+        JtJ6, pj = _f(JtJ6)
+        xrv, px = _f(np.asarray(xrv, np.float32).reshape(-1))
+        Bg, pb = _f(Bg)
+        W_Bg, pw = _f(np.asarray(W_Bg).reshape(9))
+        R_prior, pr = _f(np.asarray(R_prior).reshape(9))
+        res = []
+        outs = [PairOut(), PairOut()]
+        sts = [np.zeros(22, np.float32) for _ in range(2)]
+        sec = [np.zeros(44, np.float32) for _ in range(2)]
+        _chk(lib().rebvio_hip_test_glue(self.h, pv, pj, F, sigma_rho_min, accept_mask, px, n_new, frame_dt, pb, pw, pr,
+                                        C.byref(outs[0]), sts[0].ctypes.data_as(_fp), sec[0].ctypes.data_as(_fp),
+                                        C.byref(outs[1]), sts[1].ctypes.data_as(_fp), sec[1].ctypes.data_as(_fp)))
+        for i in range(2):
+            res.append((outs[i], sts[i], sec[i]))
+        return res
 
     def next_record(self):
         """The oldest complete pair record not handed out yet, or None."""

@@ -678,12 +678,15 @@ void enqueue_lm_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm,
 // identical bits (same per-keyline code, same record order).
 // xrv_dst: where the extRotVel block records go - the pinned slot's tail (per-pair API: the host sums them) or device
 // memory (streaming driver: the device glue sums them).
-int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3], PairSlot* slot, float* xrv_dst) {
+// ga.lm != null: the pair's glue runs on the device behind the extRotVel sums (streaming driver).
+int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3], PairSlot* slot, float* xrv_dst,
+                    const GlueArgs& ga) {
   const int calls = (int)c->P.iterations + 1;
   if (!c->lm_persistent) {
     enqueue_lm_chain(c, om, nm, vel0);
     launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
                        c->part + (size_t)(calls - 1) * part_call_stride(c), xrv_dst, vel0, slot, c->hist);
+    if (ga.lm) launch_pair_glue(c->s_trk, nm->d, ga);
     return 0;
   }
   if (*c->lm_bar_err) {
@@ -722,7 +725,7 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
   }
   const bool spec_now = c->lm_spec && (c->lm_spec_forced || c->lm_miss_ema < 0.17f);
   launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, spec_now ? 2 : 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
-                  xrv_dst, slot, c->hist, c->lm_stamps, c->lm_threads);
+                  xrv_dst, slot, c->hist, c->lm_stamps, c->lm_threads, ga);
   c->lm_tag_base += 2u * ((unsigned)calls + 1u);  // (the speculative kernel numbers repeated evaluations in a second range)
   if (c->lm_tag_base > 0xFFFFFF00u) {  // tags must stay unique and non-zero: restart the sequence on clean exchange words
     (void)hipMemsetAsync(c->lm_xch, 0, lm_xch_words(c->maxblocks) * sizeof(unsigned long long), c->s_trk);
@@ -1652,7 +1655,7 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   const float v0[3] = {0, 0, 0};                  // imu_state_.Vg = Zeros (rebvio.cpp:167)
   // minimizeVel, forwardMatch + extRotVel (rebvio.cpp:169-177); results land in slot 0
   PairSlot* slot = c->slot[0];
-  rc = enqueue_pair_lm(c, om, nm, v0, slot, slot->xrv);
+  rc = enqueue_pair_lm(c, om, nm, v0, slot, slot->xrv, GlueArgs{});
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
@@ -1714,7 +1717,7 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   }
   const float v0[3] = {0, 0, 0};
   PairSlot* slot = c->slot[0];
-  rc = enqueue_pair_lm(c, om, nm, v0, slot, slot->xrv);
+  rc = enqueue_pair_lm(c, om, nm, v0, slot, slot->xrv, GlueArgs{});
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->slot_ev[0], s));
@@ -1917,8 +1920,6 @@ int stream_enqueue_pair(rebvio_hip_ctx* c) {
     launch_rotate(s, c->K, om->d, RT, c->hist, 0);
   }
   const float v0[3] = {0, 0, 0};
-  rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part);  // rebvio.cpp:167-177
-  if (rc) return rc;
   const float frame_dt = (float)((double)(float)(nm->ts - om->ts) / 1000000.0);  // rebvio.cpp:183
   const int calls = (int)c->P.iterations + 1;
   GlueArgs ga;
@@ -1929,7 +1930,9 @@ int stream_enqueue_pair(rebvio_hip_ctx* c) {
   ga.rec = c->rec[slot];
   ga.gd_copy = c->glue_dev + slot;
   ga.gp = glue_params(c, frame_dt);
-  launch_directed_match_glue(s, c->K, nm->d, om->d, ga, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
+  rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part, ga);  // rebvio.cpp:167-177 + the glue of rebvio.cpp:177-233
+  if (rc) return rc;
+  launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
   const int gate = (int)c->P.global_min_matches_threshold;
   launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
   std::swap(nm->d.rs, nm->d.rs_tmp);
@@ -2063,6 +2066,84 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->s_key));
   { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   return rc;
+}
+
+int rebvio_hip_test_glue(rebvio_hip_ctx* c, const float vel[3], const float JtJ6[6], float F, float sigma_rho_min, int accept_mask,
+                         const float* xrv, int n_new, float frame_dt, const float Bg[3], const float W_Bg[9], const float R_prior[9],
+                         rebvio_hip_pair_out* out_dev, float* state_dev, float* second_dev, rebvio_hip_pair_out* out_host, float* state_host,
+                         float* second_host) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n_new < 0 || n_new > c->P.keylines_max) return fail_msg("test_glue: n_new out of range", -3);
+  static_assert(sizeof(GlueState) == 22 * sizeof(float) && sizeof(GlueDev) == 44 * sizeof(float), "record layouts of the test hook");
+  LmState lm;
+  std::memset(&lm, 0, sizeof(lm));
+  for (int i = 0; i < 3; ++i) lm.vel[i] = vel[i];
+  for (int i = 0; i < 6; ++i) lm.JtJ[i] = JtJ6[i];
+  lm.F = F;
+  lm.sigma_rho_min = sigma_rho_min;
+  lm.accept_mask = accept_mask;
+  GlueState st;
+  for (int i = 0; i < 3; ++i) st.Bg[i] = Bg[i];
+  std::memcpy(st.W_Bg, W_Bg, sizeof(st.W_Bg));
+  std::memcpy(st.R, R_prior, sizeof(st.R));
+  st.pad = 0.f;
+  const int nb = div_up(n_new, 256);
+  // host form (what rebvio_hip_track_pair runs)
+  {
+    GlueState sh = st;
+    GlueDev gl;
+    std::memset(&gl, 0, sizeof(gl));
+    std::memset(out_host, 0, sizeof(*out_host));
+    hm::pair_glue_core(lm, xrv, n_new, glue_params(c, frame_dt), sh, gl, *out_host);
+    std::memcpy(state_host, &sh, sizeof(sh));
+    std::memcpy(second_host, &gl, sizeof(gl));
+  }
+  // device form (what the streaming and batch drivers run), through the stand-alone glue kernel
+  { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
+  char* buf = nullptr;
+  const size_t xb = (size_t)std::max(nb, 1) * kXrvStride * sizeof(float);
+  HIPCHK(hipMalloc(&buf, sizeof(LmState) + sizeof(MapState) + 2 * sizeof(GlueState) + sizeof(GlueDev) + sizeof(GlueRec) + xb));
+  struct Free {
+    char* p;
+    ~Free() { (void)hipFree(p); }
+  } guard{buf};
+  LmState* d_lm = reinterpret_cast<LmState*>(buf);
+  MapState* d_ms = reinterpret_cast<MapState*>(d_lm + 1);
+  GlueState* d_st = reinterpret_cast<GlueState*>(d_ms + 1);
+  GlueDev* d_gl = reinterpret_cast<GlueDev*>(d_st + 2);
+  GlueRec* d_rec = reinterpret_cast<GlueRec*>(d_gl + 1);
+  float* d_xrv = reinterpret_cast<float*>(d_rec + 1);
+  MapState ms;
+  std::memset(&ms, 0, sizeof(ms));
+  ms.n = n_new;
+  HIPCHK(hipMemcpy(d_lm, &lm, sizeof(lm), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_ms, &ms, sizeof(ms), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_st, &st, sizeof(st), hipMemcpyHostToDevice));
+  if (nb > 0) HIPCHK(hipMemcpy(d_xrv, xrv, (size_t)nb * kXrvStride * sizeof(float), hipMemcpyHostToDevice));
+  MapDev fake{};
+  fake.st = d_ms;
+  GlueArgs ga;
+  ga.lm = d_lm;
+  ga.xrv = d_xrv;
+  ga.st_in = d_st;
+  ga.st_out = d_st + 1;
+  ga.rec = d_rec;
+  ga.gd_copy = d_gl;
+  ga.gp = glue_params(c, frame_dt);
+  launch_pair_glue(c->s_trk, fake, ga);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->s_trk));
+  GlueRec rec;
+  GlueState sd;
+  GlueDev gd;
+  HIPCHK(hipMemcpy(&rec, d_rec, sizeof(rec), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&sd, d_st + 1, sizeof(sd), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&gd, d_gl, sizeof(gd), hipMemcpyDeviceToHost));
+  *out_dev = rec.out;
+  std::memcpy(state_dev, &sd, sizeof(sd));
+  std::memcpy(second_dev, &gd, sizeof(gd));
+  if (std::memcmp(&rec.gs, &sd, sizeof(sd)) != 0) return fail_msg("test_glue: the record's state copy differs from the state written", -5);
+  return 0;
 }
 
 int rebvio_hip_profile_enable(rebvio_hip_ctx* c, int on) {
@@ -2367,11 +2448,10 @@ int batch_enqueue_pair(rebvio_hip_batch* b) {
   bool spec_now = b->lane[0]->lm_spec;  // one launch for all lanes: speculative while every lane's recent miss rate allows it
   if (spec_now && !b->lane[0]->lm_spec_forced)
     for (auto* c : b->lane) spec_now = spec_now && c->lm_miss_ema < 0.17f;
-  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0);
-  const int gate = (int)b->P.global_min_matches_threshold;
   const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
-  launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, calls,
-                   glue_params(b->lane[0], frame_dt), b->dm_head_form);
+  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0, glue_params(b->lane[0], frame_dt));
+  const int gate = (int)b->P.global_min_matches_threshold;
+  launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);
   HIPCHK(hipGetLastError());
   for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
     rebvio_hip_map* nm = nf.m[l];

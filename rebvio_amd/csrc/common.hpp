@@ -21,8 +21,12 @@ constexpr int kPartStride = 16;     // floats per block record of k_try_vel
 constexpr int kXrvStride = 32;      // floats per block record of k_ext_rot_vel
 constexpr int kMaxLmCalls = 8;
 // 64-bit exchange words of the persistent LM kernels for `groups` record groups of 256 keylines (track.hip: record sets per
-// evaluation, the final velocity, neighbour carry words and barrier words of the speculative form)
-constexpr size_t lm_xch_words(size_t groups) { return ((size_t)kMaxLmCalls * groups + 1) * 16 + (2 * (size_t)kMaxLmCalls + 1) * groups; }
+// evaluation, the final velocity, neighbour carry words and barrier words of the speculative form), then the words of the
+// extRotVel sums the device glue collects (kXrvStride per group)
+__host__ __device__ constexpr size_t lm_xch_xrv_offset(size_t groups, size_t workgroups) {
+  return ((size_t)kMaxLmCalls * groups + 1) * 16 + (2 * (size_t)kMaxLmCalls + 1) * workgroups;
+}
+constexpr size_t lm_xch_words(size_t groups) { return lm_xch_xrv_offset(groups, groups) + groups * (size_t)kXrvStride; }
 constexpr int kDfTile = 32;         // distance-field tile edge (pixels); 64 for sensors with more than kDfMaxTiles 32-pixel tiles
 constexpr int kDfMaxTiles = 4096;   // per-workgroup LDS counter table of the binning pass
 constexpr int kDfTileCap = 512;     // list capacity per tile (32-byte entries); a fuller tile falls back to scanning its candidate rows
@@ -205,8 +209,8 @@ struct GlueParams {
   float gyro_std_dev, gyro_bias_std_dev;
 };
 
-// Device glue of a pair, run in the prologue of the directedMatch head kernel (glue.hpp, track.hip: glue_prologue). lm == null:
-// no device glue - the kernel takes the second half's inputs from its arguments (per-pair API: the host ran the glue).
+// Device glue of a pair, run by workgroup 0 of the persistent LM kernel behind its last phase (glue_dev.hpp). lm == null: no
+// device glue - the extRotVel records go to memory for the host (per-pair API: the host runs the glue).
 struct GlueArgs {
   const LmState* lm;       // final minimizeVel state of this pair (device memory)
   const float* xrv;        // extRotVel block records of this pair (device memory, kXrvStride floats per record group)
@@ -226,16 +230,18 @@ void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, co
 // the context is created; default 512).
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
                      LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
-                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps, int threads);
+                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps, int threads, const GlueArgs& ga);
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
 // lanes whose persistent LM workgroups (512 threads, ceil(kmax / 512) per lane) the device holds resident at once
 int lm_chain_b_max_lanes(int device, int kmax, int calls);
+// the device glue as a launch of its own, behind k_ext_rot_vel (REBVIO_HIP_LM=percall: no persistent kernel to run it in)
+void launch_pair_glue(hipStream_t s, const MapDev& newm, const GlueArgs& ga);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
                            const float* R0_on_the_fly, int head_form);
-// the same two launches with the pair's glue evaluated on the device in front of the head; the tail reads *ga.gd_copy
-void launch_directed_match_glue(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueArgs& ga,
-                                float max_radius, int* work, int* work_n, int head_form);
+// the same two launches with the second half's inputs read from *gd (device memory) at run time
+void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
+                               int* work, int* work_n, int head_form);
 void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* work_n_reset,
                                int* hist);
 // fused regularize1Iter + depth EKF: reads m.rs, writes m.rs_tmp (caller swaps the pointers); Rnext != null also
@@ -314,9 +320,9 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
-                       int spec);
+                       int spec, const GlueParams& gp);
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
-                      float max_radius, int gate, int calls, const GlueParams& gp, int head_form);
+                      float max_radius, int gate, int head_form);
 
 // Optional per-kernel timing with HIP events recorded on the launching stream (api.hip).
 void prof_begin(hipStream_t s, const char* name);

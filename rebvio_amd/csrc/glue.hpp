@@ -60,7 +60,10 @@ RH_HD inline void pair_glue_core(const LmState& lm, const float* xrv, int n_new,
   out.sigma_rho_min = lm.sigma_rho_min;
   float Xv[6], W_Xv[36], JtF6[6];
   sum_xrv(xrv, (n_new + 255) / 256, W_Xv, JtF6);
-  sym6_solve(W_Xv, JtF6, Xv);
+  {
+    double ws[72];
+    sym6_solve_ws(W_Xv, JtF6, Xv, ws);
+  }
   out.ext_ok = 1;
   for (int i = 0; i < 6; ++i)
     if (Xv[i] != Xv[i]) out.ext_ok = 0;

@@ -222,119 +222,141 @@ RH_HD inline M3 so3_exp(const float w[3]) {
   return R;
 }
 
-// TooN Cholesky<6,float>::get_inverse (LDL^T)
-RH_HD inline void cholesky6_inverse(const float* A, float* inv) {
+// TooN Cholesky<6,float>::get_inverse (LDL^T), in two steps so that the device can give every column of the inverse to a
+// lane of its own (each lane factorises for itself: the same operations either way).
+RH_HD inline void cholesky6_factor(const float* A, float L[6][6]) {
   constexpr int N = 6;
-  float L[N][N];
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) L[i][j] = A[i * N + j];
   for (int col = 0; col < N; ++col) {
     float inv_diag = 1;
+    bool stop = false;  // TooN leaves the column at a zero pivot (`break`): a flag keeps the loop bounds static for the device
     for (int row = col; row < N; ++row) {
+      if (stop) continue;
       float val = L[row][col];
       for (int c2 = 0; c2 < col; ++c2) val -= L[c2][col] * L[row][c2];
       if (row == col) {
         L[row][col] = val;
-        if (val == 0) break;
-        inv_diag = 1 / val;
+        if (val == 0)
+          stop = true;
+        else
+          inv_diag = 1 / val;
       } else {
         L[col][row] = val;
         L[row][col] = val * inv_diag;
       }
     }
   }
+}
+// column c of the inverse: solve L D L^T x = e_c
+RH_HD inline void cholesky6_inverse_col(const float L[6][6], int c, float res[6]) {
+  constexpr int N = 6;
+  float y[N];
+  for (int i = 0; i < N; ++i) {
+    float val = (i == c) ? 1.0f : 0.0f;
+    for (int j = 0; j < i; ++j) val -= L[i][j] * y[j];
+    y[i] = val;
+  }
+  for (int i = 0; i < N; ++i) y[i] /= L[i][i];
+  for (int i = N - 1; i >= 0; --i) {
+    float val = y[i];
+    for (int j = i + 1; j < N; ++j) val -= L[j][i] * res[j];
+    res[i] = val;
+  }
+}
+RH_HD inline void cholesky6_inverse(const float* A, float* inv) {
+  constexpr int N = 6;
+  float L[N][N];
+  cholesky6_factor(A, L);
   for (int c = 0; c < N; ++c) {
-    float y[N], res[N];
-    for (int i = 0; i < N; ++i) {
-      float val = (i == c) ? 1.0f : 0.0f;
-      for (int j = 0; j < i; ++j) val -= L[i][j] * y[j];
-      y[i] = val;
-    }
-    for (int i = 0; i < N; ++i) y[i] /= L[i][i];
-    for (int i = N - 1; i >= 0; --i) {
-      float val = y[i];
-      for (int j = i + 1; j < N; ++j) val -= L[j][i] * res[j];
-      res[i] = val;
-    }
+    float res[N];
+    cholesky6_inverse_col(L, c, res);
     for (int i = 0; i < N; ++i) inv[i * N + c] = res[i];
   }
 }
 
-// x = pinv(A) b for symmetric 6x6 A (stands in for SVD<6,6,float>(A).backsub(b), core.cpp:247-248)
-RH_HD inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
+// x = pinv(A) b for symmetric 6x6 A (stands in for SVD<6,6,float>(A).backsub(b), core.cpp:247-248): cyclic Jacobi with
+// TooN's 1e9 condition cut. ws = 72 doubles of workspace (on the device: LDS; its loops index dynamically, which a register
+// array would turn into scratch memory).
+RH_HD inline void sym6_pinv_solve_ws(const float* A_, const float* b_, float* x_, double* ws) {
   constexpr int N = 6;
-  double A[N][N], V[N][N];
+  double* A = ws;       // [N][N]
+  double* V = ws + 36;  // [N][N]
   bool bad = false;
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) {
-      if (std::isnan(A_[i * N + j])) bad = true;
-      A[i][j] = 0.5 * ((double)A_[i * N + j] + (double)A_[j * N + i]);
-      V[i][j] = (i == j) ? 1.0 : 0.0;
+      if (A_[i * N + j] != A_[i * N + j]) bad = true;
+      A[i * N + j] = 0.5 * ((double)A_[i * N + j] + (double)A_[j * N + i]);
+      V[i * N + j] = (i == j) ? 1.0 : 0.0;
     }
   for (int sweep = 0; sweep < 60 && !bad; ++sweep) {
     double off = 0;
     for (int p = 0; p < N; ++p)
-      for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
+      for (int q = p + 1; q < N; ++q) off += A[p * N + q] * A[p * N + q];
     if (off < 1e-300) break;
     for (int p = 0; p < N; ++p)
       for (int q = p + 1; q < N; ++q) {
-        if (A[p][q] == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        if (A[p * N + q] == 0.0) continue;
+        const double theta = (A[q * N + q] - A[p * N + p]) / (2.0 * A[p * N + q]);
         const double t = ((theta >= 0) ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
         const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
         for (int k = 0; k < N; ++k) {
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = cs * akp - sn * akq;
-          A[k][q] = sn * akp + cs * akq;
+          const double akp = A[k * N + p], akq = A[k * N + q];
+          A[k * N + p] = cs * akp - sn * akq;
+          A[k * N + q] = sn * akp + cs * akq;
         }
         for (int k = 0; k < N; ++k) {
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = cs * apk - sn * aqk;
-          A[q][k] = sn * apk + cs * aqk;
+          const double apk = A[p * N + k], aqk = A[q * N + k];
+          A[p * N + k] = cs * apk - sn * aqk;
+          A[q * N + k] = sn * apk + cs * aqk;
         }
         for (int k = 0; k < N; ++k) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = cs * vkp - sn * vkq;
-          V[k][q] = sn * vkp + cs * vkq;
+          const double vkp = V[k * N + p], vkq = V[k * N + q];
+          V[k * N + p] = cs * vkp - sn * vkq;
+          V[k * N + q] = sn * vkp + cs * vkq;
         }
       }
   }
   double dmax = 0, x[N] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < N; ++i) dmax = (std::fabs(A[i][i]) > dmax) ? std::fabs(A[i][i]) : dmax;
+  for (int i = 0; i < N; ++i) dmax = (std::fabs(A[i * N + i]) > dmax) ? std::fabs(A[i * N + i]) : dmax;
   for (int k = 0; k < N && !bad; ++k) {
-    const double lam = A[k][k];
+    const double lam = A[k * N + k];
     if (!(std::fabs(lam) * 1e9 > dmax)) continue;
     double proj = 0;
-    for (int i = 0; i < N; ++i) proj += V[i][k] * (double)b_[i];
+    for (int i = 0; i < N; ++i) proj += V[i * N + k] * (double)b_[i];
     proj /= lam;
-    for (int i = 0; i < N; ++i) x[i] += V[i][k] * proj;
+    for (int i = 0; i < N; ++i) x[i] += V[i * N + k] * proj;
   }
   for (int i = 0; i < N; ++i) x_[i] = bad ? std::numeric_limits<float>::quiet_NaN() : (float)x[i];
+}
+inline void sym6_pinv_solve(const float* A_, const float* b_, float* x_) {
+  double ws[72];
+  sym6_pinv_solve_ws(A_, b_, x_, ws);
 }
 
 // SVD<6>::backsub stand-in used by the pipeline: for a well-conditioned SPD JtJ (the normal case) the pseudo-inverse
 // IS the inverse, so solve by an LDL^T factorisation in double (~300 flops); if a pivot falls below the 1e9 condition
 // cut relative to the largest diagonal, use the Jacobi pseudo-inverse (minimum-norm solution like the SVD).
-RH_HD inline void sym6_solve(const float* A_, const float* b_, float* x_) {
+// sym6_ldlt_solve returns false (x untouched) when the fall-back is needed.
+RH_HD inline bool sym6_ldlt_solve(const float* A_, const float* b_, float* x_) {
   constexpr int N = 6;
   double L[N][N], d[N], dmax = 0;
   bool ok = true;
   for (int i = 0; i < N; ++i) dmax = (std::fabs((double)A_[i * N + i]) > dmax) ? std::fabs((double)A_[i * N + i]) : dmax;
-  for (int j = 0; j < N && ok; ++j) {
+  for (int j = 0; j < N; ++j) {  // (loop bounds static, `ok` tested inside: the device keeps L and d in registers)
+    if (!ok) continue;
     double v = 0.5 * ((double)A_[j * N + j] + (double)A_[j * N + j]);
     for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * d[k];
     if (!(v * 1e7 > dmax)) ok = false;
     d[j] = v;
-    for (int i = j + 1; i < N && ok; ++i) {
+    for (int i = j + 1; i < N; ++i) {
+      if (!ok) continue;
       double s = 0.5 * ((double)A_[i * N + j] + (double)A_[j * N + i]);
       for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k] * d[k];
       L[i][j] = s / v;
     }
   }
-  if (!ok) {
-    sym6_pinv_solve(A_, b_, x_);
-    return;
-  }
+  if (!ok) return false;
   double y[N], x[N];
   for (int i = 0; i < N; ++i) {
     double s = (double)b_[i];
@@ -348,6 +370,14 @@ RH_HD inline void sym6_solve(const float* A_, const float* b_, float* x_) {
     x[i] = s;
   }
   for (int i = 0; i < N; ++i) x_[i] = (float)x[i];
+  return true;
+}
+RH_HD inline void sym6_solve_ws(const float* A_, const float* b_, float* x_, double* ws72) {
+  if (!sym6_ldlt_solve(A_, b_, x_)) sym6_pinv_solve_ws(A_, b_, x_, ws72);
+}
+inline void sym6_solve(const float* A_, const float* b_, float* x_) {
+  double ws[72];
+  sym6_solve_ws(A_, b_, x_, ws);
 }
 
 // Core::gyroBiasCorrection (core.cpp:264-284); dgbias is zero on entry, as in the reference.

@@ -9,7 +9,7 @@
 // Bound: HBM/L2 gather bandwidth (keyline SoA streams + distance-field / mask / matched-keyline gathers);
 // no dense contraction exists on this path (largest product is 6x6), so MFMA does not apply.
 #include "common.hpp"
-#include "glue.hpp"
+#include "glue_dev.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -910,6 +910,54 @@ __device__ __forceinline__ void chain_collect_records(const unsigned long long* 
   __syncthreads();
 }
 
+__device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const LaneDyn& d, int calls, const GlueParams& gp) {
+  GlueArgs ga;
+  ga.lm = L.lm + calls + 1;
+  ga.xrv = L.xrv_part;
+  ga.st_in = L.gstate + (d.gpar & 1);
+  ga.st_out = L.gstate + ((d.gpar & 1) ^ 1);
+  ga.rec = L.rec[d.slot];
+  ga.gd_copy = L.glue_dev + d.slot;
+  ga.gp = gp;
+  return ga;
+}
+
+// Tail of the persistent LM kernels when the pair's glue runs on the device (ga.lm != null): every workgroup publishes the
+// extRotVel sums of its record groups as tagged words (the exchange of the LM records, one more round), workgroup 0 waits
+// for the groups that hold live keylines of the new map, sums them in group order in double (hm::sum_xrv) and runs the
+// glue (glue_dev.hpp). The other workgroups leave right after publishing. stage: LDS, stage_groups * 32 floats.
+template <int kChainThreads>
+__device__ __forceinline__ void lm_tail_glue(const GlueArgs& ga, unsigned long long* __restrict__ xch_xrv, unsigned tag, int n_new,
+                                             float* stage, int stage_groups, GlueLds& gw, const LmState& s, int* err, int slow) {
+  if (blockIdx.x != 0) return;
+  const int tid = threadIdx.x;
+  const int nb = (n_new + 255) / 256;
+  double acc = 0.0;
+  for (int b0 = 0; b0 < nb; b0 += stage_groups) {
+    const int cnt = min(stage_groups, nb - b0);
+    for (int i = tid; i < cnt * kXrvStride; i += kChainThreads)
+      if ((i & (kXrvStride - 1)) < 27) stage[i] = xch_wait(xch_xrv + (size_t)b0 * kXrvStride + i, tag, err, slow);
+    __syncthreads();
+    if (tid < 27)
+      for (int b = 0; b < cnt; ++b) acc += (double)stage[b * kXrvStride + tid];
+    __syncthreads();
+  }
+  if (tid < 21) {  // upper triangle in row-major order -> both halves of the symmetric matrix
+    int i = 0, base = 0;
+    while (tid >= base + (6 - i)) {
+      base += 6 - i;
+      ++i;
+    }
+    const int j = i + (tid - base);
+    gw.W[i * 6 + j] = (float)acc;
+    gw.W[j * 6 + i] = (float)acc;
+  } else if (tid < 27) {
+    gw.JtF[tid - 21] = (float)acc;
+  }
+  __syncthreads();
+  glue_workgroup(gw, s, ga);
+}
+
 template <int kChainThreads>
 __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, int calls, int do_ext,
                                                             const LmState* __restrict__ st_in, LmState* __restrict__ st_out,
@@ -917,8 +965,9 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
                                                             int* __restrict__ bar_err, const int* __restrict__ hist,
                                                             unsigned frame_count, float* __restrict__ xrv_part,
                                                             PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
-                                                            unsigned long long* __restrict__ stamps, int slow_poll = 0) {
+                                                            unsigned long long* __restrict__ stamps, int slow_poll, const GlueArgs ga) {
   constexpr int kChainGroups = kChainThreads / 256;
+  __shared__ GlueLds gw;
   // optional phase stamps of workgroup 0 (REBVIO_HIP_LM_STAMPS diagnostic): 100 MHz constant clock
 #define RH_STAMP(i) \
   do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1110,15 +1159,24 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
     for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
   }
   __syncthreads();
+  // (both kernels keep the same exchange layout: the extRotVel words follow the speculative kernel's words)
+  unsigned long long* xch_xrv = xch + lm_xch_xrv_offset((size_t)nrec_launched, (size_t)gridDim.x);
   if (tid < kChainGroups * 32) {
     const int g = tid >> 5, k = tid & 31;
     if (k < 28) {
       float acc = 0.f;
       for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
-      xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
+      if (ga.lm)
+        xch_publish(xch_xrv + ((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k, tag_final, acc);
+      else
+        xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
     }
   }
   RH_STAMP(2 + calls * 6);
+  if (ga.lm) {
+    __syncthreads();  // (rec is free: every LM collect is over)
+    lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, rec, kMaxRecBlocks * kPartStride / kXrvStride, gw, s, bar_err, slow_poll);
+  }
 #undef RH_STAMP
 }
 
@@ -1147,9 +1205,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
                                                    LmState* __restrict__ st_out, unsigned long long* __restrict__ xch, unsigned tag_base,
                                                    int* __restrict__ bar_err, const int* __restrict__ hist, unsigned frame_count,
                                                    float* __restrict__ xrv_part, PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
-                                                   unsigned long long* __restrict__ stamps, int slow_poll) {
+                                                   unsigned long long* __restrict__ stamps, int slow_poll, const GlueArgs ga) {
   constexpr int kChainGroups = kChainThreads / 256;
   constexpr int kWaves = kChainThreads / 64;
+  __shared__ GlueLds gw;
   // REBVIO_HIP_LM_STAMPS: 1 start, 2/3 evaluations 0/1 published, 4 hypothesis states ready, speculative evaluations: 5 projected,
   // 6 gathers issued, 7 matches known, 8 neighbour round done, 9 weighted sums done, 10 published; 11 all record sets staged and
   // reduced, 12 hypothesis checked, 13 LM done, 14 extRotVel rows out (stamps[0] = 1 marks the layout)
@@ -1612,16 +1671,26 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
   }
   __syncthreads();
+  unsigned long long* xch_xrv = xch + lm_xch_xrv_offset((size_t)nrec_launched, (size_t)nwg);
   if (tid < kChainGroups * 32) {
     const int g = tid >> 5, k = tid & 31;
     if (k < 28) {
       float acc = 0.f;
       for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
-      xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
+      if (ga.lm)
+        xch_publish(xch_xrv + ((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k, tag_final, acc);
+      else
+        xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
     }
   }
   RH_STAMP(14);
   if (stamps && blockIdx.x == 0 && tid == 0) stamps[0] = 1ull;
+  if (ga.lm) {
+    __syncthreads();  // (recm is free: every LM collect is over)
+    // recm holds (calls - 2) record sets of 16 words per launched group: at least 32 floats per group
+    lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, recm, (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride > 0
+                                    ? (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride : 1, gw, s, bar_err, slow_poll);
+  }
 #undef RH_STAMP
 }
 
@@ -1630,19 +1699,21 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec(KParams p, MapD
                                                                  LmState* __restrict__ st_out, unsigned long long* __restrict__ xch,
                                                                  unsigned tag_base, int* __restrict__ bar_err, const int* __restrict__ hist,
                                                                  float* __restrict__ xrv_part, PairSlot* __restrict__ slot,
-                                                                 int* __restrict__ hist_to_zero, unsigned long long* __restrict__ stamps) {
+                                                                 int* __restrict__ hist_to_zero, unsigned long long* __restrict__ stamps,
+                                                                 GlueArgs ga) {
   lm_chain_spec_body<kChainThreads>(p, om, nm, calls, st_in, st_out, xch, tag_base, bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps,
-                                    0);
+                                    0, ga);
 }
 template <int kChainThreads>
 __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec_b(KParams p, const LaneStatic* __restrict__ ls,
-                                                                   const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll) {
+                                                                   const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll,
+                                                                   GlueParams gp) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
   PairSlot* slot = L.slot[d.slot];
   lm_chain_spec_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls,
                                     L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist,
-                                    nullptr, slow_poll);
+                                    nullptr, slow_poll, lane_glue_args(L, d, calls, gp));
 }
 
 template <int kChainThreads>
@@ -1652,21 +1723,51 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
                                                             int* __restrict__ bar_err, const int* __restrict__ hist,
                                                             unsigned frame_count, float* __restrict__ xrv_part,
                                                             PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
-                                                            unsigned long long* __restrict__ stamps) {
+                                                            unsigned long long* __restrict__ stamps, GlueArgs ga) {
   lm_chain_body<kChainThreads>(p, om, nm, calls, do_ext, st_in, st_out, xch, tag_base, bar_err, hist, frame_count, xrv_part, slot,
-                               hist_to_zero, stamps);
+                               hist_to_zero, stamps, 0, ga);
 }
 // batched form (lane = blockIdx.z): every lane's workgroups exchange records among themselves through the lane's own words
 template <int kChainThreads>
 __global__ __launch_bounds__(kChainThreads) void k_lm_chain_b(KParams p, const LaneStatic* __restrict__ ls,
-                                                              const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll) {
+                                                              const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll,
+                                                              GlueParams gp) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
   PairSlot* slot = L.slot[d.slot];
   lm_chain_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls, 1,
                                L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist, nullptr,
-                               slow_poll);
+                               slow_poll, lane_glue_args(L, d, calls, gp));
 }
+
+// The device glue behind the per-call kernels (REBVIO_HIP_LM=percall): one workgroup; the extRotVel records are in memory
+// (kernel boundary), summed in group order in double like hm::sum_xrv.
+__global__ __launch_bounds__(256) void k_pair_glue(MapDev nm, GlueArgs ga) {
+  __shared__ GlueLds gw;
+  __shared__ LmState s;
+  const int tid = threadIdx.x;
+  if (tid == 0) s = *ga.lm;
+  const int nb = (nm.st->n + 255) / 256;
+  if (tid < 27) {
+    double acc = 0.0;
+    for (int b = 0; b < nb; ++b) acc += (double)ga.xrv[(size_t)b * kXrvStride + tid];
+    if (tid < 21) {
+      int i = 0, base = 0;
+      while (tid >= base + (6 - i)) {
+        base += 6 - i;
+        ++i;
+      }
+      const int j = i + (tid - base);
+      gw.W[i * 6 + j] = (float)acc;
+      gw.W[j * 6 + i] = (float)acc;
+    } else {
+      gw.JtF[tid - 21] = (float)acc;
+    }
+  }
+  __syncthreads();
+  glue_workgroup(gw, s, ga);
+}
+void launch_pair_glue(hipStream_t s, const MapDev& newm, const GlueArgs& ga) { RH_LAUNCH(k_pair_glue, dim3(1), dim3(256), 0, s, newm, ga); }
 
 // ---- EdgeMap::directedMatch / searchMatch (edge_map.cpp:101-218) ----------------------------------------------
 // Probe geometry of one query keyline (edge_map.cpp:104-147): everything up to the probe loop.
@@ -1816,41 +1917,6 @@ constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-
 // queued for pass 2 (a wave with one such lane would otherwise idle 63 lanes for up to 40 more dependent steps).
 // vel / Rvel are already rotated by Rback on the host (:193-194).
 // gd != null: vel / Rvel / Rback / R0 come from *gd (uniform scalar loads) instead of the kernel arguments.
-// The glue of the pair (glue.hpp) in front of the directedMatch head, for the drivers that keep a pair's two halves on the
-// device: every workgroup evaluates it for itself from the LM kernel's records (a kernel boundary lies between them: plain
-// loads), so nothing has to be handed from one workgroup to the others; workgroup 0 also leaves the device copy for the
-// kernels queued behind the head, the filter state after this pair (other parity slot) and the host's record.
-// Returns the record the head reads its inputs from (LDS), or null when the host supplied them as kernel arguments.
-__device__ __forceinline__ const GlueDev* glue_prologue(const GlueArgs& ga, int n_new, GlueDev* s_gl) {
-  if (!ga.lm) return nullptr;
-  if (threadIdx.x == 0) {
-    GlueState st = *ga.st_in;
-    GlueDev gl;
-    rebvio_hip_pair_out out;
-    hm::pair_glue_core(*ga.lm, ga.xrv, n_new, ga.gp, st, gl, out);
-    *s_gl = gl;
-    if (blockIdx.x == 0) {
-      *ga.gd_copy = gl;
-      *ga.st_out = st;
-      ga.rec->out = out;
-      ga.rec->gs = st;
-    }
-  }
-  __syncthreads();
-  return s_gl;
-}
-__device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const LaneDyn& d, int calls, const GlueParams& gp) {
-  GlueArgs ga;
-  ga.lm = L.lm + calls + 1;
-  ga.xrv = L.xrv_part;
-  ga.st_in = L.gstate + (d.gpar & 1);
-  ga.st_out = L.gstate + ((d.gpar & 1) ^ 1);
-  ga.rec = L.rec[d.slot];
-  ga.gd_copy = L.glue_dev + d.slot;
-  ga.gp = gp;
-  return ga;
-}
-
 struct DmArgs {
   Vec3 vel;
   Mat3 Rvel, Rback, R0;
@@ -1884,15 +1950,13 @@ __device__ __forceinline__ DmArgs dm_args(const GlueDev* __restrict__ gd, const 
 
 __device__ __forceinline__ void directed_match_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                        int rot_, Mat3 R0_, const GlueArgs ga) {
+                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid), in flight during the glue
+  const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid)
   const float2 rsq = nm.rs[idx];
   const float2 gq = nm.grad[idx];
   const float gnq = nm.gnorm[idx];
   const int n = nm.st->n;
-  __shared__ GlueDev s_gl;
-  const GlueDev* gd = glue_prologue(ga, n, &s_gl);
   const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
   if (A.skip) return;
   const Vec3& vel = A.vel;
@@ -1986,17 +2050,17 @@ __device__ __forceinline__ void directed_match_body(KParams p, MapDev nm, MapDev
 
 __global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                        int rot_, Mat3 R0_, GlueArgs ga) {
-  directed_match_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, ga);
+                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
+  directed_match_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd);
 }
 __global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
-                                                          LaneDynB dyn, float max_radius, int calls, GlueParams gp) {
+                                                          LaneDynB dyn, float max_radius) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
   directed_match_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
-                      L.dm_work, L.dm_work_n, 1, z9, lane_glue_args(L, d, calls, gp));
+                      L.dm_work, L.dm_work_n, 1, z9, L.glue_dev + d.slot);
 }
 
 // Pass 1, wide form: EIGHT lanes per keyline of the NEW map, one per probe slot of the head (2 * kHeadSteps == 8). The
@@ -2008,20 +2072,17 @@ __global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneS
 // hence the same bits; ~1/6 of the instructions per wave on eight times the waves.
 __device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                          float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                         int rot_, Mat3 R0_, const GlueArgs ga) {
+                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
   static_assert(kHeadSteps == 4, "eight probe slots per keyline");
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int idx = gid >> 3, slot = gid & 7;  // keyline, probe slot (slot = 2 * step + side; side 0: tn, 1: tp)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024), issued before the glue of the pair runs
-  // (streaming / batch drivers: glue_prologue): they are in flight meanwhile
+  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024), issued before the parameter block is read
   const float2 pi = nm.pos_img[idx];
   const float2 rsq = nm.rs[idx];
   const float2 gq = nm.grad[idx];
   const float gnq = nm.gnorm[idx];
   const int n = nm.st->n;
-  __shared__ GlueDev s_gl;
-  const GlueDev* gd = glue_prologue(ga, n, &s_gl);
   const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
   if (A.skip) return;
   bool acc = false, more = false;
@@ -2090,17 +2151,17 @@ __device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDe
 
 __global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                          float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                         int rot_, Mat3 R0_, GlueArgs ga) {
-  directed_match8_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, ga);
+                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
+  directed_match8_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd);
 }
 __global__ __launch_bounds__(256) void k_directed_match8_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
-                                                           LaneDynB dyn, float max_radius, int calls, GlueParams gp) {
+                                                           LaneDynB dyn, float max_radius) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
   directed_match8_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
-                       L.dm_work, L.dm_work_n, 1, z9, lane_glue_args(L, d, calls, gp));
+                       L.dm_work, L.dm_work_n, 1, z9, L.glue_dev + d.slot);
 }
 
 // Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
@@ -2549,29 +2610,29 @@ static bool lm_spec_usable(int kmax, int calls) {
 
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
                      LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
-                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps, int threads) {
+                     PairSlot* slot, int* hist_to_zero, unsigned long long* stamps, int threads, const GlueArgs& ga) {
   const dim3 grid((p.kmax + threads - 1) / threads);
   if (do_ext == 2 && threads <= 512 && lm_spec_usable(p.kmax, calls)) {
     if (threads == 256)
       RH_LAUNCH(k_lm_chain_spec<256>, grid, dim3(256), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out,
-                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
+                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps, ga);
     else
       RH_LAUNCH(k_lm_chain_spec<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out,
-                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps);
+                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps, ga);
     return;
   }
   switch (threads) {
     case 256:
       RH_LAUNCH(k_lm_chain<256>, grid, dim3(256), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
-                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps);
+                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps, ga);
       break;
     case 512:
       RH_LAUNCH(k_lm_chain<512>, grid, dim3(512), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
-                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps);
+                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps, ga);
       break;
     default:
       RH_LAUNCH(k_lm_chain<1024>, grid, dim3(1024), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
-                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps);
+                bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps, ga);
   }
 }
 
@@ -2611,30 +2672,29 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
   const int rot = R0_on_the_fly ? 1 : 0;
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
-  const GlueArgs none{};
   if (dm_head_wide(p.kmax, head_form))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback),
-              max_radius, work, work_n, rot, R0, none);
+              max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr);
   else
     RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
-                       mat3(Rback), max_radius, work, work_n, rot, R0, none);
+                       mat3(Rback), max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
             (const int*)work, (const int*)work_n, rot, R0, (const GlueDev*)nullptr);
 }
 
-// the same two launches with the pair's glue evaluated on the device in front of the head (streaming driver): the head
-// leaves the second half's inputs in *ga.gd_copy, which the tail (and the kernels after it) read
-void launch_directed_match_glue(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueArgs& ga,
-                                float max_radius, int* work, int* work_n, int head_form) {
+// the same two launches with the second half's inputs read from *gd at run time: the record the pair's LM kernel left
+// (device glue, glue_dev.hpp)
+void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
+                               int* work, int* work_n, int head_form) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
   if (dm_head_wide(p.kmax, head_form))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
-              work, work_n, 1, mat3(I), ga);
+              work, work_n, 1, mat3(I), gd);
   else
     RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, work,
-              work_n, 1, mat3(I), ga);
+              work_n, 1, mat3(I), gd);
   RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
-            (const int*)work, (const int*)work_n, 1, mat3(I), (const GlueDev*)ga.gd_copy);
+            (const int*)work, (const int*)work_n, 1, mat3(I), gd);
 }
 
 void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& searched, const rebvio_hip_keyline& q, const float vel[3],
@@ -2663,15 +2723,15 @@ void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m,
 }
 
 void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
-                       int spec) {
+                       int spec, const GlueParams& gp) {
   // 512-thread workgroups (the single-stream default); lanes x 30 workgroups at 16k keylines must all be resident: with one
   // workgroup per CU that holds up to 8 lanes on 256 CUs (rebvio_hip_batch_create checks the bound)
   const int slow_poll = lanes >= 3 ? 1 : 0;
   if (spec && lm_spec_usable(p.kmax, calls))
     RH_LAUNCH(k_lm_chain_spec_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), lm_spec_shm(p.kmax, calls), s, p, ls, maptab,
-              dyn, calls, slow_poll);
+              dyn, calls, slow_poll, gp);
   else
-    RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll);
+    RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll, gp);
 }
 
 // The batched persistent LM kernel needs every workgroup of the launch resident at once (they wait for each other's
@@ -2692,18 +2752,18 @@ int lm_chain_b_max_lanes(int device, int kmax, int calls) {
   return std::max(1, std::min(kMaxLanes, nb * cus / per_lane));
 }
 
-// second half of a batched step: every lane's glue runs in front of its directedMatch head (glue_prologue)
+// second half of a batched step (every lane's inputs come from the record its LM kernel's glue left)
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
-                      float max_radius, int gate, int calls, const GlueParams& gp, int head_form) {
+                      float max_radius, int gate, int head_form) {
   const unsigned z = (unsigned)lanes;
   // head form: eight lanes per keyline is the low-latency form while the chip is mostly idle; from a few lanes on the chip is
   // full and the thread-per-keyline form (an eighth of the waves) is the cheaper one (REBVIO_HIP_BATCH_DM_HEAD=wide|thread,
   // read when the batch is created)
   const bool wide = head_form ? head_form == 2 : (lanes < 4 && p.kmax <= 32768);
   if (wide)
-    RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius, calls, gp);
+    RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   else
-    RH_LAUNCH(k_directed_match_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius, calls, gp);
+    RH_LAUNCH(k_directed_match_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   RH_LAUNCH(k_directed_match_tail_b, dim3(dm_tail_blocks(p.kmax), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
 }

@@ -627,6 +627,71 @@ def test_device_glue_equals_host_glue(B, c2_stream, monkeypatch):
         del last
 
 
+def test_glue_probe_random_inputs(B):
+    """rebvio_hip_test_glue: the device form of the pair glue (glue_dev.hpp: three waves, one column / cofactor per lane) against
+    the host form (glue.hpp: pair_glue_core, one thread) on random inputs - well-conditioned systems, rank-deficient ones (the
+    6x6 solve falls back to the Jacobi pseudo-inverse), zero pivots in the LDL^T inverses, rotations in each branch of
+    SO3::exp (|w|^2 < 1e-8, < 1e-6, larger, beyond pi), NaN inputs. Every output word must agree bit for bit."""
+    ctx = B.Context(B.default_params(96, 128, keylines_ref=3000, keylines_max=4000))
+    rng = np.random.default_rng(11)
+
+    def words(a):
+        return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+    n_fallback = n_nan = 0
+    for trial in range(160):
+        kind = trial % 8
+        n_new = int(rng.integers(1, 4000))
+        nb = (n_new + 255) // 256
+        # extRotVel records: sums of outer products of rows with realistic scales (pixels / focal length / depth)
+        scale = np.array([400.0, 400.0, 200.0, 500.0, 500.0, 300.0], np.float64) * 10.0 ** rng.uniform(-2, 1)
+        rows = rng.standard_normal((nb, 300, 6)) * scale
+        if kind == 1:
+            rows[:, :, 5] = rows[:, :, 4] * 2.0            # rank-deficient: Jacobi pseudo-inverse
+        if kind == 2:
+            rows[:, :, 3:] = 0.0                            # zero rotational block
+        Y = rng.standard_normal((nb, 300)) * 0.3
+        xrv = np.zeros((nb, 32), np.float32)
+        iu = np.triu_indices(6)
+        for b in range(nb):
+            W = rows[b].T @ rows[b]
+            xrv[b, :21] = W[iu]
+            xrv[b, 21:27] = rows[b].T @ Y[b]
+            xrv[b, 27] = 300
+        if kind == 3:
+            xrv[0, 2] = np.nan
+        J = rng.standard_normal((200, 3)) * [300.0, 300.0, 150.0]
+        JtJ = J.T @ J
+        JtJ6 = np.array([JtJ[0, 0], JtJ[1, 1], JtJ[2, 2], JtJ[0, 1], JtJ[0, 2], JtJ[1, 2]], np.float32)
+        vel = (rng.standard_normal(3) * 0.01).astype(np.float32)
+        bg_scale = [1e-5, 3e-4, 1e-2, 1.0][trial % 4]      # SO3::exp branches of the prior rotation
+        Bg = (rng.standard_normal(3) * bg_scale).astype(np.float32)
+        if kind == 4:
+            Bg[:] = 0
+        W_Bg = (np.eye(3) * 10.0 ** rng.uniform(-2, 6) + rng.standard_normal((3, 3)) * 1e-3).astype(np.float32)
+        W_Bg = ((W_Bg + W_Bg.T) / 2).astype(np.float32)
+        from scipy.spatial.transform import Rotation
+        Rp = Rotation.from_rotvec(rng.standard_normal(3) * [1e-3, 1e-2, 0.3][trial % 3]).as_matrix().astype(np.float32)
+        if kind == 5:
+            Y *= 40.0                                       # a large rotation increment (beyond pi/2 after scaling)
+            for b in range(nb):
+                xrv[b, 21:27] = rows[b].T @ Y[b]
+        frame_dt = [0.05, 0.0333333, 0.1][trial % 3]
+        (od, sd, gd), (oh, sh, gh) = ctx.test_glue(vel, JtJ6, float(rng.uniform(1, 1e4)), float(rng.uniform(0.1, 5)), trial & 31, xrv, n_new,
+                                                   frame_dt, Bg, W_Bg, Rp)
+        td, th = pair_tuple(od), pair_tuple(oh)
+        for i, (x, y) in enumerate(zip(td, th)):
+            assert np.array_equal(words(np.atleast_1d(x)), words(np.atleast_1d(y))), (trial, kind, "record field", i, x, y)
+        assert np.array_equal(words(sd), words(sh)), (trial, kind, "state", sd, sh)
+        assert np.array_equal(words(gd), words(gh)), (trial, kind, "second half", gd, gh)
+        n_nan += int(oh.status == 1)
+        if kind == 1:
+            n_fallback += 1
+            assert np.isfinite(np.array(oh.Xv)).all() or oh.ext_ok == 0
+    assert n_fallback >= 15 and n_nan >= 15
+    ctx.close()
+
+
 def test_speculative_lm_kernel_rolls_back_when_a_later_step_is_accepted(B, monkeypatch):
     """The default persistent kernel evaluates minimizeVel's evaluations 2.. in one pass under the hypothesis that all of
     them are rejected (what consecutive frames do: accept mask 00001), checks the hypothesis with the real scores and
