@@ -258,10 +258,11 @@ int rebvio_hip_track_pair_hint_next(rebvio_hip_ctx* ctx, rebvio_hip_map* next_ne
  * (6x6 solve, gyroBiasCorrection, SO3, covariance: rebvio.cpp:177-233 without the accelerometer branch) is evaluated in front
  * of the directedMatch kernel from the first half's records, with the gyro-bias state kept in device memory, so the host only
  * queues launches and reads records. `out` receives the oldest COMPLETE pair not handed out yet, in pair order, several calls
- * behind `frame` (the detect stage leads the tracker by REBVIO_HIP_LEAD frames, default 5; a pair's match counters arrive with
- * the next pair; up to seven pairs are in flight between the device and the host); status -1 while there is none.
- * rebvio_hip_flush() finishes the pairs in flight and drops the frames no pair was started for; the records it completes (and
- * any others not handed out yet) are fetched with rebvio_hip_next_record: 1 = *out / *keylines filled, 0 = none left.
+ * behind `frame` (the detect stage leads the tracker by REBVIO_HIP_LEAD frames, default 5; pairs are queued on the track stream
+ * in groups of REBVIO_HIP_GROUP, default 4, with one stream wait and one event per group; a pair's match counters arrive with
+ * the next pair; up to fifteen pairs are in flight between the device and the host); status -1 while there is none.
+ * rebvio_hip_flush() tracks the pairs not started yet and finishes everything in flight: a stream of n frames yields n - 1
+ * records; those not handed out by a push are fetched with rebvio_hip_next_record: 1 = *out / *keylines filled, 0 = none left.
  * rebvio_hip_get_gyro_state follows the stream with that lag and is exact after a flush; rebvio_hip_set_gyro_state is refused
  * (-7) while frames are in flight. */
 int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_dev, uint64_t ts_us,

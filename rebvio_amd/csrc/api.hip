@@ -169,6 +169,7 @@ struct rebvio_hip_map {
   hipEvent_t detected{};  // keylines + mask + chaining finished (detect stream)
   hipEvent_t ready{};     // ... and distance field built (distance-field stream)
   hipEvent_t done{};   // last track-stream consumer finished, recorded at release
+  hipEvent_t done_ref{};  // ... or (streaming driver) the result-slot event of the pair that used the map last: no packet of its own
   bool has_done = false;
   uint64_t release_seq = 0;  // order of release (pool reuse is oldest-first)
   bool df_built = false;
@@ -272,9 +273,11 @@ struct rebvio_hip_ctx {
   GlueState* h_gstate = nullptr;  // [2] pinned staging for the upload in front of a stream's first pair
   hm::M3 gs_R{};                  // host mirror of the device state's prior rotation (with Bg / W_Bg above)
   int lead = 5;                   // detected frames queued when a pair is started (REBVIO_HIP_LEAD 3..12, see push_frame)
+  int group = 4;                  // pairs queued together (REBVIO_HIP_GROUP 1..6, see stream_enqueue_group)
   struct InFlight {               // a pair whose kernels are queued and whose record has not been read yet
     rebvio_hip_map* nm = nullptr;
     int slot = -1;
+    int ev_slot = -1;             // the slot whose event stands for this pair's completion (its group's last pair)
     float frame_dt = 0.f;
   };
   struct Done {                   // a complete record waiting to be handed to the caller
@@ -322,7 +325,7 @@ struct rebvio_hip_ctx {
 };
 
 namespace {
-void release_map(rebvio_hip_map* m);
+void release_map(rebvio_hip_map* m, hipEvent_t done_ref);
 
 // A map handle whose context has been destroyed: every entry point that takes a map alone answers with this.
 inline bool map_dead(const rebvio_hip_map* m) { return !m || !m->life || m->life->dead.load(std::memory_order_acquire); }
@@ -526,7 +529,7 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
   HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
   launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2);
-  if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done, 0));
+  if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done_ref ? m->done_ref : m->done, 0));
   launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev_flag[b], c->s_key));  // (after join: coarser than needed, same stream order)
@@ -712,7 +715,7 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
     // only if it is monotonic and spans less than a millisecond
     const bool spec = c->lm_stamps[0] == 1ull;  // k_lm_chain_spec: stamps 1..14, [0] is a marker
     const int i0 = spec ? 1 : 0;
-    const int ns = spec ? 15 : 3 + calls * 6;
+    const int ns = spec ? 16 : 3 + calls * 6;
     unsigned long long snap[64];
     for (int i = 0; i < ns; ++i) snap[i] = c->lm_stamps[i];
     bool sane = snap[ns - 1] > snap[i0] && snap[ns - 1] - snap[i0] < 100000ull;
@@ -1004,6 +1007,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMemset(c->gstate, 0, 2 * sizeof(GlueState)));
   HIPCHK(hipHostMalloc(&c->h_gstate, 2 * sizeof(GlueState), hipHostMallocDefault));
   if (const char* l = std::getenv("REBVIO_HIP_LEAD")) c->lead = std::min(12, std::max(3, std::atoi(l)));
+  if (const char* g = std::getenv("REBVIO_HIP_GROUP")) c->group = std::min(6, std::max(1, std::atoi(g)));
   if (const char* e = std::getenv("REBVIO_HIP_LM_THREADS")) {
     const int v = std::atoi(e);
     if (v == 256 || v == 512 || v == 1024) c->lm_threads = v;
@@ -1304,7 +1308,7 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
     if (m->in_use) delete m;
     return;
   }
-  release_map(m);
+  release_map(m, nullptr);
 }
 
 }  // extern "C"
@@ -1312,7 +1316,8 @@ void rebvio_hip_map_release(rebvio_hip_map* m) {
 namespace {
 // Stream-ordered return of a map to its pool (the library's own releases call this directly; the C-ABI entry adds the
 // lifetime check).
-void release_map(rebvio_hip_map* m) {
+// done_ref: an event already recorded behind the map's last consumer (null: one is recorded here).
+void release_map(rebvio_hip_map* m, hipEvent_t done_ref = nullptr) {
   if (!m || !m->in_use) return;
   rebvio_hip_ctx* c = m->ctx;
   (void)hipSetDevice(c->device);
@@ -1325,7 +1330,8 @@ void release_map(rebvio_hip_map* m) {
         hipEventRecord(c->bf_done[r], c->s_trk) == hipSuccess)
       c->bf_copy_queued[r] = true;
   }
-  (void)hipEventRecord(m->done, c->s_trk);
+  m->done_ref = done_ref;
+  if (!done_ref) (void)hipEventRecord(m->done, c->s_trk);
   m->has_done = true;
   if (c->df_map == m) c->df_map = nullptr;
   m->release_seq = ++c->release_counter;
@@ -1838,18 +1844,6 @@ namespace {
 // read from the NEXT pair's slot (its first kernel copies its old map's state record), so pair k is reported once pair
 // k + 1's event has fired; rebvio_hip_flush() fetches the last pair's counters itself.
 
-// Every stream operation between two kernels of the track stream is a packet of its own for the command processor, so a map
-// is waited for once (the old map of a pair was the new map of the previous one).
-int stream_wait_maps(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm) {
-  for (rebvio_hip_map* m : {om, nm}) {
-    if (m->trk_waited) continue;
-    wait_enqueued(m);
-    HIPCHK(trk_wait_ready(c->s_trk, m));
-    m->trk_waited = true;
-  }
-  return 0;
-}
-
 void stream_finish_record(rebvio_hip_ctx* c, const rebvio_hip_ctx::InFlight& a, const MapState& st) {
   const GlueRec* r = c->rec[a.slot];
   rebvio_hip_ctx::Done d;
@@ -1877,10 +1871,10 @@ int stream_harvest(rebvio_hip_ctx* c, int need) {
     const rebvio_hip_ctx::InFlight& b = c->inflight[1];
     if (need > 0) {
       const auto t0 = std::chrono::steady_clock::now();
-      HIPCHK(hipEventSynchronize(c->slot_ev[b.slot]));
+      HIPCHK(hipEventSynchronize(c->slot_ev[b.ev_slot]));
       c->t_wait += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     } else {
-      const hipError_t q = hipEventQuery(c->slot_ev[b.slot]);
+      const hipError_t q = hipEventQuery(c->slot_ev[b.ev_slot]);
       if (q == hipErrorNotReady) break;
       HIPCHK(q);
     }
@@ -1892,62 +1886,91 @@ int stream_harvest(rebvio_hip_ctx* c, int need) {
   return 0;
 }
 
-int stream_enqueue_pair(rebvio_hip_ctx* c) {
+// `npairs` consecutive pairs (frames[0..npairs]) as ONE group on the track stream. Every stream operation between two
+// kernels is a packet of its own for the command processor, and with the kernels queued back to back those packets are what
+// is left between them (measured with in-kernel stamps: ~6 us per event record / event wait on the pair-to-pair path). A group
+// carries two of them whatever its size: one wait for the detection of its NEWEST map (the keyline stream is in order, so the
+// maps before it are ready too) and one event behind its last kernel, which stands for every pair's completion and for the
+// release of every old map.
+int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
   // the slot of pair k is reused by pair k + kSlots: its record (and its successor's) must have been read
-  while ((int)c->inflight.size() >= rebvio_hip_ctx::kSlots - 1) {
+  while ((int)c->inflight.size() + npairs > rebvio_hip_ctx::kSlots - 1) {
     const int rc = stream_harvest(c, 1);
     if (rc) return rc;
   }
-  rebvio_hip_map *om = c->frames[0], *nm = c->frames[1];
   hipStream_t s = c->s_trk;
-  int rc = stream_wait_maps(c, om, nm);
-  if (rc) return rc;
-  c->df_map = nm;
-  const int slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
-  const int gpar = (int)(c->pair_seq & 1);
-  if (!om->pre_rotated) {
-    // first pair of a stream (or after a flush): no second half has applied the prior rotation yet, and the filter state the
-    // device works on is the host's
-    const hm::M3 R = prior_rotation(c, nullptr);
-    GlueState& gs = c->h_gstate[gpar];
-    for (int i = 0; i < 3; ++i) gs.Bg[i] = c->Bg[i];
-    hm::store3(c->W_Bg, gs.W_Bg);
-    hm::store3(R, gs.R);
-    gs.pad = 0.f;
-    HIPCHK(hipMemcpyAsync(c->gstate + gpar, &gs, sizeof(GlueState), hipMemcpyHostToDevice, s));
-    float RT[9];
-    hm::store3(hm::transpose(R), RT);
-    launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+  if (!c->frames[0]->trk_waited) {  // first group of a stream
+    wait_enqueued(c->frames[0]);
+    HIPCHK(trk_wait_ready(s, c->frames[0]));
+    c->frames[0]->trk_waited = true;
   }
-  const float v0[3] = {0, 0, 0};
-  const float frame_dt = (float)((double)(float)(nm->ts - om->ts) / 1000000.0);  // rebvio.cpp:183
-  const int calls = (int)c->P.iterations + 1;
-  GlueArgs ga;
-  ga.lm = c->lm + calls + 1;
-  ga.xrv = c->xrv_part;
-  ga.st_in = c->gstate + gpar;
-  ga.st_out = c->gstate + (gpar ^ 1);
-  ga.rec = c->rec[slot];
-  ga.gd_copy = c->glue_dev + slot;
-  ga.gp = glue_params(c, frame_dt);
-  rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part, ga);  // rebvio.cpp:167-177 + the glue of rebvio.cpp:177-233
-  if (rc) return rc;
-  launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
-  const int gate = (int)c->P.global_min_matches_threshold;
-  launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
-  std::swap(nm->d.rs, nm->d.rs_tmp);
-  std::swap(nm->d.grad, nm->d.grad_tmp);
-  nm->pre_rotated = true;
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->slot_ev[slot], s));
-  release_map(om);  // stream-ordered: reusable once this pair has drained
-  rebvio_hip_ctx::InFlight f;
-  f.nm = nm;
-  f.slot = slot;
-  f.frame_dt = frame_dt;
-  c->inflight.push_back(f);
-  c->frames.erase(c->frames.begin());
-  c->pair_seq++;
+  {
+    rebvio_hip_map* newest = c->frames[(size_t)npairs];
+    wait_enqueued(newest);  // (the detect worker launches in order: the maps before it are enqueued too)
+    HIPCHK(trk_wait_ready(s, newest));
+    for (int g = 1; g <= npairs; ++g) {
+      c->frames[(size_t)g]->trk_waited = true;
+      if (g < npairs) {  // (as trk_wait_ready does for the map it is given)
+        std::lock_guard<std::mutex> dl(c->dl_mu);
+        c->frames[(size_t)g]->trk_touched.store(true, std::memory_order_release);
+      }
+    }
+  }
+  int last_slot = -1;
+  for (int g = 0; g < npairs; ++g) {
+    rebvio_hip_map *om = c->frames[(size_t)g], *nm = c->frames[(size_t)g + 1];
+    c->df_map = nm;
+    const int slot = (int)(c->pair_seq % rebvio_hip_ctx::kSlots);
+    const int gpar = (int)(c->pair_seq & 1);
+    if (!om->pre_rotated) {
+      // first pair of a stream (or after a flush): no second half has applied the prior rotation yet, and the filter state
+      // the device works on is the host's
+      const hm::M3 R = prior_rotation(c, nullptr);
+      GlueState& gs = c->h_gstate[gpar];
+      for (int i = 0; i < 3; ++i) gs.Bg[i] = c->Bg[i];
+      hm::store3(c->W_Bg, gs.W_Bg);
+      hm::store3(R, gs.R);
+      gs.pad = 0.f;
+      HIPCHK(hipMemcpyAsync(c->gstate + gpar, &gs, sizeof(GlueState), hipMemcpyHostToDevice, s));
+      float RT[9];
+      hm::store3(hm::transpose(R), RT);
+      launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+    }
+    const float v0[3] = {0, 0, 0};
+    const float frame_dt = (float)((double)(float)(nm->ts - om->ts) / 1000000.0);  // rebvio.cpp:183
+    const int calls = (int)c->P.iterations + 1;
+    GlueArgs ga;
+    ga.lm = c->lm + calls + 1;
+    ga.xrv = c->xrv_part;
+    ga.st_in = c->gstate + gpar;
+    ga.st_out = c->gstate + (gpar ^ 1);
+    ga.rec = c->rec[slot];
+    ga.gd_copy = c->glue_dev + slot;
+    ga.gp = glue_params(c, frame_dt);
+    int rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part, ga);  // rebvio.cpp:167-177 + the glue of rebvio.cpp:177-233
+    if (rc) return rc;
+    launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
+    const int gate = (int)c->P.global_min_matches_threshold;
+    launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
+    std::swap(nm->d.rs, nm->d.rs_tmp);
+    std::swap(nm->d.grad, nm->d.grad_tmp);
+    nm->pre_rotated = true;
+    HIPCHK(hipGetLastError());
+    rebvio_hip_ctx::InFlight f;
+    f.nm = nm;
+    f.slot = slot;
+    f.ev_slot = -1;
+    f.frame_dt = frame_dt;
+    c->inflight.push_back(f);
+    last_slot = slot;
+    c->pair_seq++;
+  }
+  HIPCHK(hipEventRecord(c->slot_ev[last_slot], s));
+  for (int g = 0; g < npairs; ++g) {
+    c->inflight[c->inflight.size() - 1 - (size_t)g].ev_slot = last_slot;
+    release_map(c->frames[(size_t)g], c->slot_ev[last_slot]);  // stream-ordered: reusable once the group has drained
+  }
+  c->frames.erase(c->frames.begin(), c->frames.begin() + npairs);
   return 0;
 }
 
@@ -1957,7 +1980,7 @@ int stream_drain(rebvio_hip_ctx* c) {
   if (rc) return rc;
   if (c->inflight.size() == 1) {  // the last pair has no successor to carry its counters
     const rebvio_hip_ctx::InFlight a = c->inflight[0];
-    HIPCHK(hipEventSynchronize(c->slot_ev[a.slot]));
+    HIPCHK(hipEventSynchronize(c->slot_ev[a.ev_slot]));
     if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
     HIPCHK(hipMemcpyAsync(&c->h_st[1], a.nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
     HIPCHK(hipStreamSynchronize(c->s_trk));
@@ -1998,9 +2021,9 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   c->t_detect_enq += std::chrono::duration<double, std::micro>(td1 - td0).count();
   c->t_frames++;
   c->frames.push_back(m);
-  if ((int)c->frames.size() >= c->lead) {
-    // frames[1] was detected at least lead - 2 calls ago: the track stream will not stall on it
-    rc = stream_enqueue_pair(c);
+  if ((int)c->frames.size() >= c->lead + c->group - 1) {
+    // the newest map of the group was detected at least lead - 2 calls ago: the track stream will not stall on it
+    rc = stream_enqueue_group(c, c->group);
     if (rc) return rc;
   }
   c->t_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td1).count();
@@ -2030,9 +2053,12 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     std::fprintf(stderr,
                  "[rebvio_hip] k_lm_chain_spec workgroup 0, mean us over %llu launches: eval0 %.2f  eval1 %.2f  collect+states %.2f  "
                  "speculative evals [project %.2f  issue gathers %.2f  match %.2f  neighbour round %.2f  weighted sums %.2f  publish %.2f]  "
-                 "collect all %.2f  check %.2f  finish %.2f  forwardMatch+extRotVel %.2f\n",
+                 "collect all %.2f  check %.2f  finish %.2f  forwardMatch+extRotVel %.2f  collect sums + device glue %.2f\n",
                  (unsigned long long)c->lm_stamp_n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, a[8] / n, a[9] / n, a[10] / n,
-                 a[11] / n, a[12] / n, a[13] / n, a[14] / n);
+                 a[11] / n, a[12] / n, a[13] / n, a[14] / n, a[15] / n);
+    if (c->lm_stamps[41])
+      std::fprintf(stderr, "[rebvio_hip] end of an LM launch -> start of the next (second half of the pair + stream operations), mean over %llu: %.2f us\n",
+                   (unsigned long long)c->lm_stamps[41], (double)c->lm_stamps[40] * 0.01 / (double)c->lm_stamps[41]);
   } else if (c->lm_stamps && c->lm_stamp_n) {
     const int calls = (int)c->P.iterations + 1;
     std::fprintf(stderr, "[rebvio_hip] k_lm_chain workgroup 0, mean us per segment over %llu launches\n", (unsigned long long)c->lm_stamp_n);
@@ -2054,9 +2080,12 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
                  c->t_detect_enq / n, c->t_enq / n, c->t_wait / n, c->t_queued / n);
   }
   while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
-  int rc = stream_drain(c);
+  int rc = 0;
+  while (rc == 0 && c->frames.size() >= 2)  // the pairs no group was started for yet
+    rc = stream_enqueue_group(c, std::min(c->group, (int)c->frames.size() - 1));
+  if (rc == 0) rc = stream_drain(c);
   for (auto* m : c->frames)
-    if (m->in_use) release_map(m);
+    if (m->in_use) release_map(m, nullptr);
   c->frames.clear();
   // The last second half binned the sigma histogram for a pair that will not come (its next-rotation rides in the last
   // kernel): a stream that continues after the flush must not find those counts under its first pair's (they put the
@@ -2251,6 +2280,7 @@ struct rebvio_hip_batch {
   struct InFlight {  // a step's pairs (one per lane) whose kernels are queued and whose records have not been read yet
     Frame nf;
     int slot = -1;
+    int ev_slot = -1;  // the slot whose event stands for this step's completion (its group's last step)
   };
   struct Done {
     std::vector<rebvio_hip_pair_out> out;
@@ -2260,6 +2290,7 @@ struct rebvio_hip_batch {
   std::deque<Done> done;
   uint64_t pair_seq = 0;
   int lead = 4;
+  int group = 2;          // steps queued together (REBVIO_HIP_BATCH_GROUP 1..4, see stream_enqueue_group)
   int dm_head_form = 0;   // REBVIO_HIP_BATCH_DM_HEAD: 0 by lane count, 1 thread per keyline, 2 eight lanes per keyline
   bool poisoned = false;  // a step failed half way (some lanes prepared, others not): every later call is refused
   // detect-enqueue worker: launches the detect stage of a step while the caller thread launches the track stage (the
@@ -2297,11 +2328,14 @@ inline unsigned map_swap_bits(const rebvio_hip_map* m) { return (m->d.rs != m->c
 
 // a map of a batch goes back to its lane's pool; only the last lane's release is marked in the stream (the releases of a
 // step sit at one point of the track stream, and the detect stage waits for that one event)
-void batch_release_map(rebvio_hip_map* m, bool record_done) {
+void batch_release_map(rebvio_hip_map* m, bool record_done, hipEvent_t done_ref = nullptr) {
   if (!m || !m->in_use) return;
   rebvio_hip_ctx* c = m->ctx;
   wait_enqueued(m);
-  if (record_done) {
+  m->done_ref = done_ref;
+  if (done_ref) {
+    m->has_done = true;  // (the step's slot event, already recorded behind the maps' last consumer)
+  } else if (record_done) {
     (void)hipEventRecord(m->done, c->s_trk);
     m->has_done = true;
   }
@@ -2383,9 +2417,9 @@ int batch_harvest(rebvio_hip_batch* b, int need) {
     const rebvio_hip_batch::InFlight& a = b->inflight[0];
     const rebvio_hip_batch::InFlight& n = b->inflight[1];
     if (need > 0) {
-      HIPCHK(hipEventSynchronize(b->slot_ev[n.slot]));
+      HIPCHK(hipEventSynchronize(b->slot_ev[n.ev_slot]));
     } else {
-      const hipError_t q = hipEventQuery(b->slot_ev[n.slot]);
+      const hipError_t q = hipEventQuery(b->slot_ev[n.ev_slot]);
       if (q == hipErrorNotReady) break;
       HIPCHK(q);
     }
@@ -2400,73 +2434,86 @@ int batch_harvest(rebvio_hip_batch* b, int need) {
   return 0;
 }
 
-// one step's pairs, all lanes: [rotate +] LM kernel, directedMatch head with every lane's glue in its prologue, tail,
-// regularize / EKF / next rotation, one event
-int batch_enqueue_pair(rebvio_hip_batch* b) {
-  while ((int)b->inflight.size() >= rebvio_hip_ctx::kSlots - 1) {
+// `nsteps` consecutive steps' pairs, all lanes, as one group on the track stream (see stream_enqueue_group): per step [rotate +]
+// LM kernel with every lane's glue at its end, directedMatch head, tail, regularize / EKF / next rotation; per group one wait
+// for the newest step's detection and one event
+int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
+  while ((int)b->inflight.size() + nsteps > rebvio_hip_ctx::kSlots - 1) {
     const int rc = batch_harvest(b, 1);
     if (rc) return rc;
   }
   hipStream_t s = b->st.s_trk;
-  const rebvio_hip_batch::Frame of = b->frames[0], nf = b->frames[1];
-  while (b->det_done_steps.load(std::memory_order_acquire) <= nf.step) std::this_thread::yield();  // its event has been recorded
-  HIPCHK(hipStreamWaitEvent(s, b->ev_ready[nf.step % rebvio_hip_batch::kReadyRing], 0));  // (the old frame's step is earlier: same stream order)
-  const int slot = (int)(b->pair_seq % rebvio_hip_ctx::kSlots);
-  const int gpar = (int)(b->pair_seq & 1);
-  LaneDynB dyn{};
+  {
+    const uint64_t newest = b->frames[(size_t)nsteps].step;
+    while (b->det_done_steps.load(std::memory_order_acquire) <= newest) std::this_thread::yield();  // its event has been recorded
+    HIPCHK(hipStreamWaitEvent(s, b->ev_ready[newest % rebvio_hip_batch::kReadyRing], 0));  // (earlier steps: same stream order)
+  }
   const int calls = (int)b->P.iterations + 1;
-  for (int l = 0; l < b->B; ++l) {
-    rebvio_hip_ctx* c = b->lane[l];
-    rebvio_hip_map *om = of.m[l], *nm = nf.m[l];
-    c->df_map = nm;
-    if (!om->pre_rotated) {  // first pair of the lane: no second half has applied the prior rotation yet; the host's state goes up
-      const hm::M3 R = prior_rotation(c, nullptr);
-      GlueState& gs = c->h_gstate[gpar];
-      for (int i = 0; i < 3; ++i) gs.Bg[i] = c->Bg[i];
-      hm::store3(c->W_Bg, gs.W_Bg);
-      hm::store3(R, gs.R);
-      gs.pad = 0.f;
-      HIPCHK(hipMemcpyAsync(c->gstate + gpar, &gs, sizeof(GlueState), hipMemcpyHostToDevice, s));
-      float RT[9];
-      hm::store3(hm::transpose(R), RT);
-      launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+  int last_slot = -1;
+  std::vector<rebvio_hip_batch::Frame> olds;
+  for (int g = 0; g < nsteps; ++g) {
+    const rebvio_hip_batch::Frame of = b->frames[0], nf = b->frames[1];
+    const int slot = (int)(b->pair_seq % rebvio_hip_ctx::kSlots);
+    const int gpar = (int)(b->pair_seq & 1);
+    LaneDynB dyn{};
+    for (int l = 0; l < b->B; ++l) {
+      rebvio_hip_ctx* c = b->lane[l];
+      rebvio_hip_map *om = of.m[l], *nm = nf.m[l];
+      c->df_map = nm;
+      if (!om->pre_rotated) {  // first pair of the lane: no second half has applied the prior rotation yet; the host's state goes up
+        const hm::M3 R = prior_rotation(c, nullptr);
+        GlueState& gs = c->h_gstate[gpar];
+        for (int i = 0; i < 3; ++i) gs.Bg[i] = c->Bg[i];
+        hm::store3(c->W_Bg, gs.W_Bg);
+        hm::store3(R, gs.R);
+        gs.pad = 0.f;
+        HIPCHK(hipMemcpyAsync(c->gstate + gpar, &gs, sizeof(GlueState), hipMemcpyHostToDevice, s));
+        float RT[9];
+        hm::store3(hm::transpose(R), RT);
+        launch_rotate(s, c->K, om->d, RT, c->hist, 0);
+      }
+      LaneDyn& d = dyn.v[l];
+      d.nm = (short)nm->tab_idx;
+      d.om = (short)om->tab_idx;
+      d.nm_swap = (unsigned char)map_swap_bits(nm);
+      d.om_swap = (unsigned char)map_swap_bits(om);
+      d.slot = (unsigned char)slot;
+      d.gpar = (unsigned char)gpar;
+      d.tag_base = c->lm_tag_base;
+      c->lm_tag_base += 2u * ((unsigned)calls + 1u);
+      if (c->lm_tag_base > 0xFFFFFF00u) {
+        (void)hipMemsetAsync(c->lm_xch, 0, lm_xch_words(c->maxblocks) * sizeof(unsigned long long), s);
+        c->lm_tag_base = 0;
+      }
     }
-    LaneDyn& d = dyn.v[l];
-    d.nm = (short)nm->tab_idx;
-    d.om = (short)om->tab_idx;
-    d.nm_swap = (unsigned char)map_swap_bits(nm);
-    d.om_swap = (unsigned char)map_swap_bits(om);
-    d.slot = (unsigned char)slot;
-    d.gpar = (unsigned char)gpar;
-    d.tag_base = c->lm_tag_base;
-    c->lm_tag_base += 2u * ((unsigned)calls + 1u);
-    if (c->lm_tag_base > 0xFFFFFF00u) {
-      (void)hipMemsetAsync(c->lm_xch, 0, lm_xch_words(c->maxblocks) * sizeof(unsigned long long), s);
-      c->lm_tag_base = 0;
+    bool spec_now = b->lane[0]->lm_spec;  // one launch for all lanes: speculative while every lane's recent miss rate allows it
+    if (spec_now && !b->lane[0]->lm_spec_forced)
+      for (auto* c : b->lane) spec_now = spec_now && c->lm_miss_ema < 0.17f;
+    const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
+    launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0, glue_params(b->lane[0], frame_dt));
+    const int gate = (int)b->P.global_min_matches_threshold;
+    launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);
+    HIPCHK(hipGetLastError());
+    for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
+      rebvio_hip_map* nm = nf.m[l];
+      std::swap(nm->d.rs, nm->d.rs_tmp);
+      std::swap(nm->d.grad, nm->d.grad_tmp);
+      nm->pre_rotated = true;
     }
+    rebvio_hip_batch::InFlight f;
+    f.nf = nf;
+    f.slot = slot;
+    f.ev_slot = -1;
+    b->inflight.push_back(f);
+    olds.push_back(of);
+    b->frames.pop_front();
+    b->pair_seq++;
+    last_slot = slot;
   }
-  bool spec_now = b->lane[0]->lm_spec;  // one launch for all lanes: speculative while every lane's recent miss rate allows it
-  if (spec_now && !b->lane[0]->lm_spec_forced)
-    for (auto* c : b->lane) spec_now = spec_now && c->lm_miss_ema < 0.17f;
-  const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
-  launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0, glue_params(b->lane[0], frame_dt));
-  const int gate = (int)b->P.global_min_matches_threshold;
-  launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);
-  HIPCHK(hipGetLastError());
-  for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
-    rebvio_hip_map* nm = nf.m[l];
-    std::swap(nm->d.rs, nm->d.rs_tmp);
-    std::swap(nm->d.grad, nm->d.grad_tmp);
-    nm->pre_rotated = true;
-    batch_release_map(of.m[l], l == b->B - 1);
-  }
-  HIPCHK(hipEventRecord(b->slot_ev[slot], s));
-  rebvio_hip_batch::InFlight f;
-  f.nf = nf;
-  f.slot = slot;
-  b->inflight.push_back(f);
-  b->frames.pop_front();
-  b->pair_seq++;
+  HIPCHK(hipEventRecord(b->slot_ev[last_slot], s));
+  for (int g = 0; g < nsteps; ++g) b->inflight[b->inflight.size() - 1 - (size_t)g].ev_slot = last_slot;
+  for (auto& of : olds)
+    for (auto* m : of.m) batch_release_map(m, false, b->slot_ev[last_slot]);  // the group's one event covers every old map
   return 0;
 }
 
@@ -2475,7 +2522,7 @@ int batch_drain(rebvio_hip_batch* b) {
   if (rc) return rc;
   if (b->inflight.size() == 1) {  // the last step has no successor to carry its counters
     const rebvio_hip_batch::InFlight a = b->inflight[0];
-    HIPCHK(hipEventSynchronize(b->slot_ev[a.slot]));
+    HIPCHK(hipEventSynchronize(b->slot_ev[a.ev_slot]));
     std::vector<MapState> st((size_t)b->B);
     for (int l = 0; l < b->B; ++l) {
       if (*b->lane[l]->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
@@ -2629,6 +2676,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   for (auto& e : b->ev_ready) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : b->slot_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_LEAD")) b->lead = std::min(8, std::max(3, std::atoi(e)));
+  if (const char* e = std::getenv("REBVIO_HIP_BATCH_GROUP")) b->group = std::min(4, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_DM_HEAD"))
     b->dm_head_form = std::strcmp(e, "thread") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
   HIPCHK(hipDeviceSynchronize());
@@ -2724,7 +2772,7 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   job.par = par;
   job.step = b->step;
   // maps are released in lane order at one point of the track stream: the last lane's event covers all of them
-  job.reuse_done = (last_reused && last_reused->has_done) ? last_reused->done : nullptr;
+  job.reuse_done = (last_reused && last_reused->has_done) ? (last_reused->done_ref ? last_reused->done_ref : last_reused->done) : nullptr;
   job.maps = fr.m;
   job.lens = b->lens;
   for (auto* m : fr.m) m->enqueued.store(0, std::memory_order_relaxed);
@@ -2738,8 +2786,8 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   b->step++;
 
   // ---- track stage: the step's pairs, whole, for every lane; then whatever records have become complete ----
-  if ((int)b->frames.size() >= b->lead) {
-    const int rc = batch_enqueue_pair(b);
+  if ((int)b->frames.size() >= b->lead + b->group - 1) {
+    const int rc = batch_enqueue_group(b, b->group);
     if (rc) {
       b->poisoned = true;
       return rc;
@@ -2756,7 +2804,10 @@ int rebvio_hip_batch_next_records(rebvio_hip_batch* b, rebvio_hip_pair_out* out,
 int rebvio_hip_batch_flush(rebvio_hip_batch* b) {
   HIPCHK(hipSetDevice(b->device));
   while (b->det_done_steps.load(std::memory_order_acquire) < b->step) std::this_thread::yield();
-  const int rc = batch_drain(b);
+  int rc = 0;
+  while (rc == 0 && b->frames.size() >= 2)  // the steps no group was started for yet
+    rc = batch_enqueue_group(b, std::min(b->group, (int)b->frames.size() - 1));
+  if (rc == 0) rc = batch_drain(b);
   for (auto& f : b->frames)
     for (size_t l = 0; l < f.m.size(); ++l) batch_release_map(f.m[l], l + 1 == f.m.size());
   b->frames.clear();

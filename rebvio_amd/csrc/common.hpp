@@ -264,7 +264,7 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // tables: LaneStatic (device memory, fixed for the life of the lane: its scratch buffers) and the lane's map table
 // (device memory, one MapDev per pooled edge map), plus a small by-value LaneDyn per launch (which maps, which ring slots).
 constexpr int kMaxLanes = 16;
-constexpr int kPairSlots = 8;  // result slots of the streaming / batch drivers: pairs in flight between the device and the host
+constexpr int kPairSlots = 16;  // result slots of the streaming / batch drivers: pairs in flight between the device and the host
 constexpr int kLaneMaps = 24;  // map-table entries per lane (the batch driver bounds its pool by this)
 struct LaneStatic {
   float* sa[2];   // scan buffer A per filter

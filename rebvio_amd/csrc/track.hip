@@ -935,8 +935,24 @@ __device__ __forceinline__ void lm_tail_glue(const GlueArgs& ga, unsigned long l
   double acc = 0.0;
   for (int b0 = 0; b0 < nb; b0 += stage_groups) {
     const int cnt = min(stage_groups, nb - b0);
-    for (int i = tid; i < cnt * kXrvStride; i += kChainThreads)
-      if ((i & (kXrvStride - 1)) < 27) stage[i] = xch_wait(xch_xrv + (size_t)b0 * kXrvStride + i, tag, err, slow);
+    // a thread's words are polled TOGETHER (one memory round trip per round whatever their number, see xch_wait_many)
+    for (int i0 = 0; i0 < cnt * kXrvStride; i0 += kChainThreads * 4) {
+      const unsigned long long* w4[4];
+      unsigned t4[4];
+      bool ok4[4];
+      float o4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * kChainThreads + tid;
+        ok4[j] = i < cnt * kXrvStride && (i & (kXrvStride - 1)) < 27;
+        w4[j] = xch_xrv + (size_t)b0 * kXrvStride + min(i, cnt * kXrvStride - 1);
+        t4[j] = tag;
+      }
+      xch_wait_many<4>(w4, t4, ok4, o4, err, slow);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ok4[j]) stage[i0 + j * kChainThreads + tid] = o4[j];
+    }
     __syncthreads();
     if (tid < 27)
       for (int b = 0; b < cnt; ++b) acc += (double)stage[b * kXrvStride + tid];
@@ -1373,6 +1389,15 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   };
 
   const int nspec = calls - 2;  // evaluations 2 .. calls - 1 (the launcher guarantees 2 <= nspec <= kSpecMax)
+  // diagnostic: from the end of the previous launch (its last stamp) to the start of this one = the pair's second half with
+  // every stream operation between the kernels; summed on the device (the launches of a stream are serialised)
+  if (stamps && blockIdx.x == 0 && tid == 0) {
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime(), prev_end = stamps[15];
+    if (stamps[0] == 1ull && prev_end != 0ull && now > prev_end && now - prev_end < 100000ull) {
+      stamps[40] += now - prev_end;
+      stamps[41] += 1ull;
+    }
+  }
   RH_STAMP(1);
   if (lm_live) {
     normal_pass(0, 0);
@@ -1684,12 +1709,16 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     }
   }
   RH_STAMP(14);
-  if (stamps && blockIdx.x == 0 && tid == 0) stamps[0] = 1ull;
+  if (stamps && blockIdx.x == 0 && tid == 0) {
+    stamps[15] = stamps[14];  // (no device glue in this launch: a zero-length last segment)
+    stamps[0] = 1ull;
+  }
   if (ga.lm) {
     __syncthreads();  // (recm is free: every LM collect is over)
     // recm holds (calls - 2) record sets of 16 words per launched group: at least 32 floats per group
     lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, recm, (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride > 0
                                     ? (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride : 1, gw, s, bar_err, slow_poll);
+    RH_STAMP(15);
   }
 #undef RH_STAMP
 }

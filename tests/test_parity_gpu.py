@@ -47,9 +47,10 @@ def assert_keylines_equal(ko, kg, fields=None, what=""):
 
 
 def run_stream(ctx, dev, order, npx, k0=0, ts_step=50000):
-    """Push order[] through the streaming driver and flush: every started pair's (record, keyline count), in pair order. Records
-    come back several pushes late (the pair step runs on the device from end to end and the host reads up to seven pairs
-    behind); the flush delivers the rest."""
+    """Push order[] through the streaming driver and flush: every pair's (record, keyline count), in pair order - len(order) - 1
+    of them. Records come back several pushes late (the pair step runs on the device from end to end, pairs are queued in
+    groups and the host reads them up to fifteen pairs behind); the flush tracks the pairs not started yet and delivers the
+    rest."""
     recs = []
     for k, i in enumerate(order):
         out, n = ctx.push_frame_u8_device(dev + int(i) * npx, (k0 + k) * ts_step)
@@ -384,7 +385,7 @@ def test_c3_stream_tracks_oracle_stream(orc_mod, B):
         sys.path.insert(0, sys_path)
     import divergence_report as D
     ref, wide, got = D.run(8, 0, W=1280, H=960, kref=60000, kmax=64000, density=2.0, threshold=0.006)
-    assert len(ref) == 7 and len(got) == 8 - 4
+    assert len(ref) == 7 == len(got)
     first, rows = D.analyse(ref, wide, got)
     assert first is None, f"LM decisions differ from the oracle's at pair {first}"
     for k, mo, mg, d_ref, d_wide, d_own, ko, kg in rows:
@@ -581,7 +582,7 @@ def test_persistent_lm_kernel_equals_per_call_kernels(B, c2_stream, monkeypatch)
         return outs, last, stream
 
     a_out, a_kl, a_stream = run("persistent", 512)
-    assert len(a_stream) == 3 * len(frames) - 2 - 4   # every pair but those of the last lead - 1 frames
+    assert len(a_stream) == 3 * len(frames) - 2 - 1   # every pair of the stream
     for mode, threads in (("percall", 512), ("seq", 512), ("seq", 256), ("seq", 1024), ("spec", 256)):
         b_out, b_kl, b_stream = run(mode, threads)
         assert a_out == b_out, (mode, threads)
@@ -609,8 +610,7 @@ def test_device_glue_equals_host_glue(B, c2_stream, monkeypatch):
         ctx = B.Context(params_for(B, cam, **KW_C2))
         dev = ctx.upload_frames(frames)
         maps = [ctx.detect_u8_device(dev + int(i) * npx, k * 50000) for k, i in enumerate(order)]
-        want = [pair_tuple(ctx.track_pair(maps[k - 1], maps[k]), maps[k].size()) for k in range(1, len(order) - 3)]
-        last = maps[len(order) - 4].keylines()
+        want = [pair_tuple(ctx.track_pair(maps[k - 1], maps[k]), maps[k].size()) for k in range(1, len(order))]
         bg_host = ctx.gyro_state()
         ctx.close()
         ctx2 = B.Context(params_for(B, cam, **KW_C2))
@@ -618,13 +618,12 @@ def test_device_glue_equals_host_glue(B, c2_stream, monkeypatch):
         got = [pair_tuple(o, nk) for o, nk in run_stream(ctx2, dev2, order, npx)]
         bg_dev = ctx2.gyro_state()          # mirrored from the device's filter state, exact after the flush
         ctx2.close()
-        assert len(got) == len(order) - 4 == len(want)
+        assert len(got) == len(order) - 1 == len(want)
         for k, (g, w) in enumerate(zip(got, want)):
             assert g == w, (head, k, [i for i in range(len(g)) if g[i] != w[i]])
         assert np.array_equal(bg_host[0].view(np.uint32), bg_dev[0].view(np.uint32)) and np.abs(bg_host[0]).max() > 0
         assert np.array_equal(bg_host[1].view(np.uint32), bg_dev[1].view(np.uint32))
         assert all(w[-2] == 0 and w[-6] > 5000 for w in want)   # status 0, thousands of matches
-        del last
 
 
 def test_glue_probe_random_inputs(B):
@@ -636,7 +635,10 @@ def test_glue_probe_random_inputs(B):
     rng = np.random.default_rng(11)
 
     def words(a):
-        return np.ascontiguousarray(a, np.float32).view(np.uint32)
+        a = np.ascontiguousarray(a, np.float32)
+        w = a.view(np.uint32).copy()
+        w[np.isnan(a)] = 0x7FC00000   # a NaN is a NaN (its sign bit is not part of the comparison)
+        return w
 
     n_fallback = n_nan = 0
     for trial in range(160):
@@ -861,7 +863,7 @@ def test_stream_continues_cleanly_after_a_flush(B, c2_stream):
 
     first, second, third = segment(0), segment(30), segment(60)
     for rec in (first, second, third):
-        assert len(rec) == 30 - 4
+        assert len(rec) == 30 - 1
         assert all(r[0] == 0 for r in rec), rec[:4]
         assert rec[0][3] == first[0][3]            # every segment's first pair starts from the fresh maps' sigma (quantile of 1000s)
         assert all(r[2] > 5000 for r in rec), rec[:4]
@@ -880,7 +882,7 @@ def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
     dev = ctx.upload_frames(frames)
     npx = cam.width * cam.height
     got = [(np.array(o.Vg), np.array(o.Xgv[3:6]), o.klm_num, o.status) for o, _ in run_stream(ctx, dev, order, npx)]
-    assert len(got) == len(order) - 4  # the last lead - 1 frames only fill the pipeline
+    assert len(got) == len(order) - 1
     # the oracle's record k describes pair (k-1, k); the pipeline reports the pairs in the same order starting at pair 1
     for j, (vg, dw, klm, status) in enumerate(got):
         k = j + 1
@@ -892,17 +894,18 @@ def test_streaming_pipeline_tracks_oracle_stream(orc_mod, B, c2_stream):
 
 
 def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeypatch):
-    """The detect stage leads the tracker by REBVIO_HIP_LEAD frames, the context's three streams have priorities or not
+    """The detect stage leads the tracker by REBVIO_HIP_LEAD frames, pairs are queued on the track stream in groups of
+    REBVIO_HIP_GROUP (one wait and one event per group), the context's three streams have priorities or not
     (REBVIO_HIP_PRIO=flat, for several contexts per process), in-kernel phase stamps are taken or not (REBVIO_HIP_LM_STAMPS):
-    all of these only move work around. Same frames -> the same records, bit for bit, in the same order; a deeper pipeline
-    merely starts fewer pairs before the flush."""
+    all of these only move work around. Same frames -> the same records, bit for bit, in the same order."""
     from rebvio_amd import synth
     frames, cam = c2_stream
     order = synth.pingpong_indices(len(frames), 40)
     npx = cam.width * cam.height
 
-    def run(lead, prio=None, stamps=False):
+    def run(lead, group, prio=None, stamps=False):
         monkeypatch.setenv("REBVIO_HIP_LEAD", str(lead))
+        monkeypatch.setenv("REBVIO_HIP_GROUP", str(group))
         if prio:
             monkeypatch.setenv("REBVIO_HIP_PRIO", prio)
         else:
@@ -917,12 +920,11 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
         ctx.close()
         return rec
 
-    base = run(3)
-    assert len(base) == len(order) - 2
-    for lead, prio, stamps in ((5, None, False), (8, None, False), (12, None, False), (5, "flat", False), (5, None, True)):
-        got = run(lead, prio, stamps)
-        assert len(got) == len(order) - lead + 1
-        assert got == base[:len(got)], (lead, prio, stamps)
+    base = run(3, 1)
+    assert len(base) == len(order) - 1
+    for lead, group, prio, stamps in ((5, 1, None, False), (5, 4, None, False), (8, 2, None, False), (12, 6, None, False), (5, 4, "flat", False),
+                                      (5, 3, None, True)):
+        assert run(lead, group, prio, stamps) == base, (lead, group, prio, stamps)
 
 
 def test_euroc_frame_size_with_lens_model(orc_mod, B):
@@ -1006,7 +1008,7 @@ def test_pair_step_failure_paths(orc_mod, B, small_stream):
     dev = ctx2.upload_frames(seq)
     npx = cam.width * cam.height
     st = [o.status for o, _ in run_stream(ctx2, dev, range(len(seq)), npx)]
-    assert len(st) == len(seq) - 4 and st[0] == 0 and 2 in st and st[-1] == 0, st   # the bad pair is reported, the stream goes on
+    assert len(st) == len(seq) - 1 and st[0] == 0 and 2 in st and st[-1] == 0, st   # the bad pair is reported, the stream goes on
 
 
 def test_pair_step_nan_path(orc_mod, B, small_stream):
@@ -1121,8 +1123,8 @@ def _batch_records(B, cam, streams, order, lens=None, **kw):
 
 
 @pytest.mark.parametrize("L,env", [(3, {}), (4, {}), (8, {}), (4, {"REBVIO_HIP_LM": "seq"}), (2, {"REBVIO_HIP_BATCH_DM_HEAD": "thread"}),
-                                   (5, {"REBVIO_HIP_BATCH_DM_HEAD": "wide", "REBVIO_HIP_BATCH_LEAD": "6"})],
-                         ids=["3-lanes", "4-lanes", "8-lanes", "4-lanes-seq-lm", "2-lanes-thread-head", "5-lanes-wide-head-lead6"])
+                                   (5, {"REBVIO_HIP_BATCH_DM_HEAD": "wide", "REBVIO_HIP_BATCH_LEAD": "6", "REBVIO_HIP_BATCH_GROUP": "3"})],
+                         ids=["3-lanes", "4-lanes", "8-lanes", "4-lanes-seq-lm", "2-lanes-thread-head", "5-lanes-wide-head-lead6-group3"])
 def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, env):
     """rebvio_hip_batch_*: L camera streams advanced in lock-step by batched launches (lane = blockIdx.z) produce, lane by lane,
     the records of L stand-alone contexts fed the same frames - bit for bit (same kernel bodies, same per-lane reduction
@@ -1138,15 +1140,13 @@ def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, e
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     got = _batch_records(B, cam, streams, order)
-    lead = int(env.get("REBVIO_HIP_BATCH_LEAD", 4))
     for k in env:
         if k.startswith("REBVIO_HIP_BATCH"):
             monkeypatch.delenv(k)
     want = [_stand_alone_records(B, cam, streams[s], order) for s in range(L)]
     for s in range(L):
-        assert len(want[s]) == n - 4 and len(got[s]) == n - lead + 1, (s, len(got[s]), len(want[s]))
-        m = min(len(got[s]), len(want[s]))
-        assert got[s][:m] == want[s][:m], s
+        assert len(want[s]) == n - 1 == len(got[s]), (s, len(got[s]), len(want[s]))
+        assert got[s] == want[s], s
         assert all(r[-2] == 0 for r in got[s])
     assert got[0] != got[1]  # different scenes per lane
 
@@ -1168,8 +1168,7 @@ def test_batched_lanes_with_the_euroc_lens_model(B, c2_stream):
         dev = ctx.upload_frames(streams[s])
         want = [pair_tuple(o, nk) for o, nk in run_stream(ctx, dev, order, npx)]
         ctx.close()
-        m = min(len(got[s]), len(want))
-        assert m >= n - 4 and got[s][:m] == want[:m], s
+        assert len(want) == n - 1 and got[s] == want, s
     plain = _batch_records(B, cam, streams[:2], order[:8])
     assert plain[0] and plain[0] != got[0][:len(plain[0])]      # the model matters
     bat = B.Batch(params_for(B, cam, **KW_C2), 2)
