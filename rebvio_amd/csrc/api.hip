@@ -272,6 +272,7 @@ struct rebvio_hip_ctx {
   GlueState* gstate = nullptr;    // [2] device: gyro-bias filter state + prior rotation, by pair parity
   GlueState* h_gstate = nullptr;  // [2] pinned staging for the upload in front of a stream's first pair
   hm::M3 gs_R{};                  // host mirror of the device state's prior rotation (with Bg / W_Bg above)
+  int min_pool = 0;               // edge maps to allocate before one is reused (see acquire_map)
   int lead = 5;                   // detected frames queued when a pair is started (REBVIO_HIP_LEAD 3..12, see push_frame)
   int group = 4;                  // pairs queued together (REBVIO_HIP_GROUP 1..6, see stream_enqueue_group)
   struct InFlight {               // a pair whose kernels are queued and whose record has not been read yet
@@ -422,6 +423,11 @@ rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
   rebvio_hip_map* best = nullptr;
   for (auto* m : c->pool)
     if (!m->in_use && (!best || m->release_seq < best->release_seq)) best = m;
+  // The streaming drivers release a map when its group of pairs is QUEUED, up to a ring of pairs before the tracker has run it
+  // on the device; the frame that reuses it waits (in stream order) for that group. With too few maps the detect stage can
+  // only work a few pairs ahead of the tracker and the tracker ends up waiting for its maps: min_pool keeps the reuse distance
+  // at two groups and more.
+  if (best && (int)c->pool.size() < c->min_pool) best = nullptr;
   if (best) {
     rebvio_hip_map* m = best;
     m->in_use = true;
@@ -971,6 +977,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   if (std::getenv("REBVIO_HIP_LM_STAMPS")) {
     HIPCHK(hipHostMalloc(&c->lm_stamps, 64 * sizeof(unsigned long long), hipHostMallocDefault));
     std::memset(c->lm_stamps, 0, 64 * sizeof(unsigned long long));
+    K.dbg = c->lm_stamps;
   }
   // REBVIO_HIP_LM = percall (one kernel per evaluation) | seq (persistent kernel, one evaluation per exchange round) |
   // anything else / unset: persistent kernel with the speculative reject chain (track.hip, k_lm_chain_spec)
@@ -2011,6 +2018,7 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
     out->status = -1;
   }
   if (keylines) *keylines = -1;
+  c->min_pool = c->lead + 3 * c->group + 3;
   int rc = detect_async(c, frame_dev, 1, ts_us, &m);
   if (rc) return rc;
   {
@@ -2059,6 +2067,12 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     if (c->lm_stamps[41])
       std::fprintf(stderr, "[rebvio_hip] end of an LM launch -> start of the next (second half of the pair + stream operations), mean over %llu: %.2f us\n",
                    (unsigned long long)c->lm_stamps[41], (double)c->lm_stamps[40] * 0.01 / (double)c->lm_stamps[41]);
+    if (c->lm_stamps[46]) {
+      const double m = 0.01 / (double)c->lm_stamps[46];
+      std::fprintf(stderr, "[rebvio_hip]   of which: LM end -> head start %.2f  head start -> tail start %.2f  tail start -> regularize/EKF start %.2f  "
+                   "regularize/EKF start -> next LM start %.2f\n", (double)c->lm_stamps[42] * m, (double)c->lm_stamps[43] * m, (double)c->lm_stamps[44] * m,
+                   (double)c->lm_stamps[45] * m);
+    }
   } else if (c->lm_stamps && c->lm_stamp_n) {
     const int calls = (int)c->P.iterations + 1;
     std::fprintf(stderr, "[rebvio_hip] k_lm_chain workgroup 0, mean us per segment over %llu launches\n", (unsigned long long)c->lm_stamp_n);
@@ -2738,6 +2752,7 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   for (int l = 0; l < B; ++l) {
     rebvio_hip_ctx* c = b->lane[l];
     rebvio_hip_ctx::DetJob job;
+    c->min_pool = std::min(kLaneMaps - 2, b->lead + 3 * b->group + 3);
     int rc = detect_prepare(c, frames_dev[l], 1, ts_us, &job);
     if (rc == 0) {
       rebvio_hip_map* m = job.m;

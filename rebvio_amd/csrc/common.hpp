@@ -98,6 +98,7 @@ struct KParams {
   float pixel_uncertainty_match, match_threshold_norm, cang_min_edge, regularization_threshold;
   int nseg;  // ceil(cols / 64)
   int df_nr; // 2 * search_range
+  unsigned long long* dbg;  // REBVIO_HIP_LM_STAMPS: pinned stamp buffer (null otherwise); [48..50] = start of the pair's second-half kernels
 };
 
 // Levenberg-Marquardt state of minimizeVel kept on the device (core.cpp:150-189).

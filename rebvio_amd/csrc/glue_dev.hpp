@@ -1,10 +1,12 @@
 // Device form of the pair glue (glue.hpp: pair_glue_core), run by workgroup 0 of the persistent LM kernel behind its last
 // phase: the same statements per output element as the host form, spread over three waves and a few lanes each so that the
 // ~2500 dependent scalar operations of the host version become a chain of ~600:
-//   wave 0  the 6x6 solve of extRotVel in double (core.cpp:244-248), then everything that needs its solution
-//   wave 1  gyroBiasCorrection's 3x3 inverses (core.cpp:264-284; nine lanes, one cofactor each), then the two LDL^T
-//           inverses (core.cpp:276, rebvio.cpp:201-202), one column per lane
-//   wave 2  invert(JtJ) of minimizeVel (core.cpp:186) for the host's record
+//   wave 0  the 6x6 solve of extRotVel in double (core.cpp:244-248), one row of L per lane; afterwards the SO3 correction, the
+//           covariance block, the second half's inputs and the host's record
+//   wave 1  gyroBiasCorrection's 3x3 inverses (core.cpp:264-284; nine lanes, one cofactor each, independent ones side by
+//           side) and inverse(Wxb), one column per lane (core.cpp:276); afterwards the filter state and the next prior
+//   wave 2  W_Xgv after the correction and its inverse (rebvio.cpp:201-202), one column per lane
+//   wave 3  invert(JtJ) of minimizeVel (core.cpp:186) for the host's record
 // Matrices live in LDS (lane-dependent element indices are LDS addresses, never register-array indices: those would become
 // scratch memory); each lane's own chain runs on registers with static indices. Bit-identical to pair_glue_core on the host:
 // tests/test_parity_gpu.py::test_device_glue_equals_host_glue (streams) and ::test_glue_probe_random_inputs (random and
@@ -19,13 +21,17 @@ struct GlueLds {
   float W[36];       // W_Xv: extRotVel JtJ
   float JtF[6];
   float Xv[6];
-  float m3[8][9];    // 0 Wg  1 inv(W_Bg)+RGBias  2 W_Bg'  3 Wg+W_Bg'  4 iWgWb  5 iWgWb*Wg  6 upd  7 (Wg*iWgWb)*W_Bg'
+  // 3x3 matrices of gyroBiasCorrection, one set per wave that needs them (waves do not wait for each other inside a phase):
+  // [0] Wg  [1] invert3(W_Bg) (+ RGBias)  [2] W_Bg'  [3] Wg + W_Bg'  [4] iWgWb  [5] scratch  [6] upd  [7] (Wg iWgWb) W_Bg'  [8] RGyro  [9] W_Bg
+  float m3[2][10][9];
   float A[2][36];    // 0: Wxb (core.cpp:271-272)   1: W_Xgv after the correction (core.cpp:283)
   float inv[2][36];
-  float X1[6], X[6];
+  float X1[2][6], X[2][6];
   float P_Vg[9];
-  float tmp3[9];
+  float JtJ9[9];
+  double Ld[36];     // L of the 6x6 solve (rows written by their lanes, read by column in the back substitution)
   double ws[72];     // Jacobi fall-back of the 6x6 solve
+  int ldlt_ok;
 };
 
 // wave-level hand-over through LDS: the LDS pipeline of a wave is in order, so only the compiler has to be kept from moving
@@ -34,6 +40,14 @@ __device__ __forceinline__ void glue_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value of lane `src` (a compile-time constant after unrolling) in every lane
+__device__ __forceinline__ double glue_bcast(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xFFFFFFFFll), src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // TooN::determinant for N = 3 (Gaussian elimination with partial pivoting): hostmath.hpp det3, from registers
@@ -75,14 +89,18 @@ __device__ __forceinline__ float glue_det3(const float (&m)[9]) {
   return det;
 }
 
-// types::invert (types/definitions.hpp:40-53): lanes 0..8 of the calling wave each produce one element of dst = inverse(src)
-__device__ __forceinline__ void glue_invert3_lanes(const float* src /*LDS*/, float* dst /*LDS*/, int lane) {
+// types::invert (types/definitions.hpp:40-53), up to four matrices at once: lane 16 g + e (e < 9) produces element e of
+// dst[g] = inverse(src[g]) for g < ngroups. Every lane of the wave calls it.
+__device__ __forceinline__ void glue_invert3_lanes(const float* const (&src)[4], float* const (&dst)[4], int ngroups, int lane) {
+  const int g = lane >> 4, e = lane & 15;
+  const bool act = g < ngroups && e < 9;
+  const float* sp = src[act ? g : 0];
   float m[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) m[i] = src[i];
+  for (int i = 0; i < 9; ++i) m[i] = sp[i];
   const float d = glue_det3(m);
   float o;
-  switch (lane) {
+  switch (e) {
     case 0: o = m[4] * m[8] - m[5] * m[7]; break;
     case 1: o = m[2] * m[7] - m[1] * m[8]; break;
     case 2: o = m[1] * m[5] - m[2] * m[4]; break;
@@ -93,180 +111,296 @@ __device__ __forceinline__ void glue_invert3_lanes(const float* src /*LDS*/, flo
     case 7: o = m[1] * m[6] - m[0] * m[7]; break;
     default: o = m[0] * m[4] - m[1] * m[3]; break;
   }
-  glue_wave_sync();  // (src may alias nothing written here, but keep the phases apart for the compiler)
-  if (lane < 9) dst[lane] = o / d;
+  glue_wave_sync();
+  if (act) dst[g][e] = o / d;
   glue_wave_sync();
 }
+__device__ __forceinline__ void glue_invert3_one(const float* src, float* dst, int lane) {
+  const float* const s4[4] = {src, src, src, src};
+  float* const d4[4] = {dst, dst, dst, dst};
+  glue_invert3_lanes(s4, d4, 1, lane);
+}
 
-// element (i, j) = lane of x * y for 3x3 matrices in LDS: dot product accumulated from 0 in index order (hostmath.hpp mul)
-__device__ __forceinline__ float glue_mul3_elem(const float* x, const float* y, int lane) {
-  const int i = lane / 3, j = lane - 3 * i;
+// element e = 3 i + j of x * y for 3x3 matrices in LDS: dot product accumulated from 0 in index order (hostmath.hpp mul)
+__device__ __forceinline__ float glue_mul3_elem(const float* x, const float* y, int e) {
+  const int i = e / 3, j = e - 3 * i;
   float s = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) s += x[i * 3 + k] * y[k * 3 + j];
   return s;
 }
 
-// Called by EVERY thread of workgroup 0 (>= 192 threads) once the sums of the extRotVel records are in w.W / w.JtF
+// gyroBiasCorrection's 3x3 algebra (hostmath.hpp gyro_bias_correction) up to `depth`: 1 = Wg only, 2 = everything. Nine lanes
+// of the calling wave (all 64 call it); M = this wave's matrix set.
+__device__ __forceinline__ void glue_gyro3(float (&M)[10][9], const GlueState* st_in, float s_g, float s_b, int depth, int lane) {
+  const int e = lane < 9 ? lane : 8;
+  const int di = e / 3, dj = e - 3 * di;
+  if (lane < 9) {
+    M[8][lane] = (di == dj) ? s_g : 0.0f;  // RGyro = diag3(s_g)
+    M[9][lane] = st_in->W_Bg[lane];
+  }
+  glue_wave_sync();
+  {
+    const float* const s4[4] = {M[8], M[9], M[8], M[8]};
+    float* const d4[4] = {M[0], M[1], M[0], M[0]};
+    glue_invert3_lanes(s4, d4, depth >= 2 ? 2 : 1, lane);  // Wg = invert3(Rg) | invert3(Wb), side by side
+  }
+  if (depth < 2) return;
+  if (lane < 9) M[1][lane] = M[1][lane] + ((di == dj) ? s_b : 0.0f);  // add(invert3(Wb), Rb)
+  glue_wave_sync();
+  glue_invert3_one(M[1], M[2], lane);  // Wb = invert3(...)
+  if (lane < 9) M[3][lane] = M[0][lane] + M[2][lane];  // add(Wg, Wb)
+  glue_wave_sync();
+  glue_invert3_one(M[3], M[4], lane);  // iWgWb
+  // mul(iWgWb, Wg) on lanes 0..8, mul(Wg, iWgWb) on lanes 16..24
+  {
+    const int g = lane >> 4, e2 = (lane & 15) < 9 ? (lane & 15) : 8;
+    const float v = g == 0 ? glue_mul3_elem(M[4], M[0], e2) : glue_mul3_elem(M[0], M[4], e2);
+    glue_wave_sync();
+    if ((lane & 15) < 9 && g == 0) M[5][e2] = ((di == dj) ? 1.0f : 0.0f) - v;  // sub(identity3(), mul(iWgWb, Wg))
+    if ((lane & 15) < 9 && g == 1) M[7][e2] = v;                                // mul(Wg, iWgWb)
+    glue_wave_sync();
+    const float w = g == 0 ? glue_mul3_elem(M[0], M[5], e2) : glue_mul3_elem(M[7], M[2], e2);
+    glue_wave_sync();
+    if ((lane & 15) < 9 && g == 0) M[6][e2] = w;  // upd = mul(Wg, ...)
+    if ((lane & 15) < 9 && g == 1) M[7][e2] = w;  // mul(mul(Wg, iWgWb), Wb): multiplies dgbias = 0 below
+    glue_wave_sync();
+  }
+}
+
+// one column of inverse(A) per lane (lanes 0..5), TooN Cholesky<6>::get_inverse: every lane factorises for itself
+__device__ __forceinline__ void glue_chol6_inverse_lanes(const float* A /*LDS*/, float* inv /*LDS*/, int lane) {
+  if (lane < 6) {
+    float L[6][6], res[6];
+    hm::cholesky6_factor(A, L);
+    hm::cholesky6_inverse_col(L, lane, res);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) inv[i * 6 + lane] = res[i];
+  }
+  glue_wave_sync();
+}
+
+// hostmath.hpp sym6_ldlt_solve with row i of L on lane i: per column one division on every lane at once instead of up to
+// five in a row, the substitutions as chains of broadcasts. Every lane of the wave calls it; returns false (all lanes) when
+// the pivots ask for the pseudo-inverse instead.
+__device__ __forceinline__ bool glue_sym6_ldlt_lanes(const float* A_ /*LDS*/, const float* b_ /*LDS*/, float* x_ /*LDS*/, double* Ld /*LDS*/,
+                                                    int lane) {
+  constexpr int N = 6;
+  const int i = lane < N ? lane : N - 1;
+  double Li[N] = {0, 0, 0, 0, 0, 0}, d[N], dmax = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) dmax = (fabs((double)A_[k * N + k]) > dmax) ? fabs((double)A_[k * N + k]) : dmax;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (!ok) continue;
+    double Lj[N];
+#pragma unroll
+    for (int k = 0; k < j; ++k) Lj[k] = glue_bcast(Li[k], j);  // row j of L
+    double v = 0.5 * ((double)A_[j * N + j] + (double)A_[j * N + j]);
+#pragma unroll
+    for (int k = 0; k < j; ++k) v -= Lj[k] * Lj[k] * d[k];
+    if (!(v * 1e7 > dmax)) ok = false;
+    d[j] = v;
+    if (ok) {
+      double s = 0.5 * ((double)A_[i * N + j] + (double)A_[j * N + i]);
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= Li[k] * Lj[k] * d[k];
+      Li[j] = s / v;  // (kept by the lanes below the diagonal; the others never use theirs)
+    }
+  }
+  if (!ok) return false;
+  // forward substitution: lane k's running sum is final at step k
+  double s = (double)b_[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double yk = glue_bcast(s, k);
+    if (i > k) s -= Li[k] * yk;
+  }
+  double dv = d[0];
+#pragma unroll
+  for (int k = 1; k < N; ++k) dv = (i == k) ? d[k] : dv;
+  const double y = s / dv;
+  // back substitution needs L by column: through LDS
+  if (lane < N) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) Ld[lane * N + k] = Li[k];
+  }
+  glue_wave_sync();
+  double x = y, xk[N];
+#pragma unroll
+  for (int ii = N - 1; ii >= 0; --ii) {
+    // lane ii finishes: x = y - sum over k > ii (ascending) of L[k][ii] * x[k]
+    if (i == ii) {
+#pragma unroll
+      for (int k = ii + 1; k < N; ++k) x -= Ld[k * N + ii] * xk[k];
+    }
+    xk[ii] = glue_bcast(x, ii);
+  }
+  if (lane < N) x_[lane] = (float)x;
+  glue_wave_sync();
+  return true;
+}
+
+// Called by EVERY thread of workgroup 0 (>= 256 threads) once the sums of the extRotVel records are in w.W / w.JtF
 // (symmetrised float matrix and vector, as hm::sum_xrv leaves them) and `lm` holds the final minimizeVel state.
-// Workgroup barriers inside. Results: *gd_out (second half of the pair), *st_out (filter state after the pair), *rec.
-__device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*LDS or registers*/, const GlueArgs& ga) {
+// One workgroup barrier inside. Results: *gd_copy (second half of the pair), *st_out (filter state after the pair), *rec.
+__device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*LDS*/, const GlueArgs& ga) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float s_b = ga.gp.gyro_bias_std_dev * ga.gp.gyro_bias_std_dev * ga.gp.frame_dt * ga.gp.frame_dt;
   const float s_g = ga.gp.gyro_std_dev * ga.gp.gyro_std_dev * ga.gp.frame_dt * ga.gp.frame_dt;
   if (wid == 0) {
-    if (lane == 0) hm::sym6_solve_ws(w.W, w.JtF, w.Xv, w.ws);
+    // ---- the 6x6 solve of extRotVel (core.cpp:244-248) ----
+    const bool ok = glue_sym6_ldlt_lanes(w.W, w.JtF, w.Xv, w.Ld, lane);
+    if (!ok && lane == 0) hm::sym6_pinv_solve_ws(w.W, w.JtF, w.Xv, w.ws);
   } else if (wid == 1) {
-    // ---- gyroBiasCorrection's 3x3 algebra (hostmath.hpp gyro_bias_correction), nine lanes ----
-    const int l9 = lane < 9 ? lane : 8;
-    const int di = l9 / 3, dj = l9 - 3 * di;
-    if (lane < 9) {
-      w.m3[5][lane] = (di == dj) ? s_g : 0.0f;  // RGyro = diag3(s_g) (scratch slot 5 until iWgWb*Wg is formed)
-      w.m3[7][lane] = ga.st_in->W_Bg[lane];     // W_Bg (scratch slot 7)
+    // ---- gyroBiasCorrection up to inverse(Wxb) (core.cpp:264-276) ----
+    glue_gyro3(w.m3[0], ga.st_in, s_g, s_b, 2, lane);
+    if (lane < 36) {  // Wxb = Wx with upd added to its lower right block (core.cpp:271-272)
+      const int i = lane / 6, j = lane - 6 * i;
+      const float v = w.W[lane];
+      w.A[0][lane] = (i >= 3 && j >= 3) ? v + w.m3[0][6][(i - 3) * 3 + (j - 3)] : v;
     }
     glue_wave_sync();
-    glue_invert3_lanes(w.m3[5], w.m3[0], l9);   // Wg = invert3(Rg)
-    glue_invert3_lanes(w.m3[7], w.tmp3, l9);    // invert3(Wb)
-    if (lane < 9) w.m3[1][lane] = w.tmp3[lane] + ((di == dj) ? s_b : 0.0f);  // add(invert3(Wb), Rb)
-    glue_wave_sync();
-    glue_invert3_lanes(w.m3[1], w.m3[2], l9);   // Wb = invert3(...)
-    if (lane < 9) w.m3[3][lane] = w.m3[0][lane] + w.m3[2][lane];  // add(Wg, Wb)
-    glue_wave_sync();
-    glue_invert3_lanes(w.m3[3], w.m3[4], l9);   // iWgWb
-    if (lane < 9) w.m3[5][lane] = glue_mul3_elem(w.m3[4], w.m3[0], l9);  // mul(iWgWb, Wg)
-    glue_wave_sync();
-    if (lane < 9) w.tmp3[lane] = ((di == dj) ? 1.0f : 0.0f) - w.m3[5][lane];  // sub(identity3(), ...)
-    glue_wave_sync();
-    if (lane < 9) w.m3[6][lane] = glue_mul3_elem(w.m3[0], w.tmp3, l9);  // upd = mul(Wg, ...)
-    glue_wave_sync();
-    if (lane < 9) w.tmp3[lane] = glue_mul3_elem(w.m3[0], w.m3[4], l9);  // mul(Wg, iWgWb)
-    glue_wave_sync();
-    if (lane < 9) w.m3[7][lane] = glue_mul3_elem(w.tmp3, w.m3[2], l9);  // mul(mul(Wg, iWgWb), Wb): multiplies dgbias = 0 below
-    // Wxb = Wx with upd added to its lower right block; Wx' = Wx with Wg added there (core.cpp:271-272, 283)
+    glue_chol6_inverse_lanes(w.A[0], w.inv[0], lane);
+  } else if (wid == 2) {
+    // ---- W_Xgv after the correction (core.cpp:283) and its inverse (rebvio.cpp:201-202) ----
+    glue_gyro3(w.m3[1], ga.st_in, s_g, s_b, 1, lane);
     if (lane < 36) {
       const int i = lane / 6, j = lane - 6 * i;
-      const bool blk = i >= 3 && j >= 3;
       const float v = w.W[lane];
-      w.A[0][lane] = blk ? v + w.m3[6][(i - 3) * 3 + (j - 3)] : v;
-      w.A[1][lane] = blk ? v + w.m3[0][(i - 3) * 3 + (j - 3)] : v;
+      w.A[1][lane] = (i >= 3 && j >= 3) ? v + w.m3[1][0][(i - 3) * 3 + (j - 3)] : v;
     }
     glue_wave_sync();
-    // the two LDL^T inverses, one column per lane: lanes 0..5 -> inverse(Wxb), lanes 8..13 -> inverse(W_Xgv')
-    if ((lane & 7) < 6 && lane < 16) {
-      const int which = lane >> 3, c = lane & 7;
-      float L[6][6], res[6];
-      hm::cholesky6_factor(w.A[which], L);
-      hm::cholesky6_inverse_col(L, c, res);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) w.inv[which][i * 6 + c] = res[i];
+    glue_chol6_inverse_lanes(w.A[1], w.inv[1], lane);
+  } else if (wid == 3) {
+    // ---- invert(JtJ) of minimizeVel (core.cpp:186) for the host's record ----
+    if (lane == 0) {
+      w.JtJ9[0] = lm.JtJ[0]; w.JtJ9[4] = lm.JtJ[1]; w.JtJ9[8] = lm.JtJ[2];
+      w.JtJ9[1] = w.JtJ9[3] = lm.JtJ[3];
+      w.JtJ9[2] = w.JtJ9[6] = lm.JtJ[4];
+      w.JtJ9[5] = w.JtJ9[7] = lm.JtJ[5];
     }
-  } else if (wid == 2) {
-    if (lane == 0) hm::lm_rvel(lm, w.P_Vg);
+    glue_wave_sync();
+    glue_invert3_one(w.JtJ9, w.P_Vg, lane);
   }
   __syncthreads();
-  if (wid == 0) {
-    // X1 = Wx * X (+ (Wg iWgWb Wb) dgbias with dgbias = 0 on entry, as the reference computes it), X = inverse(Wxb) * X1
-    if (lane < 6) {
-      float s = 0;
+  if (wid >= 2) return;
+  // Both remaining waves form X (core.cpp:273-276) for themselves: X1 = Wx * X (+ (Wg iWgWb Wb) dgbias with dgbias = 0 on
+  // entry, as the reference computes it), X = inverse(Wxb) * X1.
+  float (&M)[10][9] = w.m3[0];
+  if (lane < 6) {
+    float s = 0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s += w.W[lane * 6 + k] * w.Xv[k];
-      if (lane >= 3) {
-        float t = 0;
+    for (int k = 0; k < 6; ++k) s += w.W[lane * 6 + k] * w.Xv[k];
+    if (lane >= 3) {
+      float t = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t += w.m3[7][(lane - 3) * 3 + k] * 0.0f;
-        s += t;
-      }
-      w.X1[lane] = s;
+      for (int k = 0; k < 3; ++k) t += M[7][(lane - 3) * 3 + k] * 0.0f;
+      s += t;
     }
-    glue_wave_sync();
-    if (lane < 6) {
-      float s = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s += w.inv[0][lane * 6 + k] * w.X1[k];
-      w.X[lane] = s;
-    }
-    glue_wave_sync();
-    if (lane == 0) {
-      GlueState st = *ga.st_in;
-      GlueDev gl;
-      GlueRec rec;
-      rebvio_hip_pair_out& out = rec.out;
-      float Xgv[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) Xgv[i] = w.X[i];
-      // dgbias = iWgWb * (Wg * X[3:6] + Wb * dgbias(=0))
-      float a3[3], b3[3], sum3[3], dg[3];
-      const float xw[3] = {Xgv[3], Xgv[4], Xgv[5]}, zero3[3] = {0.f, 0.f, 0.f};
-      hm::mulv(hm::load3(w.m3[0]), xw, a3);
-      hm::mulv(hm::load3(w.m3[2]), zero3, b3);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) sum3[i] = a3[i] + b3[i];
-      hm::mulv(hm::load3(w.m3[4]), sum3, dg);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) st.Bg[i] += dg[i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) st.W_Bg[i] = w.m3[3][i];  // Wb = add(Wg, Wb)
-      float Vg[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Vg[i] = lm.vel[i];
-      const float dVgv[3] = {Xgv[0], Xgv[1], Xgv[2]};
-      const float dWgv[3] = {Xgv[3], Xgv[4], Xgv[5]};
-      const hm::M3 R0 = hm::so3_exp(dWgv);
-      const hm::M3 R = hm::transpose(hm::mul(R0, hm::transpose(hm::load3(st.R))));
-      float V[3];
-      hm::mulv(R0, Vg, V);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) V[i] += dVgv[i];
-      float P_V[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) P_V[i * 3 + j] = w.inv[1][i * 6 + j];
-      hm::mulv(R, V, gl.vel_r);
-      hm::store3(hm::mul(hm::mul(R, hm::load3(P_V)), hm::transpose(R)), gl.Rvel_r);
-      hm::store3(R, gl.Rgva);
-      hm::store3(R0, gl.R0a);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) gl.V[i] = V[i];
-      gl.nan_v = (V[0] != V[0] || V[1] != V[1] || V[2] != V[2]) ? 1 : 0;
-      const hm::M3 Rn = hm::prior_rotation(st.Bg, hm::identity3());
-      hm::store3(Rn, st.R);
-      hm::store3(hm::transpose(Rn), gl.RT_next);
-      gl.has_next = 1;
-      st.pad = 0.f;
-      out.F = lm.F;
-      out.lm_accept_mask = lm.accept_mask;
-      out.sigma_rho_min = lm.sigma_rho_min;
-      out.ext_ok = 1;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        if (w.Xv[i] != w.Xv[i]) out.ext_ok = 0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        out.Vg[i] = Vg[i];
-        out.V[i] = V[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        out.P_Vg[i] = w.P_Vg[i];
-        out.R[i] = gl.Rgva[i];
-        out.P_V[i] = P_V[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        out.Xv[i] = w.Xv[i];
-        out.Xgv[i] = Xgv[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 36; ++i) out.W_Xv[i] = w.W[i];
-      out.klm_num = out.kf_matches = out.reg_num = 0;
-      out.status = gl.nan_v ? 1 : 0;
-      rec.gs = st;
-      *ga.gd_copy = gl;
-      *ga.st_out = st;
-      *ga.rec = rec;
-    }
+    w.X1[wid][lane] = s;
   }
+  glue_wave_sync();
+  if (lane < 6) {
+    float s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += w.inv[0][lane * 6 + k] * w.X1[wid][k];
+    w.X[wid][lane] = s;
+  }
+  glue_wave_sync();
+  if (lane != 0) return;
+  float Xgv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Xgv[i] = w.X[wid][i];
+  if (wid == 1) {
+    // ---- filter state after the pair: dgbias = iWgWb * (Wg * X[3:6] + Wb * dgbias(=0)), Wb = Wg + Wb, the next pair's prior ----
+    GlueState st = *ga.st_in;
+    float a3[3], b3[3], sum3[3], dg[3];
+    const float xw[3] = {Xgv[3], Xgv[4], Xgv[5]}, zero3[3] = {0.f, 0.f, 0.f};
+    hm::mulv(hm::load3(M[0]), xw, a3);
+    hm::mulv(hm::load3(M[2]), zero3, b3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sum3[i] = a3[i] + b3[i];
+    hm::mulv(hm::load3(M[4]), sum3, dg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st.Bg[i] += dg[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st.W_Bg[i] = M[3][i];
+    const hm::M3 Rn = hm::prior_rotation(st.Bg, hm::identity3());
+    hm::store3(Rn, st.R);
+    st.pad = 0.f;
+    hm::store3(hm::transpose(Rn), ga.gd_copy->RT_next);
+    ga.gd_copy->has_next = 1;
+    *ga.st_out = st;
+    ga.rec->gs = st;
+    return;
+  }
+  // ---- wave 0: SO3 correction, covariance, the second half's inputs, the host's record (rebvio.cpp:195-203, 228) ----
+  float Vg[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Vg[i] = lm.vel[i];
+  const float dVgv[3] = {Xgv[0], Xgv[1], Xgv[2]};
+  const float dWgv[3] = {Xgv[3], Xgv[4], Xgv[5]};
+  const hm::M3 R0 = hm::so3_exp(dWgv);
+  const hm::M3 R = hm::transpose(hm::mul(R0, hm::transpose(hm::load3(ga.st_in->R))));
+  float V[3];
+  hm::mulv(R0, Vg, V);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) V[i] += dVgv[i];
+  float P_V[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P_V[i * 3 + j] = w.inv[1][i * 6 + j];
+  GlueDev* gl = ga.gd_copy;
+  float vel_r[3], Rvel_r[9], Rgva[9], R0a[9];
+  hm::mulv(R, V, vel_r);
+  hm::store3(hm::mul(hm::mul(R, hm::load3(P_V)), hm::transpose(R)), Rvel_r);
+  hm::store3(R, Rgva);
+  hm::store3(R0, R0a);
+  const int nan_v = (V[0] != V[0] || V[1] != V[1] || V[2] != V[2]) ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gl->vel_r[i] = vel_r[i];
+    gl->V[i] = V[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    gl->Rvel_r[i] = Rvel_r[i];
+    gl->Rgva[i] = Rgva[i];
+    gl->R0a[i] = R0a[i];
+  }
+  gl->nan_v = nan_v;
+  rebvio_hip_pair_out& out = ga.rec->out;  // pinned host memory: plain stores, complete when the kernel ends
+  out.F = lm.F;
+  out.lm_accept_mask = lm.accept_mask;
+  out.sigma_rho_min = lm.sigma_rho_min;
+  int ext_ok = 1;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if (w.Xv[i] != w.Xv[i]) ext_ok = 0;
+  out.ext_ok = ext_ok;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    out.Vg[i] = Vg[i];
+    out.V[i] = V[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    out.P_Vg[i] = w.P_Vg[i];
+    out.R[i] = Rgva[i];
+    out.P_V[i] = P_V[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    out.Xv[i] = w.Xv[i];
+    out.Xgv[i] = Xgv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) out.W_Xv[i] = w.W[i];
+  out.klm_num = out.kf_matches = out.reg_num = 0;
+  out.status = nan_v;
 }
 
 }  // namespace rh

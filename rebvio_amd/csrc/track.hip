@@ -183,6 +183,29 @@ __device__ __forceinline__ float quantile_from_hist(const int* __restrict__ hist
   return sigma_rho;
 }
 
+// The same on a whole wave (bins <= 128, two per lane): an exclusive prefix over the lanes' pairs replaces the up to `bins`
+// dependent LDS reads of the loop above (1-2 us on a lone lane at the head of the persistent LM kernels). Integer counts:
+// the same bin whatever the order. Every lane of ONE wave calls it; every lane returns the result.
+__device__ __forceinline__ float quantile_from_hist_wave(const int* __restrict__ hist, int bins, float pct, int n, int lane) {
+  const int h0 = (2 * lane < bins) ? hist[2 * lane] : 0;
+  const int h1 = (2 * lane + 1 < bins) ? hist[2 * lane + 1] : 0;
+  int incl = h0 + h1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  const int before0 = incl - (h0 + h1), before1 = before0 + h0;  // running count when the loop reaches bin 2 lane / 2 lane + 1
+  const float thr = pct * (float)n;
+  const bool c0 = 2 * lane < bins && (float)before0 > thr;
+  const bool c1 = 2 * lane + 1 < bins && (float)before1 > thr;
+  const unsigned long long m = __ballot(c0 || c1);
+  if (m == 0ull) return 1e3f;
+  const int fl = __ffsll((long long)m) - 1;
+  const int first = 2 * fl + (__shfl((int)c0, fl) ? 0 : 1);
+  return float(first) * (kRhoMax - kRhoMin) / float(bins) + kRhoMin;
+}
+
 __global__ void k_quantile(MapDev m, const int* __restrict__ hist, int bins, float pct, float* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *out = quantile_from_hist(hist, bins, pct, m.st->n);
 }
@@ -1020,9 +1043,12 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   if (tid == 0) s = *st_in;
   if (tid < kChainGroups) carry_in[tid] = 0.f;
   __syncthreads();
-  if (tid == 0) {
-    s.sigma_rho_min = quantile_from_hist(shist, p.quantile_num_bins, p.quantile_cutoff, n);
-    for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
+  if (tid < 64) {
+    const float q = quantile_from_hist_wave(shist, p.quantile_num_bins, p.quantile_cutoff, n, tid);
+    if (tid == 0) {
+      s.sigma_rho_min = q;
+      for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
+    }
   }
   __syncthreads();
   const unsigned min_matches = min(p.min_match_threshold, frame_count);
@@ -1269,9 +1295,12 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   if (tid == 0) s = *st_in;
   if (tid < kChainGroups) carry_in[tid] = 0.f;
   __syncthreads();
-  if (tid == 0) {
-    s.sigma_rho_min = quantile_from_hist(shist, p.quantile_num_bins, p.quantile_cutoff, n);
-    for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
+  if (tid < 64) {
+    const float q = quantile_from_hist_wave(shist, p.quantile_num_bins, p.quantile_cutoff, n, tid);
+    if (tid == 0) {
+      s.sigma_rho_min = q;
+      for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i];
+    }
   }
   __syncthreads();
   const unsigned min_matches = min(p.min_match_threshold, frame_count);
@@ -1396,6 +1425,14 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     if (stamps[0] == 1ull && prev_end != 0ull && now > prev_end && now - prev_end < 100000ull) {
       stamps[40] += now - prev_end;
       stamps[41] += 1ull;
+      const unsigned long long t1 = stamps[48], t2 = stamps[49], t3 = stamps[50];
+      if (t1 > prev_end && t2 > t1 && t3 > t2 && now > t3) {  // start of the head, the tail, regularize / EKF of that pair
+        stamps[42] += t1 - prev_end;
+        stamps[43] += t2 - t1;
+        stamps[44] += t3 - t2;
+        stamps[45] += now - t3;
+        stamps[46] += 1ull;
+      }
     }
   }
   RH_STAMP(1);
@@ -2103,6 +2140,7 @@ __device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDe
                                                          float max_radius, int* __restrict__ work, int* __restrict__ work_n,
                                                          int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
   static_assert(kHeadSteps == 4, "eight probe slots per keyline");
+  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[48] = __builtin_amdgcn_s_memrealtime();
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int idx = gid >> 3, slot = gid & 7;  // keyline, probe slot (slot = 2 * step + side; side 0: tn, 1: tp)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -2200,6 +2238,7 @@ __device__ __forceinline__ void directed_match_tail_body(KParams p, MapDev nm, M
                                                              float max_radius, const int* __restrict__ work,
                                                              const int* __restrict__ work_n, int rot_, Mat3 R0_,
                                                              const GlueDev* __restrict__ gd) {
+  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[49] = __builtin_amdgcn_s_memrealtime();
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   // queue length, this wave's first entry (speculative: the queue array has kmax entries) and the parameter block are three
@@ -2471,6 +2510,7 @@ __device__ __forceinline__ void regularize_ekf_body(KParams p, MapDev m, Vec3 ve
                                                         int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
                                                         int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
   __shared__ int sh[128];
+  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[50] = __builtin_amdgcn_s_memrealtime();
   if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float2 rs = m.rs[idx];  // bound-free early loads, issued before the parameter block is read
