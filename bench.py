@@ -31,7 +31,7 @@ def pmc_traffic_bytes(kernel: str):
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs). Counters are in KiB; per
     MI355X_MICROARCH.md §HBM FETCH_SIZE reads half of a wide coalesced stream on gfx950 -> doubled; other access
     widths are uncalibrated, so this is an upper estimate for gather-style kernels. None when no pass is committed."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_hbm.json") for r in (2, 1)) if os.path.exists(q)), None)
+    path = pmc_profile_path()
     if path is None:
         return None
     try:
@@ -45,6 +45,10 @@ def pmc_traffic_bytes(kernel: str):
         return (2.0 * f + w) * 1024.0
     except Exception:
         return None
+
+
+def pmc_profile_path():
+    return next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_hbm.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
 
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
@@ -167,9 +171,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=None,
-                    help="untimed frames in front of the timed region, exactly as given (default 1000). The stream needs ~1000 "
-                         "frames until depths / match queues reach their steady state: a shorter warm-up is preceded by "
-                         "1000 - W untimed settle frames (config.settle_frames in the line)")
+                    help="untimed warm-up frames directly in front of the timed region (default 1000). NOTE: the stream needs ~1000 "
+                         "frames until depths / match queues reach their steady state, so when W < 1000 another 1000 - W untimed "
+                         "'settle' frames run BEFORE the W warm-up frames (reported as config.settle_frames): the timed window "
+                         "always measures the sustained rate, never the faster first frames of a stream")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--base-frames", type=int, default=24, help="distinct rendered frames (ping-pong replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,6 +183,7 @@ def main():
                     help="extra runs (N=1 only, never the headline): this many camera streams per GPU advanced in lock-step by "
                          "batched launches (rebvio_hip_batch_*); '' or 0 skips them")
     ap.add_argument("--no-host-class", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the extra window with every frame handed over from host memory")
     ap.add_argument("--batched-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--child-keylines", type=int, default=15000, help=argparse.SUPPRESS)
     ap.add_argument("--control-plane-only", action="store_true",
@@ -361,10 +367,36 @@ def main():
         long_elapsed = time.perf_counter() - tl0
         if world > 1:
             dist.barrier()
+    # ---- the same loop with every frame handed over from HOST memory (the reference's contract starts at a host image,
+    # rebvio.cpp:38-48): pinned ring + asynchronous copy ahead of the frame's scans. Reported as config.pcie_inclusive_fps,
+    # never as `value`.
+    pcie_steps = 0 if args.no_pcie else 1500
+    pcie_elapsed = 0.0
+    if pcie_steps:
+        barrier()
+        tp0 = time.perf_counter()
+        for _ in range(pcie_steps):
+            ctx.push_frame_u8(frames[int(order[k % len(order)])], k * 50000)
+            k += 1
+        torch.cuda.synchronize()
+        pcie_elapsed = time.perf_counter() - tp0
+        if world > 1:
+            dist.barrier()
     ctx.flush()
 
     tmax = shard.max_over_ranks(elapsed, world, "cuda" if backend_name == "nccl" else "cpu")
     long_tmax = shard.max_over_ranks(long_elapsed, world, "cuda" if backend_name == "nccl" else "cpu") if long_steps else 0.0
+    pcie_tmax = shard.max_over_ranks(pcie_elapsed, world, "cuda" if backend_name == "nccl" else "cpu") if pcie_steps else 0.0
+    # CPU baseline of an N-stream run: N instances of the restatement x 2 threads, one per rank, at the same
+    # time; rank 0 reports the sum. (N = 1: rank 0's own leg below, with the serial figure and the stage split.)
+    cpu_multi = None
+    if world > 1 and not args.no_cpu_baseline:
+        mine = cpu_baseline(frames, cam, cfg, args.base_frames, min(args.cpu_seconds, 10.0), serial_leg=False)
+        tot = shard.sum_over_ranks(mine["value"], world, "cuda" if backend_name == "nccl" else "cpu")
+        cpu_multi = {"value": tot, "unit": "frames/s", "cores": 2 * world, "kind": "port",
+                     "sample": f"{world} instances of the CPU restatement at the same time, one per rank on its own stream, detect || track "
+                               f"on 2 threads each; rank 0's instance: {mine['sample']}",
+                     "rank0": {k: mine[k] for k in ("value", "frames_run", "seconds", "keylines")}}
     bad = sum(1 for s in statuses if s not in (0, -1))  # -1: no finished pair to report in that call
     if bad:
         print(f"[rank {rank}] WARNING: {bad} of {steps} frame pairs ended with a non-zero tracking status", file=sys.stderr)
@@ -397,18 +429,32 @@ def main():
                                                 "the weight a short window gives to pipeline fill and drain"} if long_steps else None),
                        "parallelism": f"{world} independent streams, 1 per GPU",
                        "rank0_numa_node": numa_node,
-                       "pose_tolerance": "keyline set/order and every per-keyline output bit-exact vs the CPU restatement; pair "
-                                         "velocity within 5e-3 (rel.) of the restatement run with double-accumulated sums - the "
-                                         "sequential-fp32 restatement itself is 0.25-4.8 % from that (tests/test_parity_gpu.py)"},
+                       "pcie_inclusive_fps": (shard.whole_job_fps(world, pcie_steps, pcie_tmax) if pcie_steps else None),
+                       "pcie_inclusive_note": ("every frame handed over from host memory (rebvio_hip_push_frame_u8: pinned ring + async copy), "
+                                               f"{pcie_steps} frames right after the timed region; `value` is with frames resident in HBM"
+                                               if pcie_steps else None),
+                       "pose_tolerance": "keyline set/order and every per-keyline output bit-exact vs the CPU restatement (parity "
+                                         "unpinned: the reference holds no vector for this path); pair velocity within 1e-2 (rel.; "
+                                         "observed <= 5.5e-3) of the restatement run with double-accumulated sums while the LM decisions "
+                                         "agree - the sequential-fp32 restatement itself is 0.25-4.8 % from that "
+                                         "(tests/test_parity_gpu.py::test_stream_divergence_report)"},
             "frame_ms": percentiles_ms(push_done),
             "stage_us": stage_us(per_frame),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dominant),
+                         "traffic_source": (f"{os.path.relpath(pmc_profile_path(), ROOT)}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                                            "this command (separate runs, committed), 2 x FETCH_SIZE + WRITE_SIZE per launch - NOT measured in "
+                                            "this run" if pmc_profile_path() else None),
                          "avg_launch_us": dom_us, "launches": dom[1], "algorithmic_bytes_per_launch": ab,
                          "frame_algorithmic_bytes": 112 * npx + 1740 * n_keylines,
                          "frame_achieved_GBs": (112 * npx + 1740 * n_keylines) * (fps / world) / 1e9},
             "kernel_us_per_frame": {kname: round(v, 3) for kname, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
+            # per kernel: algorithmic bytes of one launch, its mean duration in the all-kernel event pass (24 frames, every launch
+            # bracketed by a HIP event pair on its stream: ~2-4 us above rocprofv3's figure for the short kernels), fraction of HBM peak
+            "kernel_roofline": kernel_roofline_table(prof, npx, n_keylines),
         }
+        if cpu_multi is not None:
+            result["cpu_baseline"] = cpu_multi
         if world == 1 and args.lanes not in ("", "0"):
             # Each batched run gets a process of its own: the HIP runtime maps streams onto a pool of hardware queues that
             # outlives the streams, and the batch's three streams must not end up sharing queues with this process's earlier
@@ -445,6 +491,20 @@ def main():
         os.dup2(2, 1)  # process-group teardown may log again
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_roofline_table(prof, npx, n_keylines):
+    out = {}
+    for kname, (us, calls) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        ab = algorithmic_bytes(kname, npx, n_keylines)
+        if kname in ("k_colscan", "k_colscan4"):
+            ab = (8 * npx + 16 * npx + 16 * npx) / 3.0
+        if not ab or us <= 0:
+            continue
+        gbs = ab / (us * 1e-6) / 1e9
+        out[kname] = {"algorithmic_bytes": ab, "avg_launch_us": round(us, 3), "launches": calls, "achieved_GBs": round(gbs, 1),
+                      "frac": round(gbs / HBM_PEAK_GBS, 5)}
+    return out
 
 
 def host_class_rate(frames, cam, cfg, n=4000):
@@ -526,7 +586,7 @@ def batched_run(lanes, frames0, cam, cfg, kw, base_frames, npx, n_keylines, step
             "frame_achieved_GBs": (112 * npx + 1740 * n_keylines) * fps / 1e9}
 
 
-def cpu_baseline(frames, cam, cfg, base_frames, seconds):
+def cpu_baseline(frames, cam, cfg, base_frames, seconds, serial_leg=True):
     """The CPU oracle (faithful port of the reference path: the reference itself cannot be built here) timed on this
     host: 2 threads per stream like the reference's detect/track workers (rebvio.cpp:28-29) = `value`, plus the serial
     1-thread figure, p50/p99 frame time and ms per stage at the reference's REBVIO_TIMER tick sites.
@@ -546,10 +606,15 @@ def cpu_baseline(frames, cam, cfg, base_frames, seconds):
     n2 = int(min(max(seconds * (2.0 / 3.0) / per, 30), 1000))
     idx2 = synth.pingpong_indices(base_frames, n2)
     res = O.Oracle(p, path).run_stream(frames, idx2, threads=2)
+    skip = min(20, res["frames"] // 2)  # servo warm-up of the sample (keyline count not settled yet)
+    if not serial_leg:
+        return {"value": res["frames"] / res["seconds"], "unit": "frames/s", "cores": 2, "kind": "port",
+                "sample": f"first {res['frames']} frames of the rank's {cam.width}x{cam.height} stream (g++ -O3 -march=native -ffp-contract=off), "
+                          f"{os.cpu_count()} host cpus visible",
+                "frames_run": int(res["frames"]), "seconds": res["seconds"], "keylines": int(np.median(res["keyline_counts"][skip:]))}
     n1 = max(20, n2 // 4)  # the serial leg costs ~2x per frame: a quarter of the frames = the remaining third of the budget
     idx1 = synth.pingpong_indices(base_frames, n1)
     res1 = O.Oracle(p, path).run_stream(frames, idx1, threads=1)
-    skip = min(20, res["frames"] // 2)  # servo warm-up of the sample (keyline count not settled yet)
     stage_ms = {k: v / res1["frames"] * 1e3 for k, v in res1["stage_seconds"].items()}
     return {"value": res["frames"] / res["seconds"], "unit": "frames/s", "cores": 2, "kind": "port",
             "sample": f"first {res['frames']} frames of the same {cam.width}x{cam.height} stream, detect || track on 2 threads "

@@ -267,6 +267,10 @@ int rebvio_hip_track_pair_hint_next(rebvio_hip_ctx* ctx, rebvio_hip_map* next_ne
  * (-7) while frames are in flight. */
 int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_dev, uint64_t ts_us,
                                     rebvio_hip_pair_out* out, int* keylines);
+/* The same for a MONO8 frame in HOST memory (what imageCallback is handed, rebvio.cpp:38-48): copied into a pinned ring here
+ * (the caller's buffer is free when the call returns) and from there to the device ahead of the frame's scans, in stream order. */
+int rebvio_hip_push_frame_u8(rebvio_hip_ctx* ctx, const uint8_t* frame_host, size_t pitch_bytes, uint64_t ts_us,
+                             rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_next_record(rebvio_hip_ctx* ctx, rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_flush(rebvio_hip_ctx* ctx);
 

@@ -100,6 +100,7 @@ SIGNATURES = {
     "rebvio_hip_track_pair_result": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "rebvio_hip_track_pair_hint_next": (C.c_int, [_vp, _vp]),
     "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
+    "rebvio_hip_push_frame_u8": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_next_record": (C.c_int, [_vp, C.POINTER(PairOut), _ip]),
     "rebvio_hip_flush": (C.c_int, [_vp]),
     "rebvio_hip_batch_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(_vp)]),
@@ -447,6 +448,14 @@ class Context:
         out = PairOut()
         n = C.c_int()
         _chk(lib().rebvio_hip_push_frame_u8_device(self.h, _vp(dev_addr), ts_us, C.byref(out), C.byref(n)))
+        return out, n.value
+
+    def push_frame_u8(self, frame_u8: np.ndarray, ts_us: int):
+        """Streaming push of a MONO8 frame in host memory (rows x cols, C-contiguous rows; a row pitch is taken from the array)."""
+        assert frame_u8.dtype == np.uint8 and frame_u8.shape == (self.rows, self.cols) and frame_u8.strides[1] == 1
+        out = PairOut()
+        n = C.c_int()
+        _chk(lib().rebvio_hip_push_frame_u8(self.h, _vp(frame_u8.ctypes.data), frame_u8.strides[0], ts_us, C.byref(out), C.byref(n)))
         return out, n.value
 
     def test_glue(self, vel, JtJ6, F, sigma_rho_min, accept_mask, xrv, n_new, frame_dt, Bg, W_Bg, R_prior):

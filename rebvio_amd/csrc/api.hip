@@ -215,7 +215,7 @@ struct rebvio_hip_ctx {
   std::vector<rebvio_hip_map*> pool;
   float* img_dev = nullptr;
   uint8_t* img8_dev = nullptr;
-  static constexpr int kPin = 4;  // pinned staging ring of the host-frame detect entries (allocated on first use)
+  static constexpr int kPin = 16;  // pinned staging ring of the host-frame detect entries (allocated on first use)
   void* pin[kPin]{};
   hipEvent_t pin_ev[kPin]{};
   bool pin_used[kPin]{};
@@ -598,9 +598,19 @@ void det_worker_main(rebvio_hip_ctx* c) {
   }
 }
 
-int detect_async(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_map** out) {
+int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, size_t row_bytes, int* slot_out, size_t* bytes_out);
+// host_u8 != null: a MONO8 frame in host memory, staged through the pinned ring; the worker queues its copy to the device
+// staging frame ahead of the scans (same stream: stream order is reuse order)
+int detect_async(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_map** out, const uint8_t* host_u8 = nullptr,
+                 size_t host_pitch = 0) {
   rebvio_hip_ctx::DetJob job;
+  if (host_u8) {
+    const int rcs = stage_host_frame(c, host_u8, host_pitch ? host_pitch : (size_t)c->P.cols, (size_t)c->P.cols, &job.pin_slot, &job.pin_bytes);
+    if (rcs) return rcs;
+    img_dev = c->img8_dev;
+  }
   int rc = detect_prepare(c, img_dev, is_u8, ts, &job);
+  if (rc && job.pin_slot >= 0) c->pin_staged[job.pin_slot].store(0, std::memory_order_release);
   if (rc) return rc;
   if (!c->det_thread.joinable()) c->det_thread = std::thread(det_worker_main, c);
   job.m->enqueued.store(0, std::memory_order_relaxed);
@@ -1998,8 +2008,9 @@ int stream_drain(rebvio_hip_ctx* c) {
 }
 }  // namespace
 
-int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
-                                    int* keylines) {
+namespace {
+int push_frame(rebvio_hip_ctx* c, const uint8_t* frame_dev, const uint8_t* frame_host, size_t host_pitch, uint64_t ts_us, rebvio_hip_pair_out* out,
+               int* keylines) {
   // Software pipeline over the three HIP streams of the context:
   //   scan / keyline streams : frame f (this call, through the detect worker)
   //   track stream           : see the comment above stream_wait_maps
@@ -2019,7 +2030,7 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   }
   if (keylines) *keylines = -1;
   c->min_pool = c->lead + 3 * c->group + 3;
-  int rc = detect_async(c, frame_dev, 1, ts_us, &m);
+  int rc = detect_async(c, frame_dev, 1, ts_us, &m, frame_host, host_pitch);
   if (rc) return rc;
   {
     std::lock_guard<std::mutex> lk(c->det_mu);  // written by the detect worker
@@ -2045,6 +2056,19 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev,
   return 0;
 }
 
+}  // namespace
+
+int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* c, const uint8_t* frame_dev, uint64_t ts_us, rebvio_hip_pair_out* out,
+                                    int* keylines) {
+  return push_frame(c, frame_dev, nullptr, 0, ts_us, out, keylines);
+}
+
+int rebvio_hip_push_frame_u8(rebvio_hip_ctx* c, const uint8_t* frame_host, size_t pitch_bytes, uint64_t ts_us, rebvio_hip_pair_out* out,
+                             int* keylines) {
+  if (!frame_host) return fail_msg("push_frame_u8: null frame", -3);
+  return push_frame(c, nullptr, frame_host, pitch_bytes, ts_us, out, keylines);
+}
+
 int rebvio_hip_next_record(rebvio_hip_ctx* c, rebvio_hip_pair_out* out, int* keylines) {
   if (c->done.empty()) return 0;
   if (out) *out = c->done.front().out;
@@ -2067,6 +2091,12 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     if (c->lm_stamps[41])
       std::fprintf(stderr, "[rebvio_hip] end of an LM launch -> start of the next (second half of the pair + stream operations), mean over %llu: %.2f us\n",
                    (unsigned long long)c->lm_stamps[41], (double)c->lm_stamps[40] * 0.01 / (double)c->lm_stamps[41]);
+    if (c->lm_stamps[55]) {
+      const double m = 0.01 / (double)c->lm_stamps[55];
+      std::fprintf(stderr, "[rebvio_hip]   device glue: wait for + sum the extRotVel records %.2f  6x6 solve (wave 0) %.2f  until every wave is there %.2f  "
+                   "X, SO3, covariance, records %.2f\n", (double)c->lm_stamps[51] * m, (double)c->lm_stamps[52] * m, (double)c->lm_stamps[53] * m,
+                   (double)c->lm_stamps[54] * m);
+    }
     if (c->lm_stamps[46]) {
       const double m = 0.01 / (double)c->lm_stamps[46];
       std::fprintf(stderr, "[rebvio_hip]   of which: LM end -> head start %.2f  head start -> tail start %.2f  tail start -> regularize/EKF start %.2f  "

@@ -245,7 +245,8 @@ __device__ __forceinline__ bool glue_sym6_ldlt_lanes(const float* A_ /*LDS*/, co
 // Called by EVERY thread of workgroup 0 (>= 256 threads) once the sums of the extRotVel records are in w.W / w.JtF
 // (symmetrised float matrix and vector, as hm::sum_xrv leaves them) and `lm` holds the final minimizeVel state.
 // One workgroup barrier inside. Results: *gd_copy (second half of the pair), *st_out (filter state after the pair), *rec.
-__device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*LDS*/, const GlueArgs& ga) {
+__device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*LDS*/, const GlueArgs& ga,
+                                               unsigned long long* stamps = nullptr /*diagnostic: [17] solves done, [18] all waves there*/) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float s_b = ga.gp.gyro_bias_std_dev * ga.gp.gyro_bias_std_dev * ga.gp.frame_dt * ga.gp.frame_dt;
   const float s_g = ga.gp.gyro_std_dev * ga.gp.gyro_std_dev * ga.gp.frame_dt * ga.gp.frame_dt;
@@ -253,6 +254,7 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
     // ---- the 6x6 solve of extRotVel (core.cpp:244-248) ----
     const bool ok = glue_sym6_ldlt_lanes(w.W, w.JtF, w.Xv, w.Ld, lane);
     if (!ok && lane == 0) hm::sym6_pinv_solve_ws(w.W, w.JtF, w.Xv, w.ws);
+    if (stamps && tid == 0) stamps[17] = __builtin_amdgcn_s_memrealtime();
   } else if (wid == 1) {
     // ---- gyroBiasCorrection up to inverse(Wxb) (core.cpp:264-276) ----
     glue_gyro3(w.m3[0], ga.st_in, s_g, s_b, 2, lane);
@@ -285,6 +287,7 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
     glue_invert3_one(w.JtJ9, w.P_Vg, lane);
   }
   __syncthreads();
+  if (stamps && tid == 0) stamps[18] = __builtin_amdgcn_s_memrealtime();
   if (wid >= 2) return;
   // Both remaining waves form X (core.cpp:273-276) for themselves: X1 = Wx * X (+ (Wg iWgWb Wb) dgbias with dgbias = 0 on
   // entry, as the reference computes it), X = inverse(Wxb) * X1.

@@ -280,7 +280,27 @@ __device__ void lm_step(LmState& s_lds, const float* red_lds, int call, bool fin
   lm_step_regs(t, r, call, final_only);
   s_lds = t;
 }
-__device__ __forceinline__ void lm_step_regs(LmState& s, const float (&red)[10], int call, bool final_only) {
+// core.cpp:180-183: the matrix JtJ + u * Identity as TooN forms it (every element gets its term), and the trial point from
+// its inverse
+__device__ __forceinline__ void lm_step_matrix(const LmState& s, float (&M)[9]) {
+  sym6_to_9(s.JtJ, M);
+  M[0] = M[0] + 1.0f * s.u;
+  M[4] = M[4] + 1.0f * s.u;
+  M[8] = M[8] + 1.0f * s.u;
+  M[1] = M[1] + 0.0f * s.u; M[2] = M[2] + 0.0f * s.u; M[3] = M[3] + 0.0f * s.u;
+  M[5] = M[5] + 0.0f * s.u; M[6] = M[6] + 0.0f * s.u; M[7] = M[7] + 0.0f * s.u;
+}
+__device__ __forceinline__ void lm_step_apply(LmState& s, const float (&inv)[9]) {
+  const float neg[3] = {-s.JtF[0], -s.JtF[1], -s.JtF[2]};
+  for (int i = 0; i < 3; ++i) {
+    float acc = 0;
+    for (int k = 0; k < 3; ++k) acc += inv[i * 3 + k] * neg[k];
+    s.h[i] = acc;
+  }
+  for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i] + s.h[i];
+}
+// the accept / reject bookkeeping of one step (core.cpp:161-179)
+__device__ __forceinline__ void lm_step_book(LmState& s, const float (&red)[10], int call) {
   if (call == 1) {
     s.F = red[0];
     for (int i = 0; i < 6; ++i) s.JtJ[i] = red[1 + i];
@@ -312,23 +332,52 @@ __device__ __forceinline__ void lm_step_regs(LmState& s, const float (&red)[10],
       s.v = (float)((double)s.v * 2.0);
     }
   }
+}
+__device__ __forceinline__ void lm_step_regs(LmState& s, const float (&red)[10], int call, bool final_only) {
+  lm_step_book(s, red, call);
   if (call >= 1 && !final_only) {
     float M[9], inv[9];
-    sym6_to_9(s.JtJ, M);
-    M[0] = M[0] + 1.0f * s.u;
-    M[4] = M[4] + 1.0f * s.u;
-    M[8] = M[8] + 1.0f * s.u;
-    M[1] = M[1] + 0.0f * s.u; M[2] = M[2] + 0.0f * s.u; M[3] = M[3] + 0.0f * s.u;
-    M[5] = M[5] + 0.0f * s.u; M[6] = M[6] + 0.0f * s.u; M[7] = M[7] + 0.0f * s.u;
+    lm_step_matrix(s, M);
     invert3(M, inv);
-    const float neg[3] = {-s.JtF[0], -s.JtF[1], -s.JtF[2]};
-    for (int i = 0; i < 3; ++i) {
-      float acc = 0;
-      for (int k = 0; k < 3; ++k) acc += inv[i * 3 + k] * neg[k];
-      s.h[i] = acc;
-    }
-    for (int i = 0; i < 3; ++i) s.Vnew[i] = s.vel[i] + s.h[i];
+    lm_step_apply(s, inv);
   }
+}
+
+// The same step on a whole wave (every lane of wave 0 of a workgroup calls it, every workgroup alike): the bookkeeping on
+// registers in every lane, the 3x3 inverse with one cofactor per lane (nine divisions side by side instead of in a row: the
+// lone thread's step cost 0.9 us three times per launch), the new trial point from the inverse in LDS. Same operations per
+// element, same bits. inv_lds: 9 floats of LDS.
+__device__ __forceinline__ void lm_step_wave(LmState& s_lds, const float* red_lds, int call, bool final_only, float* inv_lds, int lane) {
+  LmState t = s_lds;
+  float r[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r[i] = red_lds[i];
+  lm_step_book(t, r, call);
+  if (call >= 1 && !final_only) {
+    float M[9];
+    lm_step_matrix(t, M);
+    const float d = glue_det3(M);
+    float o;
+    switch (lane) {
+      case 0: o = M[4] * M[8] - M[5] * M[7]; break;
+      case 1: o = M[2] * M[7] - M[1] * M[8]; break;
+      case 2: o = M[1] * M[5] - M[2] * M[4]; break;
+      case 3: o = M[5] * M[6] - M[3] * M[8]; break;
+      case 4: o = M[0] * M[8] - M[2] * M[6]; break;
+      case 5: o = M[2] * M[3] - M[0] * M[5]; break;
+      case 6: o = M[3] * M[7] - M[4] * M[6]; break;
+      case 7: o = M[1] * M[6] - M[0] * M[7]; break;
+      default: o = M[0] * M[4] - M[1] * M[3]; break;
+    }
+    glue_wave_sync();  // (the previous step's inverse has been read by every lane)
+    if (lane < 9) inv_lds[lane] = o / d;
+    glue_wave_sync();
+    float inv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) inv[i] = inv_lds[i];
+    lm_step_apply(t, inv);
+  }
+  if (lane == 0) s_lds = t;
 }
 
 // Shared prologue: fixed-order reduction of the previous tryVel call's block records + carry-in of the
@@ -951,7 +1000,8 @@ __device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const La
 // glue (glue_dev.hpp). The other workgroups leave right after publishing. stage: LDS, stage_groups * 32 floats.
 template <int kChainThreads>
 __device__ __forceinline__ void lm_tail_glue(const GlueArgs& ga, unsigned long long* __restrict__ xch_xrv, unsigned tag, int n_new,
-                                             float* stage, int stage_groups, GlueLds& gw, const LmState& s, int* err, int slow) {
+                                             float* stage, int stage_groups, GlueLds& gw, const LmState& s, int* err, int slow,
+                                             unsigned long long* stamps) {
   if (blockIdx.x != 0) return;
   const int tid = threadIdx.x;
   const int nb = (n_new + 255) / 256;
@@ -994,7 +1044,8 @@ __device__ __forceinline__ void lm_tail_glue(const GlueArgs& ga, unsigned long l
     gw.JtF[tid - 21] = (float)acc;
   }
   __syncthreads();
-  glue_workgroup(gw, s, ga);
+  if (stamps && tid == 0) stamps[16] = __builtin_amdgcn_s_memrealtime();
+  glue_workgroup(gw, s, ga, stamps);
 }
 
 template <int kChainThreads>
@@ -1007,6 +1058,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
                                                             unsigned long long* __restrict__ stamps, int slow_poll, const GlueArgs ga) {
   constexpr int kChainGroups = kChainThreads / 256;
   __shared__ GlueLds gw;
+  __shared__ float lm_inv[9];
   // optional phase stamps of workgroup 0 (REBVIO_HIP_LM_STAMPS diagnostic): 100 MHz constant clock
 #define RH_STAMP(i) \
   do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1067,7 +1119,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
       chain_collect_records<kChainThreads>(xch + (size_t)((call - 1) & 1) * nrec_launched * kPartStride, tag_base + (unsigned)call, nblocks,
                                            rec, red, carry_in, bar_err, slow_poll);
       RH_STAMP(1 + call * 6 + 1);
-      if (tid == 0) lm_step(s, red, call, false);
+      if (tid < 64) lm_step_wave(s, red, call, false, lm_inv, tid);
       __syncthreads();
     } else {
       RH_STAMP(1 + call * 6 + 1);
@@ -1217,7 +1269,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   RH_STAMP(2 + calls * 6);
   if (ga.lm) {
     __syncthreads();  // (rec is free: every LM collect is over)
-    lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, rec, kMaxRecBlocks * kPartStride / kXrvStride, gw, s, bar_err, slow_poll);
+    lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, rec, kMaxRecBlocks * kPartStride / kXrvStride, gw, s, bar_err, slow_poll, stamps);
   }
 #undef RH_STAMP
 }
@@ -1251,6 +1303,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   constexpr int kChainGroups = kChainThreads / 256;
   constexpr int kWaves = kChainThreads / 64;
   __shared__ GlueLds gw;
+  __shared__ float lm_inv[4][9];
   // REBVIO_HIP_LM_STAMPS: 1 start, 2/3 evaluations 0/1 published, 4 hypothesis states ready, speculative evaluations: 5 projected,
   // 6 gathers issued, 7 matches known, 8 neighbour round done, 9 weighted sums done, 10 published; 11 all record sets staged and
   // reduced, 12 hypothesis checked, 13 LM done, 14 extRotVel rows out (stamps[0] = 1 marks the layout)
@@ -1405,7 +1458,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   auto normal_pass = [&](int call, int phase) {
     if (call >= 1) {
       collect(call - 1, tag_of(call - 1, (phase == 1 && call - 1 >= fa + 3) ? 1 : 0));
-      if (tid == 0) lm_step(s, red, call, false);
+      if (tid < 64) lm_step_wave(s, red, call, false, lm_inv[0], tid);
       __syncthreads();
     }
     TvProj pj{};
@@ -1425,6 +1478,14 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     if (stamps[0] == 1ull && prev_end != 0ull && now > prev_end && now - prev_end < 100000ull) {
       stamps[40] += now - prev_end;
       stamps[41] += 1ull;
+      const unsigned long long g0 = stamps[14], g1 = stamps[16], g2 = stamps[17], g3 = stamps[18];
+      if (g1 > g0 && g2 > g1 && g3 >= g2 && prev_end > g3) {  // glue of the previous launch: sums in, solve done, all waves done, end
+        stamps[51] += g1 - g0;
+        stamps[52] += g2 - g1;
+        stamps[53] += g3 - g2;
+        stamps[54] += prev_end - g3;
+        stamps[55] += 1ull;
+      }
       const unsigned long long t1 = stamps[48], t2 = stamps[49], t3 = stamps[50];
       if (t1 > prev_end && t2 > t1 && t3 > t2 && now > t3) {  // start of the head, the tail, regularize / EKF of that pair
         stamps[42] += t1 - prev_end;
@@ -1442,24 +1503,54 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     normal_pass(1, 0);
     RH_STAMP(3);
     collect(1, tag_of(1, 0));
-    if (tid == 0) {
-      lm_step(s, red, 2, false);
-      stc[0] = s;
+    if (tid < 64) {
+      lm_step_wave(s, red, 2, false, lm_inv[0], tid);
+      if (tid == 0) stc[0] = s;
     }
     __syncthreads();
-    // states under the hypothesis: thread j applies j rejections' (u, v) updates and then one lm_step whose score is NaN (the
-    // gain test fails for any denominator): exactly the reject branch of core.cpp:180-183 plus the next trial point
-    if (tid < nspec - 1) {
-      LmState t = s;
-      for (int j = 0; j < tid; ++j) {
-        t.u *= t.v;
-        t.v = (float)((double)t.v * 2.0);
-      }
-      float fake[10];
+    // states under the hypothesis: state g + 1 applies g rejections' (u, v) updates and then one lm_step whose score is NaN (the
+    // gain test fails for any denominator): exactly the reject branch of core.cpp:180-183 plus the next trial point. Sixteen
+    // lanes per state, nine of them with one cofactor of its 3x3 inverse each (see lm_step_wave).
+    for (int g0 = 0; g0 < nspec - 1; g0 += 4) {
+      if (tid < 64) {
+        const int g = g0 + (tid >> 4), e = tid & 15;
+        const bool act = g < nspec - 1;
+        LmState t = s;
+        for (int j = 0; j < g; ++j) {
+          t.u *= t.v;
+          t.v = (float)((double)t.v * 2.0);
+        }
+        float fake[10];
 #pragma unroll
-      for (int i = 0; i < 10; ++i) fake[i] = __uint_as_float(0x7FC00000u);
-      lm_step_regs(t, fake, 3 + tid, false);
-      stc[tid + 1] = t;
+        for (int i = 0; i < 10; ++i) fake[i] = __uint_as_float(0x7FC00000u);
+        lm_step_book(t, fake, 3 + g);
+        float M[9];
+        lm_step_matrix(t, M);
+        const float d = glue_det3(M);
+        float o;
+        switch (e) {
+          case 0: o = M[4] * M[8] - M[5] * M[7]; break;
+          case 1: o = M[2] * M[7] - M[1] * M[8]; break;
+          case 2: o = M[1] * M[5] - M[2] * M[4]; break;
+          case 3: o = M[5] * M[6] - M[3] * M[8]; break;
+          case 4: o = M[0] * M[8] - M[2] * M[6]; break;
+          case 5: o = M[2] * M[3] - M[0] * M[5]; break;
+          case 6: o = M[3] * M[7] - M[4] * M[6]; break;
+          case 7: o = M[1] * M[6] - M[0] * M[7]; break;
+          default: o = M[0] * M[4] - M[1] * M[3]; break;
+        }
+        glue_wave_sync();
+        if (act && e < 9) lm_inv[tid >> 4][e] = o / d;
+        glue_wave_sync();
+        if (act && e == 0) {
+          float inv[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) inv[i] = lm_inv[tid >> 4][i];
+          lm_step_apply(t, inv);
+          stc[g + 1] = t;
+        }
+        glue_wave_sync();
+      }
     }
     __syncthreads();
     RH_STAMP(4);
@@ -1754,7 +1845,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     __syncthreads();  // (recm is free: every LM collect is over)
     // recm holds (calls - 2) record sets of 16 words per launched group: at least 32 floats per group
     lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, recm, (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride > 0
-                                    ? (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride : 1, gw, s, bar_err, slow_poll);
+                                    ? (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride : 1, gw, s, bar_err, slow_poll, stamps);
     RH_STAMP(15);
   }
 #undef RH_STAMP

@@ -69,6 +69,15 @@ def max_over_ranks(seconds: float, world: int, device="cpu") -> float:
     return float(t.item())
 
 
+def sum_over_ranks(value: float, world: int, device="cpu") -> float:
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def whole_job_fps(world: int, steps_per_rank: int, tmax: float) -> float:
     """Every rank pushes `steps_per_rank` frames of its own stream: aggregate = all frames / slowest rank's time."""
     return world * steps_per_rank / tmax

@@ -847,6 +847,35 @@ def test_streaming_records_do_not_depend_on_the_lm_kernel_choice(B, c2_stream, m
     assert 1 in masks and len(masks) >= 3, masks   # consecutive-like pairs and several kinds of later accepts
 
 
+def test_host_frame_stream_equals_device_frame_stream(B, c2_stream):
+    """rebvio_hip_push_frame_u8 (MONO8 frames in host memory, staged through the pinned ring and copied ahead of the scans, the
+    entry the reference's imageCallback corresponds to, rebvio.cpp:38-48) against frames resident in HBM: the same records.
+    Frames are handed over from ONE reused host buffer (overwritten right after each call) and from a padded array (row
+    pitch > cols)."""
+    from rebvio_amd import synth
+    frames, cam = c2_stream
+    order = synth.pingpong_indices(len(frames), 45)
+    npx = cam.width * cam.height
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    dev = ctx.upload_frames(frames)
+    want = [pair_tuple(o, n) for o, n in run_stream(ctx, dev, order, npx)]
+    ctx.close()
+    ctx = B.Context(params_for(B, cam, **KW_C2))
+    buf = np.zeros((cam.height, cam.width + 24), np.uint8)
+    got = []
+    for k, i in enumerate(order):
+        view = buf[:, :cam.width] if k % 2 else np.ascontiguousarray(frames[i])
+        if k % 2:
+            view[:] = frames[i]
+        out, n = ctx.push_frame_u8(view, k * 50000)
+        buf[:] = 0                                    # the caller's buffer is its own again as soon as the push returns
+        if out.status >= 0:
+            got.append(pair_tuple(out, n))
+    got.extend(pair_tuple(o, n) for o, n in ctx.flush())
+    ctx.close()
+    assert len(got) == len(order) - 1 and got == want
+
+
 def test_stream_continues_cleanly_after_a_flush(B, c2_stream):
     """rebvio_hip_flush() in the middle of a stream: the stream that follows must start like a fresh one. The last second
     half before the flush has already binned the sigma histogram for a pair that never comes; those counts used to put the

@@ -33,7 +33,8 @@ def _worker(rank, world, port, q):
     elapsed = 1.0 + rank  # rank 1 is the slow one
     tmax = shard.max_over_ranks(elapsed, world)
     fps = shard.whole_job_fps(world, 100, tmax)
-    q.put((rank, int(frames.sum()), n, tmax, fps))
+    cpu_sum = shard.sum_over_ranks(70.0 + rank, world)   # N instances of the CPU baseline, one per rank: the sum is reported
+    q.put((rank, int(frames.sum()), n, tmax, fps, cpu_sum))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,7 +52,8 @@ def test_two_ranks_independent_streams():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, sum0, n0, t0, f0), (r1, sum1, n1, t1, f1) = res
+    (r0, sum0, n0, t0, f0, c0), (r1, sum1, n1, t1, f1, c1) = res
+    assert c0 == c1 == 141.0
     assert (r0, r1) == (0, 1)
     assert sum0 != sum1                      # different scenes per rank
     assert n0 > 0 and n1 > 0
