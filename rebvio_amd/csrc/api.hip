@@ -513,7 +513,7 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   DetectBufs db = c->db;
   db.rowcount = c->rowcount2[b];
   if (j.pin_slot >= 0) {  // host frame: pinned slot -> device staging frame, read by this stream's own kernels only
-    HIPCHK(hipMemcpyAsync(const_cast<void*>(j.img), c->pin[j.pin_slot], j.pin_bytes, hipMemcpyHostToDevice, c->s_det));
+    launch_copy_from_pinned(c->s_det, c->pin[j.pin_slot], const_cast<void*>(j.img), j.pin_bytes);
     HIPCHK(hipEventRecord(c->pin_ev[j.pin_slot], c->s_det));
     c->pin_staged[j.pin_slot].store(0, std::memory_order_release);
   }
@@ -762,7 +762,7 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
 int stage_host_frame(rebvio_hip_ctx* c, const void* img, size_t pitch_bytes, size_t row_bytes, int* slot_out, size_t* bytes_out) {
   if (!c->pin[0]) {
     for (int i = 0; i < rebvio_hip_ctx::kPin; ++i) {
-      HIPCHK(hipHostMalloc(&c->pin[i], (size_t)c->P.rows * c->P.cols * sizeof(float), hipHostMallocDefault));
+      HIPCHK(hipHostMalloc(&c->pin[i], (size_t)c->P.rows * c->P.cols * sizeof(float) + 16, hipHostMallocDefault));  // (+16: copied in whole 16-byte units)
       HIPCHK(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
     }
   }
@@ -973,8 +973,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     d0[i].pad = 0;
   }
   HIPCHK(hipMemcpy(c->det, d0, sizeof(d0), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&c->img_dev, Pn * sizeof(float)));
-  HIPCHK(hipMalloc(&c->img8_dev, Pn));
+  HIPCHK(hipMalloc(&c->img_dev, Pn * sizeof(float) + 16));  // (+16: host frames arrive in whole 16-byte units)
+  HIPCHK(hipMalloc(&c->img8_dev, Pn + 16));
   HIPCHK(hipMalloc(&c->aos_dev, (size_t)p->keylines_max * sizeof(rebvio_hip_keyline)));
   HIPCHK(hipMalloc(&c->scratch_i, 2 * Pn * sizeof(int)));
 

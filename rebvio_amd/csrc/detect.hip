@@ -1228,6 +1228,18 @@ __global__ __launch_bounds__(256) void k_front_end_u8_b(const LaneStatic* __rest
   front_end_body(static_cast<const uint8_t*>(dyn.v[lane].img), L.undist_map, L.undist_img[dyn.v[lane].parity], rows, cols);
 }
 
+// Host frame -> device staging frame as a kernel of the scan stream (16 bytes per lane straight from the pinned ring slot over
+// PCIe): a hipMemcpyAsync there is a packet for the DMA engine with its own cross-engine synchronisation in front of and
+// behind it, which cost the scan stream more than the transfer itself (measured: 8.2k frames/s with the DMA copy).
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+void launch_copy_from_pinned(hipStream_t s, const void* src_pinned, void* dst_dev, size_t bytes) {
+  const int n16 = (int)((bytes + 15) / 16);  // (both buffers are allocated in whole 16-byte units)
+  RH_LAUNCH(k_copy16, dim3(div_up(n16, 256)), dim3(256), 0, s, (const uint4*)src_pinned, (uint4*)dst_dev, n16);
+}
+
 void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, const int2* map, float* dst) {
   RH_LAUNCH(k_front_end_u8, dim3(div_up(p.rows * p.cols, 256)), dim3(256), 0, s, src, map, dst, p.rows, p.cols);
 }
