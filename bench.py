@@ -342,6 +342,7 @@ def main():
     matches = []
     push_done = np.zeros(steps, np.float64)
     barrier()
+    pairs_before = ctx.pairs_started()
     t0 = time.perf_counter()
     for j in range(steps):
         out, n = push(k)
@@ -351,6 +352,7 @@ def main():
         k += 1
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    pairs_in_window = ctx.pairs_started() - pairs_before
     if world > 1:
         dist.barrier()
     elapsed = t1 - t0
@@ -424,6 +426,10 @@ def main():
             "config": {"workload": cfg["name"], "streams": world, "keylines": n_keylines,
                        "mean_matches": float(np.mean([m for m in matches if m > 0])) if any(m > 0 for m in matches) else 0.0,
                        "frames_in_hbm": args.base_frames, "settle_frames": settle,
+                       # a step = one frame pushed: its detection + the tracking of an earlier pair. Pairs are queued in groups, so
+                       # a window may start a few pairs more or fewer than it pushes frames (the difference is frames waiting in the
+                       # queue at its ends); over the long window the two are equal
+                       "pairs_tracked_in_window": pairs_in_window,
                        "long_window": ({"steps": long_steps, "value": shard.whole_job_fps(world, long_steps, long_tmax), "unit": "frames/s",
                                         "note": "same loop, bracketed the same way, right after the timed region: the rate without "
                                                 "the weight a short window gives to pipeline fill and drain"} if long_steps else None),

@@ -272,6 +272,9 @@ int rebvio_hip_push_frame_u8_device(rebvio_hip_ctx* ctx, const uint8_t* frame_de
 int rebvio_hip_push_frame_u8(rebvio_hip_ctx* ctx, const uint8_t* frame_host, size_t pitch_bytes, uint64_t ts_us,
                              rebvio_hip_pair_out* out, int* keylines);
 int rebvio_hip_next_record(rebvio_hip_ctx* ctx, rebvio_hip_pair_out* out, int* keylines);
+/* Frame pairs the streaming driver has queued on the device so far (a measurement aid: pairs are queued in groups, so a short
+ * window of pushes may start a few pairs more or fewer than it pushes frames). */
+uint64_t rebvio_hip_pairs_started(rebvio_hip_ctx* ctx);
 int rebvio_hip_flush(rebvio_hip_ctx* ctx);
 
 /* Several camera streams on ONE GPU, advanced in lock-step ("lanes" of a batch). The reference runs one rebvio::Rebvio per

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rebvio_hip_push_frame_u8_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_push_frame_u8": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.POINTER(PairOut), _ip]),
     "rebvio_hip_next_record": (C.c_int, [_vp, C.POINTER(PairOut), _ip]),
+    "rebvio_hip_pairs_started": (C.c_uint64, [_vp]),
     "rebvio_hip_flush": (C.c_int, [_vp]),
     "rebvio_hip_batch_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(_vp)]),
     "rebvio_hip_batch_destroy": (None, [_vp]),
@@ -476,6 +477,10 @@ class Context:
         for i in range(2):
             res.append((outs[i], sts[i], sec[i]))
         return res
+
+    def pairs_started(self) -> int:
+        """Frame pairs the streaming driver has queued on the device so far."""
+        return int(lib().rebvio_hip_pairs_started(self.h))
 
     def next_record(self):
         """The oldest complete pair record not handed out yet, or None."""

@@ -2040,10 +2040,17 @@ int push_frame(rebvio_hip_ctx* c, const uint8_t* frame_dev, const uint8_t* frame
   c->t_detect_enq += std::chrono::duration<double, std::micro>(td1 - td0).count();
   c->t_frames++;
   c->frames.push_back(m);
-  if ((int)c->frames.size() >= c->lead + c->group - 1) {
-    // the newest map of the group was detected at least lead - 2 calls ago: the track stream will not stall on it
-    rc = stream_enqueue_group(c, c->group);
-    if (rc) return rc;
+  {
+    // Full groups while the device has pairs queued (fewest stream operations per pair); as soon as it is about to run dry - a
+    // stream's start, or right after the caller synchronised - whatever can start is started at once, down to single pairs.
+    // Either way the newest map of a group was handed to the detect worker at least lead - 2 calls ago.
+    const int Q = (int)c->frames.size();
+    const bool shallow = (int)c->inflight.size() < c->group;
+    const int npairs = shallow ? std::min(c->group, Q - c->lead + 1) : (Q >= c->lead + c->group - 1 ? c->group : 0);
+    if (npairs >= 1) {
+      rc = stream_enqueue_group(c, npairs);
+      if (rc) return rc;
+    }
   }
   c->t_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td1).count();
   rc = stream_harvest(c, 0);
@@ -2068,6 +2075,8 @@ int rebvio_hip_push_frame_u8(rebvio_hip_ctx* c, const uint8_t* frame_host, size_
   if (!frame_host) return fail_msg("push_frame_u8: null frame", -3);
   return push_frame(c, nullptr, frame_host, pitch_bytes, ts_us, out, keylines);
 }
+
+uint64_t rebvio_hip_pairs_started(rebvio_hip_ctx* c) { return c->pair_seq; }
 
 int rebvio_hip_next_record(rebvio_hip_ctx* c, rebvio_hip_pair_out* out, int* keylines) {
   if (c->done.empty()) return 0;
@@ -2831,11 +2840,16 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   b->step++;
 
   // ---- track stage: the step's pairs, whole, for every lane; then whatever records have become complete ----
-  if ((int)b->frames.size() >= b->lead + b->group - 1) {
-    const int rc = batch_enqueue_group(b, b->group);
-    if (rc) {
-      b->poisoned = true;
-      return rc;
+  {
+    const int Q = (int)b->frames.size();  // (group size by queue depth: see push_frame)
+    const bool shallow = (int)b->inflight.size() < b->group;
+    const int nsteps = shallow ? std::min(b->group, Q - b->lead + 1) : (Q >= b->lead + b->group - 1 ? b->group : 0);
+    if (nsteps >= 1) {
+      const int rc = batch_enqueue_group(b, nsteps);
+      if (rc) {
+        b->poisoned = true;
+        return rc;
+      }
     }
   }
   int rc = batch_harvest(b, 0);
