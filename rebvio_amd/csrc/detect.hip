@@ -509,47 +509,86 @@ __global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict_
 }
 
 // ---- last box pass of both filters fused with DoG and squared gradient (scale_space.cpp:210-233) ------
+// Tile of the last box pass + DoG + gradient: 64 columns x kDogRows rows per workgroup (256 threads, four rows each). The
+// two integral images are staged in LDS once per tile - the rows and columns the tile's box sums touch: (kDogRows + 2 + d)
+// x (64 + 2 + d) for scale 0 (its 3 x 3 gradient stencil needs a one-pixel ring of averages), (kDogRows + d) x (64 + d)
+// for scale 1 - and every box average takes its four corners from there: ~3.6 global loads per pixel instead of ~10 with the
+// corners fetched per pixel (PMC, 8-lane batch: 2 x FETCH_SIZE 88 MB per launch against 39 MB of integral images).
+// box_avg is handed the LDS tile as if it were the whole image (base pointer shifted by the tile's origin, LDS pitch): the
+// same border cases, the same operand order, the same bits.
+constexpr int kDogMaxD = 11;                                   // box widths 3..11 (rebvio_hip_create checks)
+constexpr int kDogPitch = 64 + 2 + kDogMaxD + 1;               // 78 (even pitch, rows staged with consecutive lanes: conflict-free)
+// kDogRows: see kTileRowsSingle
+template <int kDogRows>
 __device__ __forceinline__ void dog_mag_body(const float* __restrict__ II0, const float* __restrict__ II1, int d0,
                                                  int d1, float* __restrict__ dog, float* __restrict__ mag,
                                                  float* __restrict__ scale0, float* __restrict__ scale1, int R, int C,
                                                  int* __restrict__ rowcount) {
+  constexpr int kDogTileRows = kDogRows + 2 + kDogMaxD;
   const int ld = (C + 3) & ~3;  // pitch of the integral images
-  __shared__ float s0[6][66];
-  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
+  __shared__ float t0[kDogTileRows * kDogPitch];
+  __shared__ float t1[kDogTileRows * kDogPitch];
+  __shared__ float s0[kDogRows + 2][66];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * kDogRows;
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  for (int i = tid; i < 6 * 66; i += 256) {
-    const int lr = i / 66, lc = i - lr * 66;
-    const int r = r0 + lr - 1, c = c0 + lc - 1;
-    s0[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? box_avg(II0, r, c, d0, R, C, ld) : 0.0f;
+  const int h0 = d0 >> 1, h1 = d1 >> 1;
+  // scale 0: averages at rows r0-1 .. r0+kDogRows, columns c0-1 .. c0+64 -> integral rows r0-2-h0 .. r0+kDogRows+h0
+  const int ro0 = r0 - 2 - h0, co0 = c0 - 2 - h0, nr0 = kDogRows + 3 + 2 * h0, nc0 = 64 + 3 + 2 * h0;
+  for (int i = tid; i < nr0 * nc0; i += 256) {
+    const int lr = i / nc0, lc = i - lr * nc0;
+    const int r = min(max(ro0 + lr, 0), R - 1), c = min(max(co0 + lc, 0), C - 1);  // (clamped positions are never used)
+    t0[lr * kDogPitch + lc] = II0[(size_t)r * ld + c];
+  }
+  // scale 1: averages at the tile's own pixels -> integral rows r0-1-h1 .. r0+kDogRows-1+h1
+  const int ro1 = r0 - 1 - h1, co1 = c0 - 1 - h1, nr1 = kDogRows + 1 + 2 * h1, nc1 = 64 + 1 + 2 * h1;
+  for (int i = tid; i < nr1 * nc1; i += 256) {
+    const int lr = i / nc1, lc = i - lr * nc1;
+    const int r = min(max(ro1 + lr, 0), R - 1), c = min(max(co1 + lc, 0), C - 1);
+    t1[lr * kDogPitch + lc] = II1[(size_t)r * ld + c];
   }
   __syncthreads();
-  const int r = r0 + threadIdx.y, c = c0 + threadIdx.x;
-  if (r >= R || c >= C) return;
-  if (c == 0) rowcount[r] = 0;  // reset for the candidate kernel of this frame
-  const float v0 = s0[threadIdx.y + 1][threadIdx.x + 1];
-  const float v1 = box_avg(II1, r, c, d1, R, C, ld);
-  const size_t i = (size_t)r * C + c;
-  dog[i] = v1 - v0;
-  float m = 0.0f;
-  if (r >= 1 && r < R - 1 && c >= 1 && c < C - 1) {
-    const float dx = s0[threadIdx.y + 1][threadIdx.x + 2] - s0[threadIdx.y + 1][threadIdx.x];
-    const float dy = s0[threadIdx.y + 2][threadIdx.x + 1] - s0[threadIdx.y][threadIdx.x + 1];
-    m = dx * dx + dy * dy;
+  // (pointer arithmetic only: box_avg indexes [r * pitch + c] with image coordinates)
+  const float* v0 = t0 - ((ptrdiff_t)ro0 * kDogPitch + co0);
+  const float* v1 = t1 - ((ptrdiff_t)ro1 * kDogPitch + co1);
+  for (int i = tid; i < (kDogRows + 2) * 66; i += 256) {
+    const int lr = i / 66, lc = i - lr * 66;
+    const int r = r0 + lr - 1, c = c0 + lc - 1;
+    s0[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? box_avg(v0, r, c, d0, R, C, kDogPitch) : 0.0f;
   }
-  mag[i] = m;
-  if (scale0) scale0[i] = v0;
-  if (scale1) scale1[i] = v1;
+  __syncthreads();
+  const int c = c0 + threadIdx.x;
+  if (c >= C) return;
+#pragma unroll
+  for (int k = 0; k < kDogRows / 4; ++k) {
+    const int lr = threadIdx.y + 4 * k, r = r0 + lr;
+    if (r >= R) break;
+    if (c == 0) rowcount[r] = 0;  // reset for the candidate kernel of this frame
+    const float a0 = s0[lr + 1][threadIdx.x + 1];
+    const float a1 = box_avg(v1, r, c, d1, R, C, kDogPitch);
+    const size_t i = (size_t)r * C + c;
+    dog[i] = a1 - a0;
+    float m = 0.0f;
+    if (r >= 1 && r < R - 1 && c >= 1 && c < C - 1) {
+      const float dx = s0[lr + 1][threadIdx.x + 2] - s0[lr + 1][threadIdx.x];
+      const float dy = s0[lr + 2][threadIdx.x + 1] - s0[lr][threadIdx.x + 1];
+      m = dx * dx + dy * dy;
+    }
+    mag[i] = m;
+    if (scale0) scale0[i] = a0;
+    if (scale1) scale1[i] = a1;
+  }
 }
 
+template <int TR>
 __global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, const float* __restrict__ II1, int d0, int d1,
                                                  float* __restrict__ dog, float* __restrict__ mag, float* __restrict__ scale0,
                                                  float* __restrict__ scale1, int R, int C, int* __restrict__ rowcount) {
-  dog_mag_body(II0, II1, d0, d1, dog, mag, scale0, scale1, R, C, rowcount);
+  dog_mag_body<TR>(II0, II1, d0, d1, dog, mag, scale0, scale1, R, C, rowcount);
 }
 __global__ __launch_bounds__(256) void k_dog_mag_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int lane0, int d0, int d1, int R, int C) {
   const LaneStatic& L = ls[lane0 + blockIdx.z];
   const int b = dyn.v[lane0 + blockIdx.z].parity;
-  dog_mag_body(L.sa[0], L.sa[1], d0, d1, L.dog2[b], L.mag2[b], nullptr, nullptr, R, C, L.rowcount2[b]);
+  dog_mag_body<16>(L.sa[0], L.sa[1], d0, d1, L.dog2[b], L.mag2[b], nullptr, nullptr, R, C, L.rowcount2[b]);
 }
 
 // Threshold servo of EdgeDetector::detect (edge_detector.cpp:33-36), evaluated identically by every thread.
@@ -563,75 +602,89 @@ __device__ __forceinline__ float servo_threshold(const KParams& p, const DetStat
 }
 
 // ---- candidate test + plane fit (edge_detector.cpp:73-107) ---------------------------------------------
-// Tile = 4 rows x 64 columns; each wavefront is one 64-pixel row segment, so a __ballot is exactly the
-// raster-ordered candidate set of that segment.
+// Tile = kFlagRows rows x 64 columns per workgroup of four waves; a wavefront works on one 64-pixel row segment at a time
+// (rows wave, wave + 4, ...), so a __ballot is exactly the raster-ordered candidate set of that segment. The DoG tile with
+// its two-pixel ring is staged once: (kFlagRows + 4) x 68 values for kFlagRows x 64 pixels (1.33 x; the 4-row tile of the
+// first rounds staged 2.1 x and had a quarter of the loads in flight per thread).
+template <int kFlagRows>
 __device__ __forceinline__ void keyline_flag_body(const float* __restrict__ dog, const float* __restrict__ mag,
                                                       KParams p, const DetState* __restrict__ det_in,
                                                       float4* __restrict__ stash, unsigned long long* __restrict__ bits,
                                                       int* __restrict__ rowcount) {
-  __shared__ float sd[8][68];
+  __shared__ float sd[kFlagRows + 4][68];
   const int R = p.rows, C = p.cols;
-  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 4;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * kFlagRows;
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  for (int i = tid; i < 8 * 68; i += 256) {
+  for (int i = tid; i < (kFlagRows + 4) * 68; i += 256) {
     const int lr = i / 68, lc = i - lr * 68;
     const int r = r0 + lr - 2, c = c0 + lc - 2;
     sd[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? dog[(size_t)r * C + c] : 0.0f;
+  }
+  const int c = c0 + threadIdx.x;
+  float mgv[kFlagRows / 4];  // the gradient magnitudes of this thread's pixels: in flight while the tile lands
+#pragma unroll
+  for (int k = 0; k < kFlagRows / 4; ++k) {
+    const int r = r0 + threadIdx.y + 4 * k;
+    mgv[k] = (r >= 2 && r < R - 2 && c >= 2 && c < C - 2) ? mag[(size_t)r * C + c] : 0.0f;
   }
   __syncthreads();
   const float thr = servo_threshold(p, *det_in);
   const float pn_threshold = float((2.0 * 2 + 1.0) * (2.0 * 2 + 1.0)) * p.pos_neg_threshold;
   const float gradient_threshold_squared = (thr * kMaxImageValue * p.dog_threshold) * (thr * kMaxImageValue * p.dog_threshold);
   const float mag_threshold = (thr * kMaxImageValue) * (thr * kMaxImageValue);
-
-  const int r = r0 + threadIdx.y, c = c0 + threadIdx.x;
-  bool cand = false;
-  float4 fit = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (r >= 2 && r < R - 2 && c >= 2 && c < C - 2) {
-    const float mg = mag[(size_t)r * C + c];
-    if (!(mg < mag_threshold)) {
-      int pn = 0;
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 25; ++k) {
-        const float y = sd[threadIdx.y + k / 5][threadIdx.x + k % 5];
-        pn = (y > 0.0f) ? pn + 1 : pn - 1;
-        t0 += c_pinv[k] * y;
-        t1 += c_pinv[25 + k] * y;
-        t2 += c_pinv[50 + k] * y;
-      }
-      if (!(fabsf((float)pn) > pn_threshold)) {
-        const float g2 = t0 * t0 + t1 * t1;
-        const float tmp = t2 / g2;
-        const float xs = -t0 * tmp;
-        const float ys = -t1 * tmp;
-        if (!(fabsf(xs) > 0.5f || fabsf(ys) > 0.5f)) {
-          if (!(g2 < gradient_threshold_squared)) {
-            cand = true;
-            fit = make_float4(t0, t1, xs, ys);
+  for (int k = 0; k < kFlagRows / 4; ++k) {
+    const int lr = threadIdx.y + 4 * k, r = r0 + lr;
+    if (r >= R) break;  // (whole wave)
+    bool cand = false;
+    float4 fit = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= 2 && r < R - 2 && c >= 2 && c < C - 2) {
+      const float mg = mgv[k];
+      if (!(mg < mag_threshold)) {
+        int pn = 0;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 25; ++q) {
+          const float y = sd[lr + q / 5][threadIdx.x + q % 5];
+          pn = (y > 0.0f) ? pn + 1 : pn - 1;
+          t0 += c_pinv[q] * y;
+          t1 += c_pinv[25 + q] * y;
+          t2 += c_pinv[50 + q] * y;
+        }
+        if (!(fabsf((float)pn) > pn_threshold)) {
+          const float g2 = t0 * t0 + t1 * t1;
+          const float tmp = t2 / g2;
+          const float xs = -t0 * tmp;
+          const float ys = -t1 * tmp;
+          if (!(fabsf(xs) > 0.5f || fabsf(ys) > 0.5f)) {
+            if (!(g2 < gradient_threshold_squared)) {
+              cand = true;
+              fit = make_float4(t0, t1, xs, ys);
+            }
           }
         }
       }
     }
-  }
-  const unsigned long long b = __ballot(cand);
-  if (r < R && c < C && cand) stash[(size_t)r * C + c] = fit;
-  if (threadIdx.x == 0 && r < R) {
-    bits[(size_t)r * p.nseg + blockIdx.x] = b;
-    const int n = __popcll(b);
-    if (n) atomicAdd(&rowcount[r], n);
+    const unsigned long long b = __ballot(cand);
+    if (c < C && cand) stash[(size_t)r * C + c] = fit;
+    if (threadIdx.x == 0) {
+      bits[(size_t)r * p.nseg + blockIdx.x] = b;
+      const int n = __popcll(b);
+      if (n) atomicAdd(&rowcount[r], n);
+    }
   }
 }
 
+template <int TR>
 __global__ __launch_bounds__(256) void k_keyline_flag(const float* __restrict__ dog, const float* __restrict__ mag, KParams p,
                                                       const DetState* __restrict__ det_in, float4* __restrict__ stash,
                                                       unsigned long long* __restrict__ bits, int* __restrict__ rowcount) {
-  keyline_flag_body(dog, mag, p, det_in, stash, bits, rowcount);
+  keyline_flag_body<TR>(dog, mag, p, det_in, stash, bits, rowcount);
 }
 __global__ __launch_bounds__(256) void k_keyline_flag_b(KParams p, const LaneStatic* __restrict__ ls, LaneDynB dyn) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
-  keyline_flag_body(L.dog2[d.parity], L.mag2[d.parity], p, L.det + d.det_in, L.stash, L.bits, L.rowcount2[d.parity]);
+  keyline_flag_body<16>(L.dog2[d.parity], L.mag2[d.parity], p, L.det + d.det_in, L.stash, L.bits, L.rowcount2[d.parity]);
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -654,26 +707,52 @@ __device__ __forceinline__ float auto_threshold_from(const MapState& st, float p
 // rank = (#candidates in earlier rows) + (#candidates in earlier segments of this row) + (#lower lanes):
 // the raster rank of the reference's sequential loop, with truncation at keylines_max. Also rewrites the
 // whole dense mask and clears this map's distance-field cells.
+// kEmitRows rows x 64 columns per workgroup: the tile's row bases are formed once, by the whole workgroup
+template <int kEmitRows>
 __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const float4* __restrict__ stash,
                                                       const unsigned long long* __restrict__ bits,
                                                       const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
                                                       DetState* __restrict__ det_out, const MapState* prev_st,
                                                       int clear_df, int ntiles) {
   const int R = p.rows, C = p.cols;
-  const int r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.x * 64 + threadIdx.x;
-  const int lane = threadIdx.x;
-  if (r >= R) return;  // whole wave
-  int part = 0;
-  for (int i = lane; i < r; i += 64) part += rowcount[i];
-  if (lane < (int)blockIdx.x) part += __popcll(bits[(size_t)r * p.nseg + lane]);
-  const int offset = wave_sum(part);
-  // raster rank of the row's first keyline (segment 0: offset holds the earlier rows only), clamped like the ranks below
-  if (blockIdx.x == 0 && lane == 0) m.row_start[r] = min(offset, p.kmax);
+  const int r0 = blockIdx.y * kEmitRows;
+  const int lane = threadIdx.x, wid = threadIdx.y, tid = wid * 64 + lane;
+  __shared__ int s_rc[kEmitRows];    // candidates per row of the tile
+  __shared__ int s_seg[kEmitRows];   // ... of each row in the segments left of this one
+  __shared__ int s_base[kEmitRows];  // raster rank of the row's first candidate in THIS segment
+  __shared__ int s_p0;               // candidates in the rows above the tile
+  // rows above the tile: wave 0; the tile's own rows and the segments to the left: sixteen lanes per row
+  if (wid == 0) {
+    int part = 0;
+    for (int i = lane; i < r0; i += 64) part += rowcount[i];
+    const int tot = wave_sum(part);
+    if (lane == 0) s_p0 = tot;
+  }
+  {
+    const int lr = tid >> 4, sg = tid & 15, r = r0 + lr;
+    int acc = 0;
+    if (lr < kEmitRows && r < R)
+      for (int q = sg; q < (int)blockIdx.x; q += 16) acc += __popcll(bits[(size_t)r * p.nseg + q]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);  // (the sixteen lanes of a row are neighbours in one wave)
+    if (sg == 0 && lr < kEmitRows) {
+      s_seg[lr] = acc;
+      s_rc[lr] = (r < R) ? rowcount[r] : 0;
+    }
+  }
   {  // the distance-field tile counters of this map start at zero (k_join_edges bins into them)
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x, t = wg * 256 + threadIdx.y * 64 + threadIdx.x;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x, t = wg * 256 + tid;
     if (t < ntiles) m.tile_cnt[t] = 0;
   }
-  if (r == 0 && blockIdx.x == 0) {  // one wave publishes the frame's scalars
+  __syncthreads();
+  if (tid < kEmitRows) {
+    int base = s_p0;
+    for (int j = 0; j < tid; ++j) base += s_rc[j];
+    s_base[tid] = base + s_seg[tid];
+    // raster rank of the row's first keyline (segment 0: the rows above only), clamped like the ranks below
+    if (blockIdx.x == 0 && r0 + tid < R) m.row_start[r0 + tid] = min(base, p.kmax);
+  }
+  if (blockIdx.y == 0 && blockIdx.x == 0 && wid == 0) {  // one wave publishes the frame's scalars
     int tp = 0;
     for (int i = lane; i < R; i += 64) tp += rowcount[i];
     const int total = wave_sum(tp);
@@ -695,44 +774,52 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
       det_out->auto_threshold = prev_auto;
     }
   }
+  __syncthreads();
+  const int c = blockIdx.x * 64 + lane;
   if (c >= C) return;
-  const unsigned long long b = bits[(size_t)r * p.nseg + blockIdx.x];
-  const bool cand = (b >> lane) & 1ull;
-  const int rank = offset + __popcll(b & ((1ull << lane) - 1ull));
-  const size_t pix = (size_t)r * C + c;
-  int mk = -1;
-  if (cand && rank < p.kmax) {
-    mk = rank;
-    const float4 fit = stash[pix];
-    const float px = float(c) + fit.z, py = float(r) + fit.w;
-    m.pos[rank] = make_float2(px, py);
-    const float2 pi = make_float2(px - p.cx, py - p.cy);
-    m.pos_img[rank] = pi;
-    m.mpos_img[rank] = pi;
-    m.grad[rank] = make_float2(fit.x, fit.y);
-    m.mgrad[rank] = make_float2(0.f, 0.f);
-    m.gnorm[rank] = sqrtf(fit.x * fit.x + fit.y * fit.y);
-    m.mgnorm[rank] = 0.f;
-    m.rs[rank] = make_float2(1.0f, 20.0f);
-    m.id_prev[rank] = -1;
-    m.id_next[rank] = -1;
-    m.match_id[rank] = -1;
-    m.match_fwd[rank] = -1;
-    m.match_kf[rank] = -1;
-    m.matches[rank] = 0u;
-    m.fwd_key[rank] = 0ull;
-    m.residual[rank] = 0.f;
+#pragma unroll
+  for (int k = 0; k < kEmitRows / 4; ++k) {
+    const int lr = wid + 4 * k, r = r0 + lr;
+    if (r >= R) break;  // (whole wave)
+    const unsigned long long b = bits[(size_t)r * p.nseg + blockIdx.x];
+    const bool cand = (b >> lane) & 1ull;
+    const int rank = s_base[lr] + __popcll(b & ((1ull << lane) - 1ull));
+    const size_t pix = (size_t)r * C + c;
+    int mk = -1;
+    if (cand && rank < p.kmax) {
+      mk = rank;
+      const float4 fit = stash[pix];
+      const float px = float(c) + fit.z, py = float(r) + fit.w;
+      m.pos[rank] = make_float2(px, py);
+      const float2 pi = make_float2(px - p.cx, py - p.cy);
+      m.pos_img[rank] = pi;
+      m.mpos_img[rank] = pi;
+      m.grad[rank] = make_float2(fit.x, fit.y);
+      m.mgrad[rank] = make_float2(0.f, 0.f);
+      m.gnorm[rank] = sqrtf(fit.x * fit.x + fit.y * fit.y);
+      m.mgnorm[rank] = 0.f;
+      m.rs[rank] = make_float2(1.0f, 20.0f);
+      m.id_prev[rank] = -1;
+      m.id_next[rank] = -1;
+      m.match_id[rank] = -1;
+      m.match_fwd[rank] = -1;
+      m.match_kf[rank] = -1;
+      m.matches[rank] = 0u;
+      m.fwd_key[rank] = 0ull;
+      m.residual[rank] = 0.f;
+    }
+    m.mask[pix] = mk;
+    if (clear_df) m.df[pix] = kDfEmpty;  // only the scatter build needs a cleared field, the tiled build writes every cell
   }
-  m.mask[pix] = mk;
-  if (clear_df) m.df[pix] = kDfEmpty;  // only the scatter build needs a cleared field, the tiled build writes every cell
 }
 
 // ---- joinEdges (edge_detector.cpp:125-165) + min/max of gradient_norm for tuneThreshold (:168-174) -----
+template <int TR>
 __global__ __launch_bounds__(256) void k_keyline_emit(KParams p, MapDev m, const float4* __restrict__ stash,
                                                       const unsigned long long* __restrict__ bits, const int* __restrict__ rowcount,
                                                       const DetState* __restrict__ det_in, DetState* __restrict__ det_out,
                                                       const MapState* prev_st, int clear_df, int ntiles) {
-  keyline_emit_body(p, m, stash, bits, rowcount, det_in, det_out, prev_st, clear_df, ntiles);
+  keyline_emit_body<TR>(p, m, stash, bits, rowcount, det_in, det_out, prev_st, clear_df, ntiles);
 }
 __global__ __launch_bounds__(256) void k_keyline_emit_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
                                                         LaneDynB dyn, int clear_df, int ntiles) {
@@ -740,7 +827,7 @@ __global__ __launch_bounds__(256) void k_keyline_emit_b(KParams p, const LaneSta
   const LaneDyn d = dyn.v[blockIdx.z];
   const MapDev m = lane_map(maptab, blockIdx.z, d.nm, d.nm_swap);
   const MapState* prev = d.prev >= 0 ? maptab[blockIdx.z * kLaneMaps + d.prev].st : nullptr;
-  keyline_emit_body(p, m, L.stash, L.bits, L.rowcount2[d.parity], L.det + d.det_in, L.det + d.det_out, prev, clear_df, ntiles);
+  keyline_emit_body<16>(p, m, L.stash, L.bits, L.rowcount2[d.parity], L.det + d.det_in, L.det + d.det_out, prev, clear_df, ntiles);
 }
 
 // r-range of a keyline's probe segment (cells round(pos + u r), r in [-half, half)) that can fall into the pixel box
@@ -1190,6 +1277,11 @@ __global__ __launch_bounds__(256) void k_render_keylines(KParams p, MapDev m, ui
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------
+// Rows per 64-column tile of k_dog_mag / k_keyline_flag / k_keyline_emit. Batches: 16 (fewest staged values and prefix sums per
+// pixel: the 8-lane step went from 232 to 202 us with these three kernels re-tiled). A single stream: 8 - its 600 workgroups
+// per kernel finish sooner on an otherwise idle chip than 300 of 16 rows (rocprofv3, 640x480: k_dog_mag 8.1 / 11.3 us,
+// k_keyline_flag 7.7 / 10.7, k_keyline_emit 7.5 / 9.0 for 8 / 16 rows).
+constexpr int kTileRowsSingle = 8;
 static int lds_pitch(int cols) {
   int pad = 4;
   if (((cols + pad) / 4) % 2 == 0) pad = 8;
@@ -1283,9 +1375,9 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
   }
   if (part & 2) {
     RH_COLSCAN(false, sb.a[0], sb.a[1]);
-    const dim3 gt(div_up(C, 64), div_up(R, 4));
-    RH_LAUNCH(k_dog_mag, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2],
-                       widths[1][2], sb.dog, sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
+    const dim3 gt(div_up(C, 64), div_up(R, kTileRowsSingle));
+    RH_LAUNCH(k_dog_mag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2], widths[1][2], sb.dog,
+              sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
   }
 #undef RH_COLSCAN
 }
@@ -1324,15 +1416,14 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
   RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 2, R, C, widths[0][1], widths[1][1], ldw);
   RH_COLSCAN_B(2);
 #undef RH_COLSCAN_B
-  RH_LAUNCH(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 4), z), dim3(64, 4), 0, s, ls, dyn, lane0, widths[0][2], widths[1][2], R, C);
+  RH_LAUNCH(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 16), z), dim3(64, 4), 0, s, ls, dyn, lane0, widths[0][2], widths[1][2], R, C);
 }
 
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn) {
   const unsigned z = (unsigned)lanes;
-  const dim3 gt(div_up(p.cols, 64), div_up(p.rows, 4), z);
   const DfGrid dg = df_grid(p.rows, p.cols);
-  RH_LAUNCH(k_keyline_flag_b, gt, dim3(64, 4), 0, s, p, ls, dyn);
-  RH_LAUNCH(k_keyline_emit_b, gt, dim3(64, 4), 0, s, p, ls, maptab, dyn, 0, dg.ntx * dg.nty);
+  RH_LAUNCH(k_keyline_flag_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, dyn);
+  RH_LAUNCH(k_keyline_emit_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, maptab, dyn, 0, dg.ntx * dg.nty);
   RH_LAUNCH(k_join_edges_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, maptab, dyn, dg.T, dg.ntx,
             dg.nty);
 }
@@ -1362,12 +1453,12 @@ void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneSta
 
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
                      const DetState* det_in, DetState* det_out, const MapState* prev_st) {
-  const dim3 gt(div_up(p.cols, 64), div_up(p.rows, 4));
   const DfGrid dg = df_grid(p.rows, p.cols);
-  RH_LAUNCH(k_keyline_flag, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in,
-                     db.stash, db.bits, db.rowcount);
-  RH_LAUNCH(k_keyline_emit, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash,
-                     (const unsigned long long*)db.bits, (const int*)db.rowcount, det_in, det_out, prev_st, 0, dg.ntx * dg.nty);
+  const dim3 gt(div_up(p.cols, 64), div_up(p.rows, kTileRowsSingle));
+  RH_LAUNCH(k_keyline_flag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in, db.stash, db.bits,
+            db.rowcount);
+  RH_LAUNCH(k_keyline_emit<kTileRowsSingle>, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash, (const unsigned long long*)db.bits,
+            (const int*)db.rowcount, det_in, det_out, prev_st, 0, dg.ntx * dg.nty);
   RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, m, dg.T, dg.ntx, dg.nty);
 }
 
