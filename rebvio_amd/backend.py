@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "librebvio_hip.so")
+# REBVIO_HIP_LIB: another build of the same library (A/B measurements of compile-time variants); default = the in-tree build
+LIB_PATH = os.environ.get("REBVIO_HIP_LIB") or os.path.join(_HERE, "_build", "librebvio_hip.so")
 
 KEYLINE_DTYPE = np.dtype([
     ("pos", "<f4", (2,)), ("pos_img", "<f4", (2,)), ("match_pos_img", "<f4", (2,)), ("gradient", "<f4", (2,)),

@@ -885,6 +885,33 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
 // A poll that lasts longer than kXchSpinLimit iterations (~0.2 s) raises *err and goes on: the grid always drains.
 constexpr unsigned kXchSpinLimit = 1u << 18;
 
+// The hand-off of the forwardMatch side effects (fwd_key atomics) to the other workgroups of the launch:
+//   producer: every wave that issued them runs vm_drain() - a workgroup-scope release fence (compiler ordering: nothing it
+//             issued before may sink below; on gfx942 / gfx950 outside tgsplit mode it emits no cache operation) followed by
+//             "s_waitcnt vmcnt(0)": the atomics are performed at the device's coherence point (agent scope) and ACKNOWLEDGED
+//             before the workgroup barrier behind which the record words that announce them go out (xch_publish);
+//   consumer: polls the words (xch_wait), then xch_acquire() - a workgroup-scope acquire fence (compiler ordering: nothing
+//             behind it may be hoisted above the polls) - then reads the keys with agent-scope ATOMIC loads, which are served
+//             by the same coherence point and are issued in program order behind the poll that saw the tag.
+// Everything that crosses workgroups inside these kernels is an agent-scope atomic word; no plain store is ever read by
+// another workgroup of the same launch (match_fwd etc. are consumed by later kernels). What is deliberately NOT used is an
+// agent-scope fence: the release form writes the XCD's L2 back (15 us per pair), the acquire form
+// (buffer_inv sc1) invalidates the XCD's non-coherently cached L2 lines for every kernel running beside this one - measured
+// -4 % frames/s on one stream and -5 % with 8 lanes (13.04 k -> 12.5 k, 39.1 k -> 37.2 k, same box, alternating runs), against
+// no measurable cost for the workgroup-scope pair. The s_waitcnt immediate is the gfx9 encoding, where vmcnt counts loads,
+// stores AND atomics of the wave; targets with a separate store counter (gfx10+) need another one, hence the guard.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "track.hip: vm_drain() encodes s_waitcnt for gfx942 / gfx950 only"
+#endif
+__device__ __forceinline__ void vm_drain() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
+}
+__device__ __forceinline__ void fwd_key_max(unsigned long long* w, unsigned long long key) {
+  (void)__hip_atomic_fetch_max(w, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xch_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
 __device__ __forceinline__ void xch_publish(unsigned long long* w, unsigned tag, float v) {
   __hip_atomic_store(w, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
@@ -1137,14 +1164,14 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
       if (last) {
         if (e.matched) {
           const unsigned long long key = ((unsigned long long)order_key(in.rs.x) << 32) | (unsigned)idx;
-          atomicMax(&nm.fwd_key[e.mfwd], key);
+          fwd_key_max(&nm.fwd_key[e.mfwd], key);
         }
         om.match_fwd[idx] = e.mfwd;
       }
     }
     // last evaluation: this wave's forwardMatch atomics are acknowledged before the workgroup publishes its records (see
     // k_lm_chain_spec; a release fence on the publishing threads would order only their own operations)
-    if (last) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (last) vm_drain();
     RH_STAMP(1 + call * 6 + 3);
     // carry-forward of the last written fi in index order (see k_try_vel)
     const unsigned long long mm = __ballot(e.matched);
@@ -1232,6 +1259,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   float row[6] = {0, 0, 0, 0, 0, 0};
   float Y = 0.f;
   int cnt = 0;
+  xch_acquire();  // behind the polls of the last evaluation's records: the forwardMatch keys of every workgroup (vm_drain)
   if (idx < n_new) {
     xk.key = __hip_atomic_load(&nm.fwd_key[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     xrv_eval(p, om, nm, idx, 1, xk, vx, vy, vz, row, &Y, &cnt);
@@ -1379,12 +1407,12 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       if (last) {
         if (e.matched) {
           const unsigned long long key = ((unsigned long long)order_key(in.rs.x) << 32) | (unsigned)idx;
-          atomicMax(&nm.fwd_key[e.mfwd], key);
+          fwd_key_max(&nm.fwd_key[e.mfwd], key);
         }
         om.match_fwd[idx] = e.mfwd;
       }
     }
-    if (last) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the keys are out before the records (see the speculative phase)
+    if (last) vm_drain();  // the keys are out before the records (see the speculative phase)
     const unsigned long long mm = __ballot(e.matched);
     const unsigned long long below = mm & ((1ull << lane) - 1ull);
     const int src = below ? (63 - __clzll((long long)below)) : 0;
@@ -1594,7 +1622,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         if (2 + k == calls - 1 && idx < n) {  // the side effects of the last evaluation (forwardMatch, edge_map.cpp:78-96)
           if (mt[k].matched) {
             const unsigned long long key = ((unsigned long long)order_key(in.rs.x) << 32) | (unsigned)idx;
-            atomicMax(&nm.fwd_key[mt[k].mfwd], key);
+            fwd_key_max(&nm.fwd_key[mt[k].mfwd], key);
           }
           om.match_fwd[idx] = mt[k].mfwd;
         }
@@ -1603,7 +1631,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     // Every wave's forwardMatch atomics (performed at the memory side, device scope) are ACKNOWLEDGED before the workgroup goes
     // on to publish its records: vmcnt(0) here, on the waves that issued them. (A system-scope release fence on the
     // publishing threads, as before, orders only THEIR OWN operations and writes the XCD's whole L2 back for it.)
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    vm_drain();
     RH_STAMP(7);
     __syncthreads();
     // thread kChainThreads - 1 - k: hand-off behind evaluation 2 + k (carry-in of evaluation 3 + k), as in do_eval
@@ -1803,6 +1831,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   float row[6] = {0, 0, 0, 0, 0, 0};
   float Y = 0.f;
   int cnt = 0;
+  xch_acquire();  // behind the polls of the last evaluation's records: the forwardMatch keys of every workgroup (vm_drain)
   if (idx < n_new) {
     xk.key = __hip_atomic_load(&nm.fwd_key[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     xrv_eval(p, om, nm, idx, 1, xk, vx, vy, vz, row, &Y, &cnt);
