@@ -283,9 +283,10 @@ int rebvio_hip_flush(rebvio_hip_ctx* ctx);
  * of an MI355X busy - its kernels are short latency chains - so a batched step costs about what a single stream's step costs
  * and the frame rate scales with the lane count until the chip fills. Every lane is a full context (own maps, servo, gyro-bias
  * state) sharing the batch's three streams; its records are bit-identical to those of a stand-alone context fed the same
- * frames. lanes in 1..16, any keylines_max a context accepts; rebvio_hip_batch_create checks that the device can hold every
- * lane's persistent tracking workgroups at once and refuses (-3, with the bound in the message) otherwise: 8 lanes at 16k
- * keylines on an MI355X. A lens model (rebvio_hip_set_undistort on every lane's context, or on none) puts the batched front end
+ * frames. lanes in 1..16, any keylines_max a context accepts. The persistent tracking kernel's workgroups exchange records
+ * within a lane and must be resident together for that: the driver launches it for as many lanes at a time as the device holds
+ * (8 lanes of 16k keylines on an MI355X; 16 lanes take two such launches per step), and rebvio_hip_batch_create refuses (-3)
+ * a keylines_max whose single lane does not fit. A lens model (rebvio_hip_set_undistort on every lane's context, or on none) puts the batched front end
  * (x3 + undistort, rebvio.cpp:43-47) ahead of the scans, each lane through its own model.
  * push: frames_dev[l] = this step's u8 frame of lane l in device memory (all lanes share ts_us); out[l] / keylines[l] receive
  * lane l's oldest COMPLETE pair not handed out yet, like rebvio_hip_push_frame_u8_device (status -1 while there is none);

@@ -199,9 +199,9 @@ struct rebvio_hip_ctx {
   float* sa2[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [frame parity][filter]: sb.a per parity ([0] aliases sb.a)
   // scale-space outputs (DoG, squared gradient, per-row counts) are double buffered: the scans of frame f+1 (s_det)
   // overlap the keyline extraction of frame f (s_key)
-  float* dog2[2]{};
-  float* mag2[2]{};
-  int* rowcount2[2]{};
+  float* dog2[kDetPar]{};  // (the single-stream driver alternates between [0] and [1], a batch uses all: common.hpp kDetPar)
+  float* mag2[kDetPar]{};
+  int* rowcount2[kDetPar]{};
   hipEvent_t ev_scan[2]{}, ev_flag[2]{};
   bool ev_flag_used[2] = {false, false};
   uint64_t launch_index = 0;
@@ -222,7 +222,7 @@ struct rebvio_hip_ctx {
   std::atomic<int> pin_staged[kPin]{};  // 1: the slot holds a frame whose host-to-device copy the detect worker has not queued yet
   uint64_t pin_next = 0;
   int2* undist_map = nullptr;      // fixed-point source coordinates (null: no lens distortion, front end = x3 only)
-  float* undist_img[2]{};          // undistorted fp32 frame, double-buffered like dog2 / mag2
+  float* undist_img[kDetPar]{};    // undistorted fp32 frame, buffered like dog2 / mag2
   rebvio_hip_keyline* aos_dev = nullptr;
   int* scratch_i = nullptr;  // 2 * rows*cols ints (df decode)
   float* diag0 = nullptr;
@@ -949,10 +949,10 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->db.bits, (size_t)p->rows * K.nseg * sizeof(unsigned long long)));
   HIPCHK(hipMalloc(&c->db.rowcount, (size_t)p->rows * sizeof(int)));
   HIPCHK(hipMemset(c->db.rowcount, 0, (size_t)p->rows * sizeof(int)));
+  c->dog2[0] = c->sb.dog;
+  c->mag2[0] = c->sb.mag;
+  c->rowcount2[0] = c->db.rowcount;
   for (int i = 0; i < 2; ++i) {
-    c->dog2[i] = i ? nullptr : c->sb.dog;
-    c->mag2[i] = i ? nullptr : c->sb.mag;
-    c->rowcount2[i] = i ? nullptr : c->db.rowcount;
     HIPCHK(hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_flag[i], hipEventDisableTiming));
   }
@@ -960,10 +960,12 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     c->sa2[0][f] = c->sb.a[f];
     HIPCHK(hipMalloc(&c->sa2[1][f], Pp * sizeof(float)));
   }
-  HIPCHK(hipMalloc(&c->dog2[1], Pn * sizeof(float)));
-  HIPCHK(hipMalloc(&c->mag2[1], Pn * sizeof(float)));
-  HIPCHK(hipMalloc(&c->rowcount2[1], (size_t)p->rows * sizeof(int)));
-  HIPCHK(hipMemset(c->rowcount2[1], 0, (size_t)p->rows * sizeof(int)));
+  for (int i = 1; i < kDetPar; ++i) {
+    HIPCHK(hipMalloc(&c->dog2[i], Pn * sizeof(float)));
+    HIPCHK(hipMalloc(&c->mag2[i], Pn * sizeof(float)));
+    HIPCHK(hipMalloc(&c->rowcount2[i], (size_t)p->rows * sizeof(int)));
+    HIPCHK(hipMemset(c->rowcount2[i], 0, (size_t)p->rows * sizeof(int)));
+  }
   HIPCHK(hipMalloc(&c->det, (kDetRing + 1) * sizeof(DetState)));
   DetState d0[kDetRing + 1];
   for (int i = 0; i < kDetRing + 1; ++i) {
@@ -1105,9 +1107,11 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
     if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
     if (c->ev_flag[i]) (void)hipEventDestroy(c->ev_flag[i]);
   }
-  if (c->dog2[1]) (void)hipFree(c->dog2[1]);
-  if (c->mag2[1]) (void)hipFree(c->mag2[1]);
-  if (c->rowcount2[1]) (void)hipFree(c->rowcount2[1]);
+  for (int i = 1; i < kDetPar; ++i) {
+    if (c->dog2[i]) (void)hipFree(c->dog2[i]);
+    if (c->mag2[i]) (void)hipFree(c->mag2[i]);
+    if (c->rowcount2[i]) (void)hipFree(c->rowcount2[i]);
+  }
   for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
     if (c->slot[i]) (void)hipHostFree(c->slot[i]);
     if (c->rec[i]) (void)hipHostFree(c->rec[i]);
@@ -1116,7 +1120,7 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->gstate) (void)hipFree(c->gstate);
   if (c->h_gstate) (void)hipHostFree(c->h_gstate);
   if (c->undist_map) (void)hipFree(c->undist_map);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kDetPar; ++i)
     if (c->undist_img[i]) (void)hipFree(c->undist_img[i]);
   if (c->lm_xch) (void)hipFree(c->lm_xch);
   for (int i = 0; i < rebvio_hip_ctx::kPin; ++i) {
@@ -1190,7 +1194,7 @@ int rebvio_hip_set_undistort(rebvio_hip_ctx* c, const float K4[4], const float D
   std::vector<int> map(2 * Pn);
   hm::undistort_fixed_map(c->P.rows, c->P.cols, K4[0], K4[1], K4[2], K4[3], D5[0], D5[1], D5[2], D5[3], D5[4], map.data());
   if (!c->undist_map) HIPCHK(hipMalloc(&c->undist_map, Pn * sizeof(int2)));
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kDetPar; ++i)
     if (!c->undist_img[i]) HIPCHK(hipMalloc(&c->undist_img[i], Pn * sizeof(float)));
   HIPCHK(hipMemcpy(c->undist_map, map.data(), Pn * sizeof(int2), hipMemcpyHostToDevice));
   return 0;
@@ -1849,12 +1853,12 @@ int rebvio_hip_track_pair_finish(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_h
 
 namespace {
 // ---- streaming driver -------------------------------------------------------------------------------------------------
-// Per pair, on the track stream, four launches and one event, nothing else:
-//   [rotate]  persistent minimizeVel / forwardMatch / extRotVel   (LM state, map state records -> pinned slot; sums -> device)
-//   directedMatch head, with the pair's GLUE evaluated on the device in its prologue (glue.hpp: 6x6 solve, gyroBiasCorrection,
-//             SO3, Cholesky; inputs from the LM kernel's records, filter state in device memory, results for the host in a
-//             pinned record) -> directedMatch tail -> regularize / depth EKF / next pair's first rotation
-//   event
+// Per pair, on the track stream, four launches and nothing else (one event per GROUP of pairs, see stream_enqueue_group):
+//   persistent minimizeVel / forwardMatch / extRotVel, with the pair's GLUE at its tail: every workgroup publishes its
+//             extRotVel sums as tagged words, workgroup 0 collects them and evaluates glue.hpp (6x6 solve, gyroBiasCorrection,
+//             SO3, Cholesky) on four waves (glue_dev.hpp); filter state in device memory (double-buffered by pair parity),
+//             the second half's inputs in glue_dev[slot], the host's record in a pinned GlueRec
+//   directedMatch head (reads glue_dev[slot]) -> directedMatch tail -> regularize / depth EKF / next pair's first rotation
 // The host never stands between a pair's halves (round 2: kernel end -> event -> host glue -> flag -> wait kernel, 8-10 us
 // of an ~80 us frame, and the reason the rate moved with the box's host): it queues pair k as soon as frame k + lead - 2 has
 // been handed to the detect worker and reads the pairs' records up to kSlots - 1 pairs later. A pair's match counters are
@@ -2319,8 +2323,8 @@ struct rebvio_hip_batch {
   std::vector<LaneStatic> ls_host;  // what ls_dev holds (re-uploaded when a lane's lens model changes)
   bool lens = false;                // every lane has a lens model: the batched front end runs ahead of the scans
   MapDev* maptab_dev = nullptr;
-  hipEvent_t ev_scan[2]{}, ev_flag[2]{};
-  bool ev_flag_used[2] = {false, false};
+  hipEvent_t ev_scan[kDetPar]{}, ev_flag[kDetPar]{};
+  bool ev_flag_used[kDetPar]{};
   static constexpr int kReadyRing = 16;
   hipEvent_t ev_ready[kReadyRing]{};  // keylines + distance fields of a step finished (keyline stream)
   hipEvent_t slot_ev[rebvio_hip_ctx::kSlots]{};
@@ -2344,6 +2348,12 @@ struct rebvio_hip_batch {
   uint64_t pair_seq = 0;
   int lead = 4;
   int group = 2;          // steps queued together (REBVIO_HIP_BATCH_GROUP 1..4, see stream_enqueue_group)
+  int lm_lanes_per_launch = 1;  // lanes whose LM workgroups the device holds together (lm_chain_b_max_lanes)
+  // REBVIO_HIP_DEBUG: host time per step of the detect worker's launches, of the caller's track enqueue and of its waits for
+  // result slots (printed by rebvio_hip_batch_flush)
+  bool dbg = false;
+  std::atomic<uint64_t> t_det_ns{0};
+  double t_trk_enq = 0, t_slot_wait = 0;
   int dm_head_form = 0;   // REBVIO_HIP_BATCH_DM_HEAD: 0 by lane count, 1 thread per keyline, 2 eight lanes per keyline
   bool poisoned = false;  // a step failed half way (some lanes prepared, others not): every later call is refused
   // detect-enqueue worker: launches the detect stage of a step while the caller thread launches the track stage (the
@@ -2429,7 +2439,10 @@ void batch_det_worker(rebvio_hip_batch* b) {
       j = b->det_jobs.front();
       b->det_jobs.pop_front();
     }
-    if (batch_detect_launch(b, j) != 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int drc = batch_detect_launch(b, j);
+    if (b->dbg) b->t_det_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+    if (drc != 0) {
       std::lock_guard<std::mutex> lk(b->det_mu);
       b->det_error = g_err;
       for (auto* m : j.maps) m->enqueued.store(1, std::memory_order_release);
@@ -2470,7 +2483,9 @@ int batch_harvest(rebvio_hip_batch* b, int need) {
     const rebvio_hip_batch::InFlight& a = b->inflight[0];
     const rebvio_hip_batch::InFlight& n = b->inflight[1];
     if (need > 0) {
+      const auto t0 = std::chrono::steady_clock::now();
       HIPCHK(hipEventSynchronize(b->slot_ev[n.ev_slot]));
+      b->t_slot_wait += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     } else {
       const hipError_t q = hipEventQuery(b->slot_ev[n.ev_slot]);
       if (q == hipErrorNotReady) break;
@@ -2543,7 +2558,7 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
     if (spec_now && !b->lane[0]->lm_spec_forced)
       for (auto* c : b->lane) spec_now = spec_now && c->lm_miss_ema < 0.17f;
     const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
-    launch_lm_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0, glue_params(b->lane[0], frame_dt));
+    launch_lm_chain_b(s, b->K, b->B, b->lm_lanes_per_launch, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0, glue_params(b->lane[0], frame_dt));
     const int gate = (int)b->P.global_min_matches_threshold;
     launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);
     HIPCHK(hipGetLastError());
@@ -2621,7 +2636,7 @@ void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
   for (auto* c : b->lane) rebvio_hip_destroy(c);
   if (b->ls_dev) (void)hipFree(b->ls_dev);
   if (b->maptab_dev) (void)hipFree(b->maptab_dev);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kDetPar; ++i) {
     if (b->ev_scan[i]) (void)hipEventDestroy(b->ev_scan[i]);
     if (b->ev_flag[i]) (void)hipEventDestroy(b->ev_flag[i]);
   }
@@ -2643,19 +2658,23 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   if (ndev <= 0) return fail_msg("no HIP device present: the gfx950 backend has no CPU fallback", -4);
   if (p->device_id < 0 || p->device_id >= ndev) return fail_msg("device_id out of range", -3);
   HIPCHK(hipSetDevice(p->device_id));
+  int lm_lanes_per_launch = 1;
   {
-    // The persistent LM kernel exchanges records among the workgroups of a lane: all of a launch's workgroups (lanes x
-    // ceil(keylines_max / 512)) must be resident at once. Checked here against what the device admits, instead of finding out
-    // from an exchange time-out (-9) under load.
-    const int max_lanes = lm_chain_b_max_lanes(p->device_id, p->keylines_max, (int)p->iterations + 1);
-    if (lanes > max_lanes) {
+    // The persistent LM kernel exchanges records among the workgroups of a lane, and every workgroup of a launch has to be
+    // resident for that (no assumption about dispatch order): the batch driver launches it for as many lanes at a time as the
+    // device holds together (lm_chain_b_max_lanes; 8 lanes of 16 k keylines on an MI355X). Not even one lane: refused here
+    // instead of finding out from an exchange time-out (-9).
+    lm_lanes_per_launch = lm_chain_b_max_lanes(p->device_id, p->keylines_max, (int)p->iterations + 1);
+    if (lm_lanes_per_launch < 1) {
       char msg[200];
-      std::snprintf(msg, sizeof(msg), "batch: %d lanes of %d keylines do not fit the device at once (the persistent LM kernel needs all "
-                    "its workgroups resident): at most %d lanes", lanes, p->keylines_max, max_lanes);
+      std::snprintf(msg, sizeof(msg), "batch: the %d LM workgroups of one lane (%d keylines) do not fit this device together",
+                    (p->keylines_max + 511) / 512, p->keylines_max);
       return fail_msg(msg, -3);
     }
   }
   rebvio_hip_batch* b = new rebvio_hip_batch;
+  b->lm_lanes_per_launch = lm_lanes_per_launch;
+  b->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
   struct Guard {
     rebvio_hip_batch* b;
     ~Guard() {
@@ -2690,9 +2709,12 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
     for (int f = 0; f < 2; ++f) {
       L.sa[f] = c->sb.a[f];
       L.sb[f] = c->sb.b[f];
-      L.dog2[f] = c->dog2[f];
-      L.mag2[f] = c->mag2[f];
-      L.rowcount2[f] = c->rowcount2[f];
+    }
+    for (int i = 0; i < kDetPar; ++i) {
+      L.dog2[i] = c->dog2[i];
+      L.mag2[i] = c->mag2[i];
+      L.rowcount2[i] = c->rowcount2[i];
+      L.undist_img[i] = c->undist_img[i];
     }
     L.stash = c->db.stash;
     L.bits = c->db.bits;
@@ -2712,8 +2734,6 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
     L.gstate = c->gstate;
     L.xrv_part = c->xrv_part;
     L.undist_map = c->undist_map;
-    L.undist_img[0] = c->undist_img[0];
-    L.undist_img[1] = c->undist_img[1];
     for (auto* m : c->pool) {
       const int rc = batch_upload_map_entry(b, l, m);
       if (rc) return rc;
@@ -2722,7 +2742,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   HIPCHK(hipMalloc(&b->ls_dev, ls.size() * sizeof(LaneStatic)));
   HIPCHK(hipMemcpy(b->ls_dev, ls.data(), ls.size() * sizeof(LaneStatic), hipMemcpyHostToDevice));
   b->ls_host = ls;
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kDetPar; ++i) {
     HIPCHK(hipEventCreateWithFlags(&b->ev_scan[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&b->ev_flag[i], hipEventDisableTiming));
   }
@@ -2766,10 +2786,9 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
       rebvio_hip_ctx* c = b->lane[l];
       with += c->undist_map ? 1 : 0;
       LaneStatic& L = b->ls_host[(size_t)l];
-      if (L.undist_map != c->undist_map || L.undist_img[0] != c->undist_img[0] || L.undist_img[1] != c->undist_img[1]) {
+      if (L.undist_map != c->undist_map || std::memcmp(L.undist_img, c->undist_img, sizeof(L.undist_img)) != 0) {
         L.undist_map = c->undist_map;
-        L.undist_img[0] = c->undist_img[0];
-        L.undist_img[1] = c->undist_img[1];
+        for (int i = 0; i < kDetPar; ++i) L.undist_img[i] = c->undist_img[i];
         changed = true;
       }
     }
@@ -2786,7 +2805,7 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   fr.step = b->step;
   fr.m.resize((size_t)B);
   LaneDynB dyn{};
-  const int par = (int)(b->step & 1);
+  const int par = (int)(b->step % kDetPar);
   rebvio_hip_map* last_reused = nullptr;
   for (int l = 0; l < B; ++l) {
     rebvio_hip_ctx* c = b->lane[l];
@@ -2845,7 +2864,10 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
     const bool shallow = (int)b->inflight.size() < b->group;
     const int nsteps = shallow ? std::min(b->group, Q - b->lead + 1) : (Q >= b->lead + b->group - 1 ? b->group : 0);
     if (nsteps >= 1) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const double w0 = b->t_slot_wait;
       const int rc = batch_enqueue_group(b, nsteps);
+      b->t_trk_enq += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() - (b->t_slot_wait - w0);
       if (rc) {
         b->poisoned = true;
         return rc;
@@ -2863,6 +2885,13 @@ int rebvio_hip_batch_next_records(rebvio_hip_batch* b, rebvio_hip_pair_out* out,
 int rebvio_hip_batch_flush(rebvio_hip_batch* b) {
   HIPCHK(hipSetDevice(b->device));
   while (b->det_done_steps.load(std::memory_order_acquire) < b->step) std::this_thread::yield();
+  if (b->dbg && b->step)
+    std::fprintf(stderr, "[rebvio_hip] batch of %d lanes, host time per step (us): detect worker's launches %.1f  track enqueue %.1f  waiting "
+                 "for result slots %.1f\n", b->B, (double)b->t_det_ns.load() / 1e3 / (double)b->step, b->t_trk_enq / (double)b->step,
+                 b->t_slot_wait / (double)b->step);
+  if (b->dbg)
+    std::fprintf(stderr, "[rebvio_hip] batch: pool of lane 0 holds %d maps (min_pool %d), %d steps in flight, %d detected steps queued\n",
+                 (int)b->lane[0]->pool.size(), b->lane[0]->min_pool, (int)b->inflight.size(), (int)b->frames.size());
   int rc = 0;
   while (rc == 0 && b->frames.size() >= 2)  // the steps no group was started for yet
     rc = batch_enqueue_group(b, std::min(b->group, (int)b->frames.size() - 1));

@@ -268,12 +268,17 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 constexpr int kMaxLanes = 16;
 constexpr int kPairSlots = 16;  // result slots of the streaming / batch drivers: pairs in flight between the device and the host
 constexpr int kLaneMaps = 24;  // map-table entries per lane (the batch driver bounds its pool by this)
+// Scale-space outputs (DoG, squared gradient, per-row counts, undistorted frame) exist kDetPar times per context: the scans of
+// step k + 1 overlap the keyline extraction of step k. Two is enough: with four, an 8-lane batch ran at the same rate (38.8 k
+// frames/s either way; the scan stream's wait for the keyline stage of step k - kDetPar is not what limits a batched step,
+// DESIGN.md 6c).
+constexpr int kDetPar = 2;
 struct LaneStatic {
   float* sa[2];   // scan buffer A per filter
   float* sb[2];   // scan buffer B per filter
-  float* dog2[2];
-  float* mag2[2];
-  int* rowcount2[2];
+  float* dog2[kDetPar];
+  float* mag2[kDetPar];
+  int* rowcount2[kDetPar];
   float4* stash;
   unsigned long long* bits;
   DetState* det;  // ring [kDetRing + 1]
@@ -290,7 +295,7 @@ struct LaneStatic {
   GlueState* gstate;           // [2] gyro-bias filter state + prior rotation, by pair parity
   float* xrv_part;             // extRotVel block records of the pair in flight
   const int2* undist_map;      // the lane's lens model (fixed-point source coordinates), null without one
-  float* undist_img[2];        // x3 + undistorted fp32 frame by step parity
+  float* undist_img[kDetPar];  // x3 + undistorted fp32 frame by step parity (step % kDetPar)
 };
 struct LaneDyn {
   const void* img;              // u8 frame of this step (device memory)
@@ -321,8 +326,8 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
                           const int widths[2][3], bool lens);
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
-void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
-                       int spec, const GlueParams& gp);
+void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, int lanes_per_launch, const LaneStatic* ls, const MapDev* maptab,
+                       const LaneDynB& dyn, int calls, int spec, const GlueParams& gp);
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
                       float max_radius, int gate, int head_form);
 

@@ -3,12 +3,14 @@
 // correction, Cholesky covariance, the inputs of directedMatch rotated by Rback (edge_map.cpp:193-194) and the next pair's
 // prior rotation (rebvio.cpp:163-164). ONE source for both places it runs:
 //   * on the host, for the per-pair API (rebvio_hip_track_pair; rebvio::Rebvio runs its own fusion between the halves);
-//   * on the device, in the prologue of the directedMatch head kernel, for the streaming and batch drivers - no host round
-//     trip sits between a pair's two halves there (track.hip, glue_wave).
-// Same statements in the same order, fp contraction off on both sides; what can differ between the two is the last bit of
-// sinf / cosf (libm on the host, the device library on the GPU) inside SO3::exp. TooN's own SO3 / Cholesky / SVD are
-// tolerance-only against this restatement anyway; the bar between host and device glue is stated and
-// checked in tests/test_parity_gpu.py::test_device_glue_equals_host_glue.
+//   * on the device, for the streaming and batch drivers: workgroup 0 of the persistent LM kernel runs it at the kernel's tail
+//     (track.hip lm_tail_glue -> glue_dev.hpp glue_workgroup, the same statements dealt to the lanes of four waves; k_pair_glue
+//     in per-call mode) - no host round trip sits between a pair's two halves there.
+// Same statements in the same order, fp contraction off on both sides, and no library call whose rounding could differ
+// between host and device: the sine / cosine of SO3::exp come from hm::sincos_det (double polynomial, hostmath.hpp), square
+// roots and divisions are IEEE on both. The two therefore give identical BITS, which tests/test_parity_gpu.py checks
+// (test_device_glue_equals_host_glue on a stream, test_glue_probe_random_inputs on random and degenerate inputs through
+// rebvio_hip_test_glue). TooN's own SO3 / Cholesky / SVD remain tolerance-only against this restatement.
 #pragma once
 
 #include "common.hpp"

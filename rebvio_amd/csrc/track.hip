@@ -1893,11 +1893,12 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec(KParams p, MapD
 template <int kChainThreads>
 __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec_b(KParams p, const LaneStatic* __restrict__ ls,
                                                                    const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll,
-                                                                   GlueParams gp) {
-  const LaneStatic& L = ls[blockIdx.z];
-  const LaneDyn d = dyn.v[blockIdx.z];
+                                                                   GlueParams gp, int lane0) {
+  const int lane = lane0 + (int)blockIdx.z;  // a launch carries the lanes that fit the device together (launch_lm_chain_b)
+  const LaneStatic& L = ls[lane];
+  const LaneDyn d = dyn.v[lane];
   PairSlot* slot = L.slot[d.slot];
-  lm_chain_spec_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls,
+  lm_chain_spec_body<kChainThreads>(p, lane_map(maptab, lane, d.om, d.om_swap), lane_map(maptab, lane, d.nm, d.nm_swap), calls,
                                     L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist,
                                     nullptr, slow_poll, lane_glue_args(L, d, calls, gp));
 }
@@ -1917,11 +1918,12 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain(KParams p, MapDev om
 template <int kChainThreads>
 __global__ __launch_bounds__(kChainThreads) void k_lm_chain_b(KParams p, const LaneStatic* __restrict__ ls,
                                                               const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll,
-                                                              GlueParams gp) {
-  const LaneStatic& L = ls[blockIdx.z];
-  const LaneDyn d = dyn.v[blockIdx.z];
+                                                              GlueParams gp, int lane0) {
+  const int lane = lane0 + (int)blockIdx.z;  // a launch carries the lanes that fit the device together (launch_lm_chain_b)
+  const LaneStatic& L = ls[lane];
+  const LaneDyn d = dyn.v[lane];
   PairSlot* slot = L.slot[d.slot];
-  lm_chain_body<kChainThreads>(p, lane_map(maptab, blockIdx.z, d.om, d.om_swap), lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), calls, 1,
+  lm_chain_body<kChainThreads>(p, lane_map(maptab, lane, d.om, d.om_swap), lane_map(maptab, lane, d.nm, d.nm_swap), calls, 1,
                                L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist, nullptr,
                                slow_poll, lane_glue_args(L, d, calls, gp));
 }
@@ -2911,21 +2913,28 @@ void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m,
             p.quantile_num_bins, g_dev);
 }
 
-void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn, int calls,
-                       int spec, const GlueParams& gp) {
-  // 512-thread workgroups (the single-stream default); lanes x 30 workgroups at 16k keylines must all be resident: with one
-  // workgroup per CU that holds up to 8 lanes on 256 CUs (rebvio_hip_batch_create checks the bound)
+void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, int lanes_per_launch, const LaneStatic* ls, const MapDev* maptab,
+                       const LaneDynB& dyn, int calls, int spec, const GlueParams& gp) {
+  // 512-thread workgroups (the single-stream default). The workgroups of a lane wait for each other's records, and HIP promises
+  // nothing about the order in which a grid's workgroups become resident (MI355X_MICROARCH.md, contract [G]): a launch carries
+  // only as many lanes as fit the device TOGETHER (lm_chain_b_max_lanes: 8 lanes of 16 k keylines at one workgroup per CU), a
+  // wider batch takes several launches back to back.
   const int slow_poll = lanes >= 3 ? 1 : 0;
-  if (spec && lm_spec_usable(p.kmax, calls))
-    RH_LAUNCH(k_lm_chain_spec_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), lm_spec_shm(p.kmax, calls), s, p, ls, maptab,
-              dyn, calls, slow_poll, gp);
-  else
-    RH_LAUNCH(k_lm_chain_b<512>, dim3((p.kmax + 511) / 512, 1, (unsigned)lanes), dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll, gp);
+  const int per = std::max(1, std::min(lanes, lanes_per_launch));
+  const bool use_spec = spec && lm_spec_usable(p.kmax, calls);
+  for (int l0 = 0; l0 < lanes; l0 += per) {
+    const dim3 grid((p.kmax + 511) / 512, 1, (unsigned)std::min(per, lanes - l0));
+    if (use_spec)
+      RH_LAUNCH(k_lm_chain_spec_b<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, ls, maptab, dyn, calls, slow_poll, gp, l0);
+    else
+      RH_LAUNCH(k_lm_chain_b<512>, grid, dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll, gp, l0);
+  }
 }
 
-// The batched persistent LM kernel needs every workgroup of the launch resident at once (they wait for each other's
-// records). One block per CU is taken off the occupancy query's answer where it admits several (MI355X_MICROARCH.md: the
-// query can read one block per CU high); kernels of the other streams only delay residency, they do not depend on this one.
+// How many lanes' workgroups of the batched persistent LM kernel the device holds at once: all workgroups of a launch poll
+// their lane's records, so all of them have to be resident together whatever order they are dispatched in. One block per CU is
+// taken off the occupancy query's answer where it admits several (MI355X_MICROARCH.md: the query can read one block per CU
+// high); kernels of the other streams only delay residency, they do not depend on this one. 0: not even one lane fits.
 int lm_chain_b_max_lanes(int device, int kmax, int calls) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 1;
@@ -2938,7 +2947,7 @@ int lm_chain_b_max_lanes(int device, int kmax, int calls) {
   }
   nb = nb > 1 ? nb - 1 : 1;
   const int per_lane = (kmax + 511) / 512;
-  return std::max(1, std::min(kMaxLanes, nb * cus / per_lane));
+  return std::min(kMaxLanes, nb * cus / per_lane);
 }
 
 // second half of a batched step (every lane's inputs come from the record its LM kernel's glue left)

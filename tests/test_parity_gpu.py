@@ -1208,13 +1208,22 @@ def test_batched_lanes_with_the_euroc_lens_model(B, c2_stream):
     bat.close()
 
 
-def test_batch_create_checks_what_the_device_can_hold(B, c2_stream):
-    """The persistent LM kernel of a batch needs all lanes' workgroups resident at once; rebvio_hip_batch_create compares the
-    request with the device's occupancy instead of leaving it to an exchange time-out: 16 lanes of 64k keylines (16 x 125
-    workgroups of 512 threads) cannot fit 256 CUs, and the message names the bound."""
+def test_sixteen_lanes_equal_stand_alone_streams(B, c2_stream):
+    """The widest batch the ABI takes: 16 lanes x 16k keylines = 480 LM workgroups of 512 threads. The workgroups of a lane
+    wait for each other's records, so a launch of the batched persistent kernel carries only as many lanes as the device holds
+    together (lm_chain_b_max_lanes, track.hip: 8 at this size); the driver covers 16 lanes with two launches per step and every
+    lane's records still equal a stand-alone context's. Lane counts outside 1..16 are refused."""
+    from rebvio_amd import synth
     cam = c2_stream[1]
-    with pytest.raises(B.HipError, match="at most [0-9]+ lanes"):
-        B.Batch(params_for(B, cam, keylines_ref=60000, keylines_max=64000), 16)
+    L, n = 16, 14
+    streams = [c2_stream[0]] + [synth.render_stream(cam.width, cam.height, 8, stream_id=s)[0] for s in range(1, L)]
+    order = synth.pingpong_indices(8, n)
+    got = _batch_records(B, cam, streams, order)
+    for s in (0, 7, 15):
+        want = _stand_alone_records(B, cam, streams[s], order)
+        assert len(want) == n - 1 and got[s] == want, s
+    assert all(len(g) == n - 1 and all(r[-2] == 0 for r in g) for g in got)
+    assert len({tuple(g) for g in got}) == L  # sixteen different scenes, sixteen different record sets
     with pytest.raises(B.HipError, match="lanes must be in"):
         B.Batch(params_for(B, cam, **KW_C2), 17)
 
