@@ -26,6 +26,24 @@ void upload_tables(const float* recip128, const float* pinv75) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pinv), pinv75, sizeof(float) * 75);
 }
 
+// ---- XCD-aware tile order ------------------------------------------------------------------------------------------------
+// The hardware deals the workgroups of a launch to the 8 XCDs round-robin in the order of their linear index (observed,
+// MI355X_MICROARCH.md "Workgroup dispatch": blocks b and b + 8 share an XCD; speed only, nothing depends on it for
+// correctness), and every XCD has its own 4 MB L2. With tile = blockIdx, neighbouring tiles of an image always sit on
+// DIFFERENT XCDs: the halo rows / columns two tiles share, and the two 64-byte halves of a 128-byte line that two 16-column
+// strips of k_colscan share, are fetched into two L2s (rocprofv3 FETCH_SIZE: k_colscan_b and k_rowscan_b<2> fetched 2x their
+// algorithmic bytes, k_dog_mag_b 2.8x). Here the workgroups of one XCD take a CONTIGUOUS band of tiles instead: with n tiles
+// in row-major order, workgroup t (its class c = t % 8 names its XCD, up to a per-launch constant) takes tile
+//   c * (n / 8) + min(c, n % 8) + t / 8
+// - a bijection on [0, n) - so that what neighbouring tiles share is found in the L2 that already holds it.
+__device__ __forceinline__ uint2 xcd_band_block() {
+  const unsigned gx = gridDim.x, n = gx * gridDim.y;
+  const unsigned t = blockIdx.x + gx * blockIdx.y;
+  const unsigned c = t & 7u;
+  const unsigned tile = c * (n >> 3) + min(c, n & 7u) + (t >> 3);
+  return make_uint2(tile % gx, tile / gx);
+}
+
 // FastGaussian::average (scale_space.cpp:69-128): the nine border/interior cases with their distinct
 // operand orders. II is the integral image, d the box width.
 // `ld` = row pitch of II in floats (cols rounded up to a multiple of 4: the scan kernels move 16-byte vectors; the
@@ -262,17 +280,18 @@ template <int MODE>  // 0: u8 image * 3.0f, 1: fp32 image, 2: box average (width
 __device__ __forceinline__ void rowscan_body(const void* __restrict__ src0, const void* __restrict__ src1,
                                                  float* __restrict__ dst0, float* __restrict__ dst1, int R, int Cimg, int d0,
                                                  int d1, int ldw) {
+  const uint2 vb = xcd_band_block();  // tile coordinates: contiguous bands of tiles per XCD (see xcd_band_block)
   // C = row pitch of the integral images = the image width rounded up to a multiple of 4; the chain also runs over the
   // padding columns (they follow the image's columns, so the image's prefix values do not depend on them)
   const int C = (Cimg + 3) & ~3;
   extern __shared__ float4 smem4[];
   float* tile = reinterpret_cast<float*>(smem4);
-  const int f = blockIdx.y;
+  const int f = vb.y;
   const void* __restrict__ src = f ? src1 : src0;
   float* __restrict__ dst = f ? dst1 : dst0;
   const int d = f ? d1 : d0;
   const int d2 = d >> 1;
-  const int r0 = blockIdx.x * kStrip;
+  const int r0 = vb.x * kStrip;
   const int nrows = min(kStrip, R - r0);
   const int C4 = C >> 2;
   // thread -> (strip row, 16-byte chunk): one wave per row, 64 chunks (1 KiB) per pass; no divisions.
@@ -395,10 +414,11 @@ __global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict_
 constexpr int kColStrip = 16;
 
 __device__ __forceinline__ void colscan_body(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh) {
+  const uint2 vb = xcd_band_block();  // tile coordinates: contiguous bands of tiles per XCD (see xcd_band_block)
   extern __shared__ float4 smem4[];
   float* tile = reinterpret_cast<float*>(smem4);  // [kColStrip][ldh]
-  float* __restrict__ buf = blockIdx.y ? buf1 : buf0;
-  const int c0 = blockIdx.x * kColStrip;
+  float* __restrict__ buf = vb.y ? buf1 : buf0;
+  const int c0 = vb.x * kColStrip;
   const int ncols = min(kColStrip, C - c0);  // multiple of 4 (cols % 4 == 0)
   const int q = ncols >> 2;                  // float4 per row of the strip (<= 4)
   // thread -> (row offset, 16-byte column chunk): 4 chunks per strip row, 64 rows per pass of the 256 threads
@@ -524,12 +544,13 @@ __device__ __forceinline__ void dog_mag_body(const float* __restrict__ II0, cons
                                                  int d1, float* __restrict__ dog, float* __restrict__ mag,
                                                  float* __restrict__ scale0, float* __restrict__ scale1, int R, int C,
                                                  int* __restrict__ rowcount) {
+  const uint2 vb = xcd_band_block();  // tile coordinates: contiguous bands of tiles per XCD (see xcd_band_block)
   constexpr int kDogTileRows = kDogRows + 2 + kDogMaxD;
   const int ld = (C + 3) & ~3;  // pitch of the integral images
   __shared__ float t0[kDogTileRows * kDogPitch];
   __shared__ float t1[kDogTileRows * kDogPitch];
   __shared__ float s0[kDogRows + 2][66];
-  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * kDogRows;
+  const int c0 = vb.x * 64, r0 = vb.y * kDogRows;
   const int tid = threadIdx.y * 64 + threadIdx.x;
   const int h0 = d0 >> 1, h1 = d1 >> 1;
   // scale 0: averages at rows r0-1 .. r0+kDogRows, columns c0-1 .. c0+64 -> integral rows r0-2-h0 .. r0+kDogRows+h0
@@ -611,9 +632,10 @@ __device__ __forceinline__ void keyline_flag_body(const float* __restrict__ dog,
                                                       KParams p, const DetState* __restrict__ det_in,
                                                       float4* __restrict__ stash, unsigned long long* __restrict__ bits,
                                                       int* __restrict__ rowcount) {
+  const uint2 vb = xcd_band_block();  // tile coordinates: contiguous bands of tiles per XCD (see xcd_band_block)
   __shared__ float sd[kFlagRows + 4][68];
   const int R = p.rows, C = p.cols;
-  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * kFlagRows;
+  const int c0 = vb.x * 64, r0 = vb.y * kFlagRows;
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int i = tid; i < (kFlagRows + 4) * 68; i += 256) {
     const int lr = i / 68, lc = i - lr * 68;
@@ -668,7 +690,7 @@ __device__ __forceinline__ void keyline_flag_body(const float* __restrict__ dog,
     const unsigned long long b = __ballot(cand);
     if (c < C && cand) stash[(size_t)r * C + c] = fit;
     if (threadIdx.x == 0) {
-      bits[(size_t)r * p.nseg + blockIdx.x] = b;
+      bits[(size_t)r * p.nseg + vb.x] = b;
       const int n = __popcll(b);
       if (n) atomicAdd(&rowcount[r], n);
     }
@@ -714,8 +736,9 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
                                                       const int* __restrict__ rowcount, const DetState* __restrict__ det_in,
                                                       DetState* __restrict__ det_out, const MapState* prev_st,
                                                       int clear_df, int ntiles) {
+  const uint2 vb = xcd_band_block();  // tile coordinates: contiguous bands of tiles per XCD (see xcd_band_block)
   const int R = p.rows, C = p.cols;
-  const int r0 = blockIdx.y * kEmitRows;
+  const int r0 = vb.y * kEmitRows;
   const int lane = threadIdx.x, wid = threadIdx.y, tid = wid * 64 + lane;
   __shared__ int s_rc[kEmitRows];    // candidates per row of the tile
   __shared__ int s_seg[kEmitRows];   // ... of each row in the segments left of this one
@@ -732,7 +755,7 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
     const int lr = tid >> 4, sg = tid & 15, r = r0 + lr;
     int acc = 0;
     if (lr < kEmitRows && r < R)
-      for (int q = sg; q < (int)blockIdx.x; q += 16) acc += __popcll(bits[(size_t)r * p.nseg + q]);
+      for (int q = sg; q < (int)vb.x; q += 16) acc += __popcll(bits[(size_t)r * p.nseg + q]);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);  // (the sixteen lanes of a row are neighbours in one wave)
     if (sg == 0 && lr < kEmitRows) {
@@ -741,7 +764,7 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
     }
   }
   {  // the distance-field tile counters of this map start at zero (k_join_edges bins into them)
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x, t = wg * 256 + tid;
+    const int wg = vb.y * gridDim.x + vb.x, t = wg * 256 + tid;
     if (t < ntiles) m.tile_cnt[t] = 0;
   }
   __syncthreads();
@@ -750,9 +773,9 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
     for (int j = 0; j < tid; ++j) base += s_rc[j];
     s_base[tid] = base + s_seg[tid];
     // raster rank of the row's first keyline (segment 0: the rows above only), clamped like the ranks below
-    if (blockIdx.x == 0 && r0 + tid < R) m.row_start[r0 + tid] = min(base, p.kmax);
+    if (vb.x == 0 && r0 + tid < R) m.row_start[r0 + tid] = min(base, p.kmax);
   }
-  if (blockIdx.y == 0 && blockIdx.x == 0 && wid == 0) {  // one wave publishes the frame's scalars
+  if (vb.y == 0 && vb.x == 0 && wid == 0) {  // one wave publishes the frame's scalars
     int tp = 0;
     for (int i = lane; i < R; i += 64) tp += rowcount[i];
     const int total = wave_sum(tp);
@@ -775,13 +798,13 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
     }
   }
   __syncthreads();
-  const int c = blockIdx.x * 64 + lane;
+  const int c = vb.x * 64 + lane;
   if (c >= C) return;
 #pragma unroll
   for (int k = 0; k < kEmitRows / 4; ++k) {
     const int lr = wid + 4 * k, r = r0 + lr;
     if (r >= R) break;  // (whole wave)
-    const unsigned long long b = bits[(size_t)r * p.nseg + blockIdx.x];
+    const unsigned long long b = bits[(size_t)r * p.nseg + vb.x];
     const bool cand = (b >> lane) & 1ull;
     const int rank = s_base[lr] + __popcll(b & ((1ull << lane) - 1ull));
     const size_t pix = (size_t)r * C + c;
