@@ -322,6 +322,28 @@ __host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int l
   }
   return m;
 }
+#if defined(__HIPCC__)
+// ---- XCD-aware tile order ------------------------------------------------------------------------------------------------
+// The hardware deals the workgroups of a launch to the 8 XCDs round-robin in the order of their linear index (observed,
+// MI355X_MICROARCH.md "Workgroup dispatch": blocks b and b + 8 share an XCD; speed only, nothing depends on it for
+// correctness), and every XCD has its own 4 MB L2. With tile = blockIdx, neighbouring tiles of an image always sit on
+// DIFFERENT XCDs: the halo rows / columns two tiles share, and the two 64-byte halves of a 128-byte line that two 16-column
+// strips of k_colscan share, are fetched into two L2s (rocprofv3 FETCH_SIZE: k_colscan_b and k_rowscan_b<2> fetched 2x their
+// algorithmic bytes, k_dog_mag_b 2.8x). Here the workgroups of one XCD take a CONTIGUOUS band of tiles instead: with n tiles
+// in row-major order, workgroup t (its class c = t % 8 names its XCD, up to a per-launch constant) takes tile
+//   c * (n / 8) + min(c, n % 8) + t / 8
+// - a bijection on [0, n) - so that what neighbouring tiles share is found in the L2 that already holds it. The per-keyline
+// kernels (one workgroup per 256 keylines in raster order) use it with gridDim.y = 1: neighbouring keyline blocks probe the
+// same mask rows and old-map keylines. NOT used by the persistent LM kernels (their workgroup index is the record group's).
+__device__ __forceinline__ uint2 xcd_band_block() {
+  const unsigned gx = gridDim.x, n = gx * gridDim.y;
+  const unsigned t = blockIdx.x + gx * blockIdx.y;
+  const unsigned c = t & 7u;
+  const unsigned tile = c * (n >> 3) + min(c, n & 7u) + (t >> 3);
+  return make_uint2(tile % gx, tile / gx);
+}
+
+#endif
 void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
                           const int widths[2][3], bool lens);
 void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);

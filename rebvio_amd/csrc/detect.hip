@@ -26,24 +26,6 @@ void upload_tables(const float* recip128, const float* pinv75) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(c_pinv), pinv75, sizeof(float) * 75);
 }
 
-// ---- XCD-aware tile order ------------------------------------------------------------------------------------------------
-// The hardware deals the workgroups of a launch to the 8 XCDs round-robin in the order of their linear index (observed,
-// MI355X_MICROARCH.md "Workgroup dispatch": blocks b and b + 8 share an XCD; speed only, nothing depends on it for
-// correctness), and every XCD has its own 4 MB L2. With tile = blockIdx, neighbouring tiles of an image always sit on
-// DIFFERENT XCDs: the halo rows / columns two tiles share, and the two 64-byte halves of a 128-byte line that two 16-column
-// strips of k_colscan share, are fetched into two L2s (rocprofv3 FETCH_SIZE: k_colscan_b and k_rowscan_b<2> fetched 2x their
-// algorithmic bytes, k_dog_mag_b 2.8x). Here the workgroups of one XCD take a CONTIGUOUS band of tiles instead: with n tiles
-// in row-major order, workgroup t (its class c = t % 8 names its XCD, up to a per-launch constant) takes tile
-//   c * (n / 8) + min(c, n % 8) + t / 8
-// - a bijection on [0, n) - so that what neighbouring tiles share is found in the L2 that already holds it.
-__device__ __forceinline__ uint2 xcd_band_block() {
-  const unsigned gx = gridDim.x, n = gx * gridDim.y;
-  const unsigned t = blockIdx.x + gx * blockIdx.y;
-  const unsigned c = t & 7u;
-  const unsigned tile = c * (n >> 3) + min(c, n & 7u) + (t >> 3);
-  return make_uint2(tile % gx, tile / gx);
-}
-
 // FastGaussian::average (scale_space.cpp:69-128): the nine border/interior cases with their distinct
 // operand orders. II is the integral image, d the box width.
 // `ld` = row pitch of II in floats (cols rounded up to a multiple of 4: the scan kernels move 16-byte vectors; the
@@ -886,12 +868,13 @@ __device__ __forceinline__ bool df_clip_range(float2 pos, float2 u, int half, in
 // LDS table, one returning global atomic per touched tile and workgroup reserves the slots, and the crossing test is
 // simply evaluated twice (count, then place) instead of keeping per-thread tile lists.
 __device__ __forceinline__ void join_edges_body(KParams p, MapDev m, int T, int ntx, int nty) {
+  const uint2 vb = xcd_band_block();  // which keylines / tiles this workgroup takes: contiguous bands per XCD (common.hpp)
   extern __shared__ int t_cnt[];  // [ntx * nty] count, then cursor, of this workgroup's keylines per tile
   const int n = m.st->n;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = vb.x * 256 + threadIdx.x;
   const int C = p.cols;
   const int ntiles = ntx * nty;
-  const bool live_wg = (int)blockIdx.x * 256 < n;
+  const bool live_wg = (int)vb.x * 256 < n;
   if (live_wg)
     for (int t = threadIdx.x; t < ntiles; t += 256) t_cnt[t] = 0;
   unsigned gb = 0x7F800000u, gB = 0u;
@@ -1050,6 +1033,7 @@ unsigned long long* g_df_stamps_host = nullptr;
 #endif
 constexpr int kDfsThreads = 512;
 constexpr int kDfsList = 1024;  // candidates staged per chunk (24 KB)
+constexpr int kDfSpecSlots = 256;  // list entries a workgroup reads before it knows its tile's count
 constexpr int kDfsSub = 16;     // lanes that walk one keyline's r-range (four keylines per wave)
 
 // Field cells [y0, y1) x [x0, x1) from the row range: every keyline detected in the rows that can reach the box is a
@@ -1154,8 +1138,14 @@ __device__ __forceinline__ void df_lists_body(KParams p, MapDev m, const DetStat
   // every scalar this workgroup needs, and its own entry, in one round of independent loads
   const int cnt = m.tile_cnt[tile];
   const float4* ent = m.tile_list + (size_t)tile * kDfTileCap * 2;
-  const int slot = min(tid, kDfTileCap - 1);
-  const float4 e0 = ent[2 * slot], e1 = ent[2 * slot + 1];  // (speculative: garbage beyond cnt, never used)
+  // the first kDfSpecSlots entries are read before cnt is known (speculative: garbage beyond cnt, never used) - the usual tile
+  // holds ~200; slots beyond that only when the count says so (a dependent round trip for the few crowded tiles instead of
+  // 16 KB fetched per tile whatever its list holds: FETCH_SIZE of k_df_lists_b 37.8 -> 20.3 MB per 8-lane launch)
+  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+  if (tid < kDfSpecSlots) {
+    e0 = ent[2 * tid];
+    e1 = ent[2 * tid + 1];
+  }
   const MapState st = *m.st;
   const float prev_auto = det_prev->auto_threshold;
   const int n = st.n;
@@ -1163,6 +1153,10 @@ __device__ __forceinline__ void df_lists_body(KParams p, MapDev m, const DetStat
   if (tile == 0 && tid == 0) m.st->threshold = thr;  // EdgeMap::threshold(auto_threshold_) (:185)
   const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
   const int x1 = min(x0 + T, p.cols), y1 = min(y0 + T, p.rows);
+  if (tid >= kDfSpecSlots && tid < cnt && cnt <= kDfTileCap) {
+    e0 = ent[2 * tid];
+    e1 = ent[2 * tid + 1];
+  }
   if (cnt > kDfTileCap) {
     df_rowrange_body(p, m, thr, n, T, T, x0, x1, y0, y1, df_smem, &l_n RH_DFS_STAMP_FWD);
     return;

@@ -2139,7 +2139,8 @@ __device__ __forceinline__ DmArgs dm_args(const GlueDev* __restrict__ gd, const 
 __device__ __forceinline__ void directed_match_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const uint2 vb = xcd_band_block();  // which keylines / tiles this workgroup takes: contiguous bands per XCD (common.hpp)
+  const int idx = vb.x * 256 + threadIdx.x;
   const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid)
   const float2 rsq = nm.rs[idx];
   const float2 gq = nm.grad[idx];
@@ -2261,9 +2262,10 @@ __global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneS
 __device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
                                                          float max_radius, int* __restrict__ work, int* __restrict__ work_n,
                                                          int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
+  const uint2 vb = xcd_band_block();  // which keylines / tiles this workgroup takes: contiguous bands per XCD (common.hpp)
   static_assert(kHeadSteps == 4, "eight probe slots per keyline");
-  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[48] = __builtin_amdgcn_s_memrealtime();
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[48] = __builtin_amdgcn_s_memrealtime();
+  const int gid = vb.x * 256 + threadIdx.x;
   const int idx = gid >> 3, slot = gid & 7;  // keyline, probe slot (slot = 2 * step + side; side 0: tn, 1: tp)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024), issued before the parameter block is read
@@ -2631,10 +2633,11 @@ __global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel
 __device__ __forceinline__ void regularize_ekf_body(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
                                                         int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
                                                         int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
+  const uint2 vb = xcd_band_block();  // which keylines / tiles this workgroup takes: contiguous bands per XCD (common.hpp)
   __shared__ int sh[128];
-  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[50] = __builtin_amdgcn_s_memrealtime();
-  if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[50] = __builtin_amdgcn_s_memrealtime();
+  if (work_n_reset && vb.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
+  const int idx = vb.x * 256 + threadIdx.x;
   const float2 rs = m.rs[idx];  // bound-free early loads, issued before the parameter block is read
   const int in = m.id_next[idx], ip = m.id_prev[idx];
   const int mid = m.match_id[idx];
