@@ -2362,8 +2362,11 @@ __device__ __forceinline__ void directed_match_tail_body(KParams p, MapDev nm, M
                                                              float max_radius, const int* __restrict__ work,
                                                              const int* __restrict__ work_n, int rot_, Mat3 R0_,
                                                              const GlueDev* __restrict__ gd) {
-  if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[49] = __builtin_amdgcn_s_memrealtime();
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  // band order (common.hpp): the waves of one XCD take a contiguous part of the queue - neighbouring keylines search along
+  // parallel lines one pixel apart and meet the same mask lines and old-map keylines
+  const uint2 vb = xcd_band_block();
+  if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[49] = __builtin_amdgcn_s_memrealtime();
+  const int wave = (vb.x * 256 + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   // queue length, this wave's first entry (speculative: the queue array has kmax entries) and the parameter block are three
   // independent loads: one round trip instead of three dependent ones
@@ -2374,7 +2377,7 @@ __device__ __forceinline__ void directed_match_tail_body(KParams p, MapDev nm, M
   const Mat3& R0 = A.R0;  // (velocity, its covariance and Rback only enter the probe geometry, which the queue carries)
   const int rot = A.rot;
   (void)max_radius;
-  if (blockIdx.x == 0 && threadIdx.x == 0) nm.st->dm_queued = total;
+  if (vb.x == 0 && threadIdx.x == 0) nm.st->dm_queued = total;
   __shared__ float seq[4][2][kDmSeqMax];  // per wave: the probe sequences of the entry in work (see below)
   int nfound = 0, nkf = 0;  // per lane: the lane that holds the accepted candidate commits it
   const int wstride = (gridDim.x * 256) >> 6;
