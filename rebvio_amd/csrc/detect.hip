@@ -533,30 +533,71 @@ __device__ __forceinline__ void dog_mag_body(const float* __restrict__ II0, cons
   __shared__ float t1[kDogTileRows * kDogPitch];
   __shared__ float s0[kDogRows + 2][66];
   const int c0 = vb.x * 64, r0 = vb.y * kDogRows;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
   const int h0 = d0 >> 1, h1 = d1 >> 1;
   // scale 0: averages at rows r0-1 .. r0+kDogRows, columns c0-1 .. c0+64 -> integral rows r0-2-h0 .. r0+kDogRows+h0
+  // (staging: wave w takes tile rows w, w + 4, ..., its lanes the row's columns lane, lane + 64 - consecutive lanes read and
+  // write consecutive words, and no index needs a division by the run-time tile width)
   const int ro0 = r0 - 2 - h0, co0 = c0 - 2 - h0, nr0 = kDogRows + 3 + 2 * h0, nc0 = 64 + 3 + 2 * h0;
-  for (int i = tid; i < nr0 * nc0; i += 256) {
-    const int lr = i / nc0, lc = i - lr * nc0;
-    const int r = min(max(ro0 + lr, 0), R - 1), c = min(max(co0 + lc, 0), C - 1);  // (clamped positions are never used)
-    t0[lr * kDogPitch + lc] = II0[(size_t)r * ld + c];
-  }
+  const int tx = threadIdx.x, ty = threadIdx.y;
   // scale 1: averages at the tile's own pixels -> integral rows r0-1-h1 .. r0+kDogRows-1+h1
   const int ro1 = r0 - 1 - h1, co1 = c0 - 1 - h1, nr1 = kDogRows + 1 + 2 * h1, nc1 = 64 + 1 + 2 * h1;
-  for (int i = tid; i < nr1 * nc1; i += 256) {
-    const int lr = i / nc1, lc = i - lr * nc1;
-    const int r = min(max(ro1 + lr, 0), R - 1), c = min(max(co1 + lc, 0), C - 1);
-    t1[lr * kDogPitch + lc] = II1[(size_t)r * ld + c];
+  // every load of both tiles is issued before the first LDS write (loops of constant length over registers: with the tile
+  // heights as run-time trip counts the compiler waits for each row's load before it issues the next - seven dependent round
+  // trips per tile)
+  constexpr int kIt = (kDogRows + 3 + kDogMaxD - 1 + 3) / 4;  // rows per wave, both tiles (nr0 <= kDogRows + 3 + kDogMaxD - 1)
+  float va[kIt], vb2[kIt], wa[kIt], wb[kIt];
+  const int ca0 = min(max(co0 + tx, 0), C - 1), cb0 = min(max(co0 + tx + 64, 0), C - 1);
+  const int ca1 = min(max(co1 + tx, 0), C - 1), cb1 = min(max(co1 + tx + 64, 0), C - 1);
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    const int lr = ty + 4 * k;
+    const float* __restrict__ row0 = II0 + (size_t)min(max(ro0 + lr, 0), R - 1) * ld;  // (clamped positions are never used)
+    const float* __restrict__ row1 = II1 + (size_t)min(max(ro1 + lr, 0), R - 1) * ld;
+    va[k] = row0[ca0];
+    vb2[k] = row0[cb0];
+    wa[k] = row1[ca1];
+    wb[k] = row1[cb1];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    const int lr = ty + 4 * k;
+    if (lr < nr0) {
+      t0[lr * kDogPitch + tx] = va[k];
+      if (tx + 64 < nc0) t0[lr * kDogPitch + tx + 64] = vb2[k];
+    }
+    if (lr < nr1) {
+      t1[lr * kDogPitch + tx] = wa[k];
+      if (tx + 64 < nc1) t1[lr * kDogPitch + tx + 64] = wb[k];
+    }
   }
   __syncthreads();
   // (pointer arithmetic only: box_avg indexes [r * pitch + c] with image coordinates)
   const float* v0 = t0 - ((ptrdiff_t)ro0 * kDogPitch + co0);
   const float* v1 = t1 - ((ptrdiff_t)ro1 * kDogPitch + co1);
-  for (int i = tid; i < (kDogRows + 2) * 66; i += 256) {
-    const int lr = i / 66, lc = i - lr * 66;
-    const int r = r0 + lr - 1, c = c0 + lc - 1;
-    s0[lr][lc] = (r >= 0 && r < R && c >= 0 && c < C) ? box_avg(v0, r, c, d0, R, C, kDogPitch) : 0.0f;
+  // A tile none of whose box sums touches the image border (3 of 4 at 640x480) takes box_avg's interior case directly: the
+  // same four corners in the same operand order times the same reciprocal (scale_space.cpp:121-126), without the nine-way
+  // border logic and the per-pixel table lookup. Uniform per workgroup.
+  const bool in0 = r0 - 1 >= h0 + 1 && r0 + kDogRows < R - h0 && c0 - 1 >= h0 + 1 && c0 + 64 < C - h0;
+  const bool in1 = r0 >= h1 + 1 && r0 + kDogRows - 1 < R - h1 && c0 >= h1 + 1 && c0 + 63 < C - h1;
+  const float rc0 = c_recip[d0 * d0], rc1 = c_recip[d1 * d1];
+  for (int lr = ty; lr < kDogRows + 2; lr += 4) {
+    const int r = r0 + lr - 1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int lc = tx + 64 * half;
+      if (lc >= 66) break;
+      const int c = c0 + lc - 1;
+      float a;
+      if (in0) {
+        const float* q1 = v0 + (r + h0) * kDogPitch + c;
+        const float* q2 = v0 + (r - h0 - 1) * kDogPitch + c;
+        a = (((q1[h0] - q1[-h0 - 1]) - q2[h0]) + q2[-h0 - 1]) * rc0;
+      } else {
+        a = (r >= 0 && r < R && c >= 0 && c < C) ? box_avg(v0, r, c, d0, R, C, kDogPitch) : 0.0f;
+      }
+      s0[lr][lc] = a;
+    }
   }
   __syncthreads();
   const int c = c0 + threadIdx.x;
@@ -567,7 +608,14 @@ __device__ __forceinline__ void dog_mag_body(const float* __restrict__ II0, cons
     if (r >= R) break;
     if (c == 0) rowcount[r] = 0;  // reset for the candidate kernel of this frame
     const float a0 = s0[lr + 1][threadIdx.x + 1];
-    const float a1 = box_avg(v1, r, c, d1, R, C, kDogPitch);
+    float a1;
+    if (in1) {
+      const float* q1 = v1 + (r + h1) * kDogPitch + c;
+      const float* q2 = v1 + (r - h1 - 1) * kDogPitch + c;
+      a1 = (((q1[h1] - q1[-h1 - 1]) - q2[h1]) + q2[-h1 - 1]) * rc1;
+    } else {
+      a1 = box_avg(v1, r, c, d1, R, C, kDogPitch);
+    }
     const size_t i = (size_t)r * C + c;
     dog[i] = a1 - a0;
     float m = 0.0f;
