@@ -323,6 +323,36 @@ __host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int l
   return m;
 }
 #if defined(__HIPCC__)
+// ---- pointers that reach a kernel through a table in memory -----------------------------------------------------------------
+// A pointer passed as a kernel argument (alone or inside a by-value struct such as MapDev) is known to the compiler to be
+// global and gets global_load / global_store. One that a batched kernel LOADS from a table - LaneStatic, the lanes' map table -
+// is a generic pointer: every access through it becomes a FLAT instruction, which counts on BOTH the vector-memory and the LDS
+// counter (an LDS wait then also waits for every load in flight: the staging loops of the per-pixel kernels lose the overlap
+// they were written for) and cannot use the scalar-base addressing form. gptr() states what the table holds: device or pinned
+// memory, never LDS or scratch. (ISA of the batched kernels before: 0 global / 7..129 flat loads each; the single-stream
+// kernels: all global.)
+template <class T>
+__device__ __forceinline__ T* gptr(T* p) {
+  // The value is the same for every thread of the workgroup (read from a table entry chosen by the lane index), so it lives in
+  // scalar registers. A plain cast to the global address space and back is folded away before address spaces are inferred, and
+  // assumptions on __builtin_amdgcn_is_shared / _is_private did not take either (hipcc of ROCm 7.2); passing the typed pointer
+  // through an empty asm keeps the type, and the "s" constraint keeps the scalar base for the saddr addressing form.
+  typedef __attribute__((address_space(1))) T* G;
+  G q = (G)p;
+  asm("" : "+s"(q));
+  return (T*)q;
+}
+__device__ __forceinline__ MapDev global_map(MapDev m) {
+  m.pos = gptr(m.pos); m.pos_img = gptr(m.pos_img); m.mpos_img = gptr(m.mpos_img); m.grad = gptr(m.grad); m.mgrad = gptr(m.mgrad);
+  m.gnorm = gptr(m.gnorm); m.mgnorm = gptr(m.mgnorm); m.rs = gptr(m.rs); m.rs_tmp = gptr(m.rs_tmp); m.grad_tmp = gptr(m.grad_tmp);
+  m.id_prev = gptr(m.id_prev); m.id_next = gptr(m.id_next); m.match_id = gptr(m.match_id); m.match_fwd = gptr(m.match_fwd);
+  m.match_kf = gptr(m.match_kf); m.matches = gptr(m.matches); m.fwd_key = gptr(m.fwd_key); m.residual = gptr(m.residual);
+  m.mask = gptr(m.mask); m.df = gptr(m.df); m.unit = gptr(m.unit); m.tile_cnt = gptr(m.tile_cnt); m.tile_list = gptr(m.tile_list);
+  m.row_start = gptr(m.row_start); m.st = gptr(m.st);
+  return m;
+}
+#endif
+#if defined(__HIPCC__)
 // ---- XCD-aware tile order ------------------------------------------------------------------------------------------------
 // The hardware deals the workgroups of a launch to the 8 XCDs round-robin in the order of their linear index (observed,
 // MI355X_MICROARCH.md "Workgroup dispatch": blocks b and b + 8 share an XCD; speed only, nothing depends on it for

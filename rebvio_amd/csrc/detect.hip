@@ -381,10 +381,10 @@ __global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict_
   // stage 0: first pass on the lane's u8 frame; 3: first pass on the fp32 frame its front end left (lens model set)
   const bool first = stage == 0 || stage == 3;
   const void* s0 = stage == 0 ? dyn.v[lane].img
-                              : (stage == 3 ? (const void*)L.undist_img[dyn.v[lane].parity] : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[0]));
-  const void* s1 = first ? s0 : (stage == 1 ? (const void*)L.sa[0] : (const void*)L.sb[1]);
-  float* o0 = stage == 1 ? L.sb[0] : L.sa[0];
-  float* o1 = first ? L.sa[0] : (stage == 1 ? L.sb[1] : L.sa[1]);
+                              : (stage == 3 ? (const void*)gptr(L.undist_img[dyn.v[lane].parity]) : (stage == 1 ? (const void*)gptr(L.sa[0]) : (const void*)gptr(L.sb[0])));
+  const void* s1 = first ? s0 : (stage == 1 ? (const void*)gptr(L.sa[0]) : (const void*)gptr(L.sb[1]));
+  float* o0 = stage == 1 ? gptr(L.sb[0]) : gptr(L.sa[0]);
+  float* o1 = first ? gptr(L.sa[0]) : (stage == 1 ? gptr(L.sb[1]) : gptr(L.sa[1]));
   rowscan_body<MODE>(s0, s1, o0, o1, R, Cimg, d0, d1, ldw);
 }
 
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float
 // batched form. which 0: a[0] alone; 1: b[0], b[1]; 2: a[0], a[1]
 __global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh) {
   const LaneStatic& L = ls[lane0 + blockIdx.z];
-  colscan_body(which == 1 ? L.sb[0] : L.sa[0], which == 0 ? L.sa[0] : (which == 1 ? L.sb[1] : L.sa[1]), R, C, ldh);
+  colscan_body(which == 1 ? gptr(L.sb[0]) : gptr(L.sa[0]), which == 0 ? gptr(L.sa[0]) : (which == 1 ? gptr(L.sb[1]) : gptr(L.sa[1])), R, C, ldh);
 }
 
 // ---- last box pass of both filters fused with DoG and squared gradient (scale_space.cpp:210-233) ------
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void k_dog_mag(const float* __restrict__ II0, 
 __global__ __launch_bounds__(256) void k_dog_mag_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int lane0, int d0, int d1, int R, int C) {
   const LaneStatic& L = ls[lane0 + blockIdx.z];
   const int b = dyn.v[lane0 + blockIdx.z].parity;
-  dog_mag_body<16>(L.sa[0], L.sa[1], d0, d1, L.dog2[b], L.mag2[b], nullptr, nullptr, R, C, L.rowcount2[b]);
+  dog_mag_body<16>(gptr(L.sa[0]), gptr(L.sa[1]), d0, d1, gptr(L.dog2[b]), gptr(L.mag2[b]), nullptr, nullptr, R, C, gptr(L.rowcount2[b]));
 }
 
 // Threshold servo of EdgeDetector::detect (edge_detector.cpp:33-36), evaluated identically by every thread.
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void k_keyline_flag(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_keyline_flag_b(KParams p, const LaneStatic* __restrict__ ls, LaneDynB dyn) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
-  keyline_flag_body<16>(L.dog2[d.parity], L.mag2[d.parity], p, L.det + d.det_in, L.stash, L.bits, L.rowcount2[d.parity]);
+  keyline_flag_body<16>(gptr(L.dog2[d.parity]), gptr(L.mag2[d.parity]), p, gptr(L.det) + d.det_in, gptr(L.stash), gptr(L.bits), gptr(L.rowcount2[d.parity]));
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -878,9 +878,9 @@ __global__ __launch_bounds__(256) void k_keyline_emit_b(KParams p, const LaneSta
                                                         LaneDynB dyn, int clear_df, int ntiles) {
   const LaneStatic& L = ls[blockIdx.z];
   const LaneDyn d = dyn.v[blockIdx.z];
-  const MapDev m = lane_map(maptab, blockIdx.z, d.nm, d.nm_swap);
-  const MapState* prev = d.prev >= 0 ? maptab[blockIdx.z * kLaneMaps + d.prev].st : nullptr;
-  keyline_emit_body<16>(p, m, L.stash, L.bits, L.rowcount2[d.parity], L.det + d.det_in, L.det + d.det_out, prev, clear_df, ntiles);
+  const MapDev m = global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap));
+  const MapState* prev = d.prev >= 0 ? gptr(maptab[blockIdx.z * kLaneMaps + d.prev].st) : nullptr;
+  keyline_emit_body<16>(p, m, gptr(L.stash), gptr(L.bits), gptr(L.rowcount2[d.parity]), gptr(L.det) + d.det_in, gptr(L.det) + d.det_out, prev, clear_df, ntiles);
 }
 
 // r-range of a keyline's probe segment (cells round(pos + u r), r in [-half, half)) that can fall into the pixel box
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void join_edges_body(KParams p, MapDev m, int T, int 
 __global__ __launch_bounds__(256) void k_join_edges(KParams p, MapDev m, int T, int ntx, int nty) { join_edges_body(p, m, T, ntx, nty); }
 __global__ __launch_bounds__(256) void k_join_edges_b(KParams p, const MapDev* __restrict__ maptab, LaneDynB dyn, int T, int ntx, int nty) {
   const LaneDyn d = dyn.v[blockIdx.z];
-  join_edges_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), T, ntx, nty);
+  join_edges_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), T, ntx, nty);
 }
 
 // ---- DistanceField::build (core.hpp:37-59) ---------------------------------------------------------------
@@ -1258,7 +1258,7 @@ template <int T>
 __global__ __launch_bounds__(kDfsThreads) void k_df_lists_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
                                                             LaneDynB dyn) {
   const LaneDyn d = dyn.v[blockIdx.z];
-  df_lists_body<T>(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), ls[blockIdx.z].det + d.det_out);
+  df_lists_body<T>(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), gptr(ls[blockIdx.z].det) + d.det_out);
 }
 #endif
 
@@ -1382,7 +1382,7 @@ __global__ __launch_bounds__(256) void k_front_end_u8(const uint8_t* __restrict_
 __global__ __launch_bounds__(256) void k_front_end_u8_b(const LaneStatic* __restrict__ ls, LaneDynB dyn, int lane0, int rows, int cols) {
   const int lane = lane0 + blockIdx.z;
   const LaneStatic& L = ls[lane];
-  front_end_body(static_cast<const uint8_t*>(dyn.v[lane].img), L.undist_map, L.undist_img[dyn.v[lane].parity], rows, cols);
+  front_end_body(static_cast<const uint8_t*>(dyn.v[lane].img), gptr(L.undist_map), gptr(L.undist_img[dyn.v[lane].parity]), rows, cols);
 }
 
 // Host frame -> device staging frame as a kernel of the scan stream (16 bytes per lane straight from the pinned ring slot over

@@ -1011,12 +1011,12 @@ __device__ __forceinline__ void chain_collect_records(const unsigned long long* 
 
 __device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const LaneDyn& d, int calls, const GlueParams& gp) {
   GlueArgs ga;
-  ga.lm = L.lm + calls + 1;
-  ga.xrv = L.xrv_part;
-  ga.st_in = L.gstate + (d.gpar & 1);
-  ga.st_out = L.gstate + ((d.gpar & 1) ^ 1);
-  ga.rec = L.rec[d.slot];
-  ga.gd_copy = L.glue_dev + d.slot;
+  ga.lm = gptr(L.lm) + calls + 1;
+  ga.xrv = gptr(L.xrv_part);
+  ga.st_in = gptr(L.gstate) + (d.gpar & 1);
+  ga.st_out = gptr(L.gstate) + ((d.gpar & 1) ^ 1);
+  ga.rec = gptr(L.rec[d.slot]);
+  ga.gd_copy = gptr(L.glue_dev) + d.slot;
   ga.gp = gp;
   return ga;
 }
@@ -1897,9 +1897,9 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec_b(KParams p, co
   const int lane = lane0 + (int)blockIdx.z;  // a launch carries the lanes that fit the device together (launch_lm_chain_b)
   const LaneStatic& L = ls[lane];
   const LaneDyn d = dyn.v[lane];
-  PairSlot* slot = L.slot[d.slot];
-  lm_chain_spec_body<kChainThreads>(p, lane_map(maptab, lane, d.om, d.om_swap), lane_map(maptab, lane, d.nm, d.nm_swap), calls,
-                                    L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist,
+  PairSlot* slot = gptr(L.slot[d.slot]);
+  lm_chain_spec_body<kChainThreads>(p, global_map(lane_map(maptab, lane, d.om, d.om_swap)), global_map(lane_map(maptab, lane, d.nm, d.nm_swap)), calls,
+                                    gptr(L.lm_zero), gptr(L.lm) + calls + 1, gptr(L.lm_xch), d.tag_base, gptr(L.lm_bar_err), gptr(L.hist), 0u, gptr(L.xrv_part), slot, gptr(L.hist),
                                     nullptr, slow_poll, lane_glue_args(L, d, calls, gp));
 }
 
@@ -1922,9 +1922,9 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain_b(KParams p, const L
   const int lane = lane0 + (int)blockIdx.z;  // a launch carries the lanes that fit the device together (launch_lm_chain_b)
   const LaneStatic& L = ls[lane];
   const LaneDyn d = dyn.v[lane];
-  PairSlot* slot = L.slot[d.slot];
-  lm_chain_body<kChainThreads>(p, lane_map(maptab, lane, d.om, d.om_swap), lane_map(maptab, lane, d.nm, d.nm_swap), calls, 1,
-                               L.lm_zero, L.lm + calls + 1, L.lm_xch, d.tag_base, L.lm_bar_err, L.hist, 0u, L.xrv_part, slot, L.hist, nullptr,
+  PairSlot* slot = gptr(L.slot[d.slot]);
+  lm_chain_body<kChainThreads>(p, global_map(lane_map(maptab, lane, d.om, d.om_swap)), global_map(lane_map(maptab, lane, d.nm, d.nm_swap)), calls, 1,
+                               gptr(L.lm_zero), gptr(L.lm) + calls + 1, gptr(L.lm_xch), d.tag_base, gptr(L.lm_bar_err), gptr(L.hist), 0u, gptr(L.xrv_part), slot, gptr(L.hist), nullptr,
                                slow_poll, lane_glue_args(L, d, calls, gp));
 }
 
@@ -2248,8 +2248,8 @@ __global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneS
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
-  directed_match_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
-                      L.dm_work, L.dm_work_n, 1, z9, L.glue_dev + d.slot);
+  directed_match_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9, max_radius,
+                      gptr(L.dm_work), gptr(L.dm_work_n), 1, z9, gptr(L.glue_dev) + d.slot);
 }
 
 // Pass 1, wide form: EIGHT lanes per keyline of the NEW map, one per probe slot of the head (2 * kHeadSteps == 8). The
@@ -2351,8 +2351,8 @@ __global__ __launch_bounds__(256) void k_directed_match8_b(KParams p, const Lane
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
-  directed_match8_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9, max_radius,
-                       L.dm_work, L.dm_work_n, 1, z9, L.glue_dev + d.slot);
+  directed_match8_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9, max_radius,
+                       gptr(L.dm_work), gptr(L.dm_work_n), 1, z9, gptr(L.glue_dev) + d.slot);
 }
 
 // Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
@@ -2521,8 +2521,8 @@ __global__ __launch_bounds__(256) void k_directed_match_tail_b(KParams p, const 
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
-  directed_match_tail_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), lane_map(maptab, blockIdx.z, d.om, d.om_swap), z3, z9, z9,
-                           max_radius, L.dm_work, L.dm_work_n, 1, z9, L.glue_dev + d.slot);
+  directed_match_tail_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9,
+                           max_radius, gptr(L.dm_work), gptr(L.dm_work_n), 1, z9, gptr(L.glue_dev) + d.slot);
 }
 
 // ---- EdgeMap::searchMatch as a public single-keyline call (edge_map.hpp:93-94, edge_map.cpp:101-184) ----------------
@@ -2759,8 +2759,8 @@ __global__ __launch_bounds__(256) void k_regularize_ekf_b(KParams p, const LaneS
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
-  regularize_ekf_body(p, lane_map(maptab, blockIdx.z, d.nm, d.nm_swap), z3, gate_min_matches, L.dm_work_n, 0, z9, L.hist, p.quantile_num_bins,
-                      L.glue_dev + d.slot);
+  regularize_ekf_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), z3, gate_min_matches, gptr(L.dm_work_n), 0, z9, gptr(L.hist), p.quantile_num_bins,
+                      gptr(L.glue_dev) + d.slot);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
