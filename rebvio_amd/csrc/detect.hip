@@ -773,13 +773,20 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
   __shared__ int s_rc[kEmitRows];    // candidates per row of the tile
   __shared__ int s_seg[kEmitRows];   // ... of each row in the segments left of this one
   __shared__ int s_base[kEmitRows];  // raster rank of the row's first candidate in THIS segment
-  __shared__ int s_p0;               // candidates in the rows above the tile
-  // rows above the tile: wave 0; the tile's own rows and the segments to the left: sixteen lanes per row
-  if (wid == 0) {
+  __shared__ int s_pw[4];            // candidates in the rows above the tile, one partial sum per wave
+  // rows above the tile: the whole workgroup, four loads per thread in flight together (one memory round trip per 1024 rows;
+  // a loop with the row count as its trip count waits for every load before it issues the next: up to eight dependent round
+  // trips at 480 rows on the path of every workgroup); the tile's own rows and the segments to the left: sixteen lanes per row
+  {
     int part = 0;
-    for (int i = lane; i < r0; i += 64) part += rowcount[i];
+    for (int base = 0; base < r0; base += 1024) {
+      const int i0 = base + tid, i1 = i0 + 256, i2 = i0 + 512, i3 = i0 + 768;
+      const int v0 = i0 < r0 ? rowcount[i0] : 0, v1 = i1 < r0 ? rowcount[i1] : 0;
+      const int v2 = i2 < r0 ? rowcount[i2] : 0, v3 = i3 < r0 ? rowcount[i3] : 0;
+      part += (v0 + v1) + (v2 + v3);
+    }
     const int tot = wave_sum(part);
-    if (lane == 0) s_p0 = tot;
+    if (lane == 0) s_pw[wid] = tot;
   }
   {
     const int lr = tid >> 4, sg = tid & 15, r = r0 + lr;
@@ -799,7 +806,7 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
   }
   __syncthreads();
   if (tid < kEmitRows) {
-    int base = s_p0;
+    int base = (s_pw[0] + s_pw[1]) + (s_pw[2] + s_pw[3]);
     for (int j = 0; j < tid; ++j) base += s_rc[j];
     s_base[tid] = base + s_seg[tid];
     // raster rank of the row's first keyline (segment 0: the rows above only), clamped like the ranks below
@@ -807,7 +814,12 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
   }
   if (vb.y == 0 && vb.x == 0 && wid == 0) {  // one wave publishes the frame's scalars
     int tp = 0;
-    for (int i = lane; i < R; i += 64) tp += rowcount[i];
+    for (int base = 0; base < R; base += 256) {  // (four loads in flight per lane, as above)
+      const int i0 = base + lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+      const int v0 = i0 < R ? rowcount[i0] : 0, v1 = i1 < R ? rowcount[i1] : 0;
+      const int v2 = i2 < R ? rowcount[i2] : 0, v3 = i3 < R ? rowcount[i3] : 0;
+      tp += (v0 + v1) + (v2 + v3);
+    }
     const int total = wave_sum(tp);
     if (lane == 0) {
       // auto_threshold_ as left by the previous detect's tuneThreshold (its min/max are final: same stream). Read before
