@@ -105,6 +105,14 @@ thread_local ProfOpen t_open;
 }  // namespace
 
 namespace rh {
+thread_local ArmedStop t_armed_stop;
+bool bound_events_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("REBVIO_HIP_BOUND_EVENTS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 // selection by exact name, or by prefix when the selector ends with '*'
 static bool prof_name_selected(const std::string& only, const char* name) {
   if (!only.empty() && only.back() == '*') return std::strncmp(only.c_str(), name, only.size() - 1) == 0;
@@ -310,7 +318,13 @@ struct rebvio_hip_ctx {
   std::string det_error;
   // host-side phase timing of the streaming driver (printed by flush when REBVIO_HIP_DEBUG is set)
   double t_detect_enq = 0, t_wait = 0, t_enq = 0, t_queued = 0;
+  std::atomic<uint64_t> t_worker_ns{0}, t_worker_n{0};  // the detect worker's launches (one job = one frame)
   bool dbg = false;
+  // REBVIO_HIP_DETECT_WORKER=1: a worker thread launches the streaming driver's detect kernels. Off by default since round 3: the
+  // runtime calls of two threads largely serialise AND slow each other down (detect launches 36 us per frame alone, 65 us beside
+  // the caller's pair launches), so a burst of pushes - the driver's 20-frame window - ran at 10.4 k frames/s with the worker and
+  // runs at 13.0 k with the caller launching everything itself (47 + 21 us of host time per 74 us frame).
+  bool det_worker = false;
   uint64_t t_frames = 0;
   bool owns_streams = true;  // false for the lanes of a batch (rebvio_hip_batch_*)
   rebvio_hip_map* bf_map[2] = {nullptr, nullptr};  // new map of the pair whose counters result slot r will report
@@ -530,20 +544,23 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   // the DoG / gradient kernel run at the head of the keyline stream.
   // Their inputs sb.a[] are then read while the scan stream already works on the next frame, hence the pair per parity;
   // the frame after next waits for ev_flag[b] (recorded behind them) above.
+  arm_stop_event(c->s_det, c->ev_scan[b]);
   launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount, 1);
-  HIPCHK(hipEventRecord(c->ev_scan[b], c->s_det));
+  HIPCHK(finish_stop_event(c->s_det, c->ev_scan[b]));
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
   HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
   launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2);
   if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done_ref ? m->done_ref : m->done, 0));
+  arm_stop_event(c->s_key, c->ev_flag[b]);
   launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->ev_flag[b], c->s_key));  // (after join: coarser than needed, same stream order)
+  HIPCHK(finish_stop_event(c->s_key, c->ev_flag[b]));  // (after join: coarser than needed, same stream order)
   c->ev_flag_used[b] = true;
   // distance field of this map, behind its keylines on the same stream (stream order is the dependency)
+  arm_stop_event(c->s_key, m->ready);
   launch_df_build(c->s_key, c->K, m->d, j.det_out, true);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(m->ready, c->s_key));
+  HIPCHK(finish_stop_event(c->s_key, m->ready));
   m->enqueued.store(1, std::memory_order_release);
   return 0;
 }
@@ -589,10 +606,16 @@ void det_worker_main(rebvio_hip_ctx* c) {
       j = c->det_jobs.front();
       c->det_jobs.pop_front();
     }
+    const auto tw0 = std::chrono::steady_clock::now();
     if (detect_launch(c, j) != 0) {
       std::lock_guard<std::mutex> lk(c->det_mu);
       c->det_error = g_err;
       j.m->enqueued.store(1, std::memory_order_release);
+    }
+    if (c->dbg) {
+      c->t_worker_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw0).count(),
+                               std::memory_order_relaxed);
+      c->t_worker_n.fetch_add(1, std::memory_order_relaxed);
     }
     c->det_pending.fetch_sub(1, std::memory_order_release);
   }
@@ -612,6 +635,18 @@ int detect_async(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts,
   int rc = detect_prepare(c, img_dev, is_u8, ts, &job);
   if (rc && job.pin_slot >= 0) c->pin_staged[job.pin_slot].store(0, std::memory_order_release);
   if (rc) return rc;
+  if (!c->det_worker) {  // REBVIO_HIP_DETECT_WORKER=0: the caller launches the detect kernels itself (one thread issues every runtime call)
+    const auto tw0 = std::chrono::steady_clock::now();
+    rc = detect_launch(c, job);
+    if (c->dbg) {
+      c->t_worker_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw0).count(),
+                               std::memory_order_relaxed);
+      c->t_worker_n.fetch_add(1, std::memory_order_relaxed);
+    }
+    job.m->enqueued.store(1, std::memory_order_release);
+    *out = job.m;
+    return rc;
+  }
   if (!c->det_thread.joinable()) c->det_thread = std::thread(det_worker_main, c);
   job.m->enqueued.store(0, std::memory_order_relaxed);
   c->det_pending.fetch_add(1, std::memory_order_release);
@@ -1051,6 +1086,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   }
   rebvio_hip_reset_state(c);
   c->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
+  if (const char* e = std::getenv("REBVIO_HIP_DETECT_WORKER")) c->det_worker = e[0] != '0';
   HIPCHK(hipDeviceSynchronize());
   guard.c = nullptr;
   *out = c;
@@ -1972,6 +2008,8 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     if (rc) return rc;
     launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
     const int gate = (int)c->P.global_min_matches_threshold;
+    // the group's event rides on its last kernel's own completion signal (no marker packet behind it)
+    if (g == npairs - 1) arm_stop_event(s, c->slot_ev[slot]);
     launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
     std::swap(nm->d.rs, nm->d.rs_tmp);
     std::swap(nm->d.grad, nm->d.grad_tmp);
@@ -1986,7 +2024,7 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     last_slot = slot;
     c->pair_seq++;
   }
-  HIPCHK(hipEventRecord(c->slot_ev[last_slot], s));
+  HIPCHK(finish_stop_event(s, c->slot_ev[last_slot]));
   for (int g = 0; g < npairs; ++g) {
     c->inflight[c->inflight.size() - 1 - (size_t)g].ev_slot = last_slot;
     release_map(c->frames[(size_t)g], c->slot_ev[last_slot]);  // stream-ordered: reusable once the group has drained
@@ -2135,6 +2173,15 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
                  "[rebvio_hip] host time per frame (us): detect hand-over %.1f  pair enqueue %.1f  waiting for result slots %.1f | long "
                  "directedMatch searches per pair %.0f\n",
                  c->t_detect_enq / n, c->t_enq / n, c->t_wait / n, c->t_queued / n);
+    const uint64_t wn = c->t_worker_n.load();
+    if (wn)
+      std::fprintf(stderr, "[rebvio_hip] detect worker: %.1f us of launches per frame over %llu frames\n", (double)c->t_worker_ns.load() * 1e-3 / (double)wn,
+                   (unsigned long long)wn);
+    // (the counters start again: a caller that flushes between phases reads each phase on its own)
+    c->t_detect_enq = c->t_enq = c->t_wait = c->t_queued = 0;
+    c->t_frames = 0;
+    c->t_worker_ns.store(0);
+    c->t_worker_n.store(0);
   }
   while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   int rc = 0;
@@ -2353,6 +2400,7 @@ struct rebvio_hip_batch {
   // result slots (printed by rebvio_hip_batch_flush)
   bool dbg = false;
   std::atomic<uint64_t> t_det_ns{0};
+  bool det_worker = true;  // REBVIO_HIP_DETECT_WORKER
   double t_trk_enq = 0, t_slot_wait = 0;
   int dm_head_form = 0;   // REBVIO_HIP_BATCH_DM_HEAD: 0 by lane count, 1 thread per keyline, 2 eight lanes per keyline
   bool poisoned = false;  // a step failed half way (some lanes prepared, others not): every later call is refused
@@ -2410,17 +2458,20 @@ void batch_release_map(rebvio_hip_map* m, bool record_done, hipEvent_t done_ref 
 int batch_detect_launch(rebvio_hip_batch* b, const rebvio_hip_batch::DetStep& j) {
   const int B = b->B, par = j.par;
   if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->st.s_det, b->ev_flag[par], 0));
+  arm_stop_event(b->st.s_det, b->ev_scan[par]);
   launch_scale_space_b(b->st.s_det, b->K, 0, B, b->ls_dev, j.dyn, b->lane[0]->widths, j.lens);
-  HIPCHK(hipEventRecord(b->ev_scan[par], b->st.s_det));
+  HIPCHK(finish_stop_event(b->st.s_det, b->ev_scan[par]));
   HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan[par], 0));
   if (j.reuse_done) HIPCHK(hipStreamWaitEvent(b->st.s_key, j.reuse_done, 0));
+  arm_stop_event(b->st.s_key, b->ev_flag[par]);
   launch_keylines_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b->ev_flag[par], b->st.s_key));
+  HIPCHK(finish_stop_event(b->st.s_key, b->ev_flag[par]));
   b->ev_flag_used[par] = true;
+  arm_stop_event(b->st.s_key, b->ev_ready[j.step % rebvio_hip_batch::kReadyRing]);
   launch_df_build_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b->ev_ready[j.step % rebvio_hip_batch::kReadyRing], b->st.s_key));
+  HIPCHK(finish_stop_event(b->st.s_key, b->ev_ready[j.step % rebvio_hip_batch::kReadyRing]));
   for (int l = 0; l < B; ++l) {  // the single-map entries (size, download, ...) wait on the map's own event
     HIPCHK(hipEventRecord(j.maps[l]->ready, b->st.s_key));
     j.maps[l]->enqueued.store(1, std::memory_order_release);
@@ -2560,6 +2611,7 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
     const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
     launch_lm_chain_b(s, b->K, b->B, b->lm_lanes_per_launch, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0, glue_params(b->lane[0], frame_dt));
     const int gate = (int)b->P.global_min_matches_threshold;
+    if (g == nsteps - 1) arm_stop_event(s, b->slot_ev[slot]);  // the group's event on its last kernel's completion signal
     launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);
     HIPCHK(hipGetLastError());
     for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
@@ -2578,7 +2630,7 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
     b->pair_seq++;
     last_slot = slot;
   }
-  HIPCHK(hipEventRecord(b->slot_ev[last_slot], s));
+  HIPCHK(finish_stop_event(s, b->slot_ev[last_slot]));
   for (int g = 0; g < nsteps; ++g) b->inflight[b->inflight.size() - 1 - (size_t)g].ev_slot = last_slot;
   for (auto& of : olds)
     for (auto* m : of.m) batch_release_map(m, false, b->slot_ev[last_slot]);  // the group's one event covers every old map
@@ -2675,6 +2727,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   rebvio_hip_batch* b = new rebvio_hip_batch;
   b->lm_lanes_per_launch = lm_lanes_per_launch;
   b->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
+  if (const char* e = std::getenv("REBVIO_HIP_DETECT_WORKER")) b->det_worker = e[0] != '0';
   struct Guard {
     rebvio_hip_batch* b;
     ~Guard() {
@@ -2849,12 +2902,24 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
   job.maps = fr.m;
   job.lens = b->lens;
   for (auto* m : fr.m) m->enqueued.store(0, std::memory_order_relaxed);
-  if (!b->det_thread.joinable()) b->det_thread = std::thread(batch_det_worker, b);
-  {
-    std::lock_guard<std::mutex> lk(b->det_mu);
-    b->det_jobs.push_back(job);
+  if (!b->det_worker) {  // the caller launches the step's detect kernels itself (see detect_async)
+    const auto t0 = std::chrono::steady_clock::now();
+    const int drc = batch_detect_launch(b, job);
+    if (b->dbg) b->t_det_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+    for (auto* m : fr.m) m->enqueued.store(1, std::memory_order_release);
+    b->det_done_steps.store(job.step + 1, std::memory_order_release);
+    if (drc) {
+      b->poisoned = true;
+      return drc;
+    }
+  } else {
+    if (!b->det_thread.joinable()) b->det_thread = std::thread(batch_det_worker, b);
+    {
+      std::lock_guard<std::mutex> lk(b->det_mu);
+      b->det_jobs.push_back(job);
+    }
+    b->det_cv.notify_one();
   }
-  b->det_cv.notify_one();
   b->frames.push_back(fr);
   b->step++;
 

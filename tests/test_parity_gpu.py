@@ -932,9 +932,13 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
     order = synth.pingpong_indices(len(frames), 40)
     npx = cam.width * cam.height
 
-    def run(lead, group, prio=None, stamps=False):
+    def run(lead, group, prio=None, stamps=False, extra=None):
         monkeypatch.setenv("REBVIO_HIP_LEAD", str(lead))
         monkeypatch.setenv("REBVIO_HIP_GROUP", str(group))
+        for name in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_BOUND_EVENTS"):
+            monkeypatch.delenv(name, raising=False)
+        for name, val in (extra or {}).items():
+            monkeypatch.setenv(name, val)
         if prio:
             monkeypatch.setenv("REBVIO_HIP_PRIO", prio)
         else:
@@ -954,6 +958,11 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
     for lead, group, prio, stamps in ((5, 1, None, False), (5, 4, None, False), (8, 2, None, False), (12, 6, None, False), (5, 4, "flat", False),
                                       (5, 3, None, True)):
         assert run(lead, group, prio, stamps) == base, (lead, group, prio, stamps)
+    # who launches the detect kernels (the caller itself, the default, or the context's worker thread) and how the streams'
+    # events are recorded (bound to a kernel's completion signal, the default, or as marker packets) move no result either
+    for extra in ({"REBVIO_HIP_DETECT_WORKER": "1"}, {"REBVIO_HIP_BOUND_EVENTS": "0"},
+                  {"REBVIO_HIP_DETECT_WORKER": "1", "REBVIO_HIP_BOUND_EVENTS": "0"}):
+        assert run(5, 4, extra=extra) == base, extra
 
 
 def test_euroc_frame_size_with_lens_model(orc_mod, B):
@@ -1152,8 +1161,10 @@ def _batch_records(B, cam, streams, order, lens=None, **kw):
 
 
 @pytest.mark.parametrize("L,env", [(3, {}), (4, {}), (8, {}), (4, {"REBVIO_HIP_LM": "seq"}), (2, {"REBVIO_HIP_BATCH_DM_HEAD": "thread"}),
-                                   (5, {"REBVIO_HIP_BATCH_DM_HEAD": "wide", "REBVIO_HIP_BATCH_LEAD": "6", "REBVIO_HIP_BATCH_GROUP": "3"})],
-                         ids=["3-lanes", "4-lanes", "8-lanes", "4-lanes-seq-lm", "2-lanes-thread-head", "5-lanes-wide-head-lead6-group3"])
+                                   (5, {"REBVIO_HIP_BATCH_DM_HEAD": "wide", "REBVIO_HIP_BATCH_LEAD": "6", "REBVIO_HIP_BATCH_GROUP": "3"}),
+                                   (3, {"REBVIO_HIP_DETECT_WORKER": "0", "REBVIO_HIP_BOUND_EVENTS": "0"})],
+                         ids=["3-lanes", "4-lanes", "8-lanes", "4-lanes-seq-lm", "2-lanes-thread-head", "5-lanes-wide-head-lead6-group3",
+                              "3-lanes-caller-launches-marker-events"])
 def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, env):
     """rebvio_hip_batch_*: L camera streams advanced in lock-step by batched launches (lane = blockIdx.z) produce, lane by lane,
     the records of L stand-alone contexts fed the same frames - bit for bit (same kernel bodies, same per-lane reduction
@@ -1170,7 +1181,7 @@ def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, e
         monkeypatch.setenv(k, v)
     got = _batch_records(B, cam, streams, order)
     for k in env:
-        if k.startswith("REBVIO_HIP_BATCH"):
+        if k.startswith("REBVIO_HIP_BATCH") or k in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_BOUND_EVENTS"):
             monkeypatch.delenv(k)
     want = [_stand_alone_records(B, cam, streams[s], order) for s in range(L)]
     for s in range(L):
