@@ -106,12 +106,9 @@ thread_local ProfOpen t_open;
 
 namespace rh {
 thread_local ArmedStop t_armed_stop;
-bool bound_events_enabled() {
-  static const bool on = [] {
-    const char* e = std::getenv("REBVIO_HIP_BOUND_EVENTS");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+bool bound_events_enabled() {  // (read per call, a few times per frame: tests switch it between contexts of one process)
+  const char* e = std::getenv("REBVIO_HIP_BOUND_EVENTS");
+  return !(e && e[0] == '0');
 }
 // selection by exact name, or by prefix when the selector ends with '*'
 static bool prof_name_selected(const std::string& only, const char* name) {
