@@ -317,6 +317,10 @@ struct rebvio_hip_ctx {
   double t_detect_enq = 0, t_wait = 0, t_enq = 0, t_queued = 0;
   std::atomic<uint64_t> t_worker_ns{0}, t_worker_n{0};  // the detect worker's launches (one job = one frame)
   bool dbg = false;
+  // host shadow of the information matrix W_Bg the DEVICE glue works on (streaming driver, glue_params_pre)
+  hm::M3 wbg_shadow{};
+  bool wbg_shadow_valid = false;
+  bool gyro_pre_on = true;  // REBVIO_HIP_GYRO_PRE=0: the device forms the gyroBiasCorrection matrices itself
   // REBVIO_HIP_DETECT_WORKER=1: a worker thread launches the streaming driver's detect kernels. Off by default since round 3: the
   // runtime calls of two threads largely serialise AND slow each other down (detect launches 36 us per frame alone, 65 us beside
   // the caller's pair launches), so a burst of pushes - the driver's 20-frame window - ran at 10.4 k frames/s with the worker and
@@ -883,6 +887,7 @@ int rebvio_hip_set_gyro_state(rebvio_hip_ctx* c, const float Bg[3], const float 
     return fail_msg("set_gyro_state: the streaming driver has frames in flight (rebvio_hip_flush first)", -7);
   for (int i = 0; i < 3; ++i) c->Bg[i] = Bg[i];
   c->W_Bg = hm::load3(W_Bg);
+  c->wbg_shadow_valid = false;  // (the next stream's first pair uploads this state and starts the shadow from it)
   return 0;
 }
 
@@ -1084,6 +1089,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   rebvio_hip_reset_state(c);
   c->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
   if (const char* e = std::getenv("REBVIO_HIP_DETECT_WORKER")) c->det_worker = e[0] != '0';
+  if (const char* e = std::getenv("REBVIO_HIP_GYRO_PRE")) c->gyro_pre_on = e[0] != '0';
   HIPCHK(hipDeviceSynchronize());
   guard.c = nullptr;
   *out = c;
@@ -1645,7 +1651,20 @@ GlueParams glue_params(const rebvio_hip_ctx* c, float frame_dt) {
   gp.frame_dt = frame_dt;
   gp.gyro_std_dev = c->P.gyro_std_dev;
   gp.gyro_bias_std_dev = c->P.gyro_bias_std_dev;
+  gp.has_pre = 0;
+  std::memset(gp.pre, 0, sizeof(gp.pre));
   return gp;
+}
+// Streaming driver: the pair's gyroBiasCorrection matrices from the host's shadow of the device's W_Bg (GlueParams::pre); the
+// shadow advances with every pair queued. Not valid (after rebvio_hip_set_gyro_state, before the first pair of a stream has
+// uploaded the host's state): the device forms them itself.
+void glue_params_pre(rebvio_hip_ctx* c, GlueParams* gp) {
+  if (!c->gyro_pre_on || !c->wbg_shadow_valid) return;
+  const float s_b = gp->gyro_bias_std_dev * gp->gyro_bias_std_dev * gp->frame_dt * gp->frame_dt;  // (rebvio.cpp:186-191, as the glue forms them)
+  const float s_g = gp->gyro_std_dev * gp->gyro_std_dev * gp->frame_dt * gp->frame_dt;
+  hm::gyro_pre(c->wbg_shadow, s_g, s_b, gp->pre);
+  gp->has_pre = 1;
+  c->wbg_shadow = hm::load3(gp->pre[2]);
 }
 GlueOut pair_glue(rebvio_hip_ctx* c, const LmState& lm, const float* xrv, int n_new, float frame_dt, hm::M3 R,
                   rebvio_hip_pair_out* out) {
@@ -1986,6 +2005,8 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
       hm::store3(R, gs.R);
       gs.pad = 0.f;
       HIPCHK(hipMemcpyAsync(c->gstate + gpar, &gs, sizeof(GlueState), hipMemcpyHostToDevice, s));
+      c->wbg_shadow = c->W_Bg;  // what the device's filter state starts from
+      c->wbg_shadow_valid = true;
       float RT[9];
       hm::store3(hm::transpose(R), RT);
       launch_rotate(s, c->K, om->d, RT, c->hist, 0);
@@ -2001,6 +2022,7 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     ga.rec = c->rec[slot];
     ga.gd_copy = c->glue_dev + slot;
     ga.gp = glue_params(c, frame_dt);
+    glue_params_pre(c, &ga.gp);
     int rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part, ga);  // rebvio.cpp:167-177 + the glue of rebvio.cpp:177-233
     if (rc) return rc;
     launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);

@@ -210,6 +210,14 @@ struct GlueRec {
 struct GlueParams {
   float frame_dt;
   float gyro_std_dev, gyro_bias_std_dev;
+  // The 3x3 matrices of gyroBiasCorrection (core.cpp:264-270, 282) depend on the filter's information matrix W_Bg and on
+  // frame_dt only - never on the pair's data - and W_Bg itself follows the recurrence W_Bg <- Wg + invert(invert(W_Bg) + Rb).
+  // The streaming driver keeps a host shadow of W_Bg and hands the pair's matrices over by value (hm::gyro_pre, the same
+  // statements as gyro_bias_correction): four dependent 3x3 inversions and two products leave the device glue's critical
+  // path (wave 1 of glue_workgroup, ~1.5 us per pair). has_pre == 0: the device forms them itself (batches, per-call API).
+  // [0] Wg  [1] Wb' = invert(invert(W_Bg) + Rb)  [2] Wg + Wb'  [3] iWgWb  [4] upd  [5] (Wg iWgWb) Wb'
+  int has_pre;
+  float pre[6][9];
 };
 
 // Device glue of a pair, run by workgroup 0 of the persistent LM kernel behind its last phase (glue_dev.hpp). lm == null: no

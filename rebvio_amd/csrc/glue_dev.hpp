@@ -168,6 +168,28 @@ __device__ __forceinline__ void glue_gyro3(float (&M)[10][9], const GlueState* s
   }
 }
 
+// element `lane` (< 9) of a 3x3 matrix handed over by value: selects, no lane-dependent index into the kernel arguments
+__device__ __forceinline__ float glue_pre_elem(const float (&m)[9], int lane) {
+  float v = m[0];
+#pragma unroll
+  for (int e = 1; e < 9; ++e) v = (lane == e) ? m[e] : v;
+  return v;
+}
+// the matrix set glue_gyro3 would leave, from GlueParams::pre (hm::gyro_pre on the host: the same statements, the same bits)
+__device__ __forceinline__ void glue_gyro3_from_pre(float (&M)[10][9], const GlueParams& gp, int depth, int lane) {
+  if (lane < 9) {
+    M[0][lane] = glue_pre_elem(gp.pre[0], lane);
+    if (depth >= 2) {
+      M[2][lane] = glue_pre_elem(gp.pre[1], lane);
+      M[3][lane] = glue_pre_elem(gp.pre[2], lane);
+      M[4][lane] = glue_pre_elem(gp.pre[3], lane);
+      M[6][lane] = glue_pre_elem(gp.pre[4], lane);
+      M[7][lane] = glue_pre_elem(gp.pre[5], lane);
+    }
+  }
+  glue_wave_sync();
+}
+
 // one column of inverse(A) per lane (lanes 0..5), TooN Cholesky<6>::get_inverse: every lane factorises for itself
 __device__ __forceinline__ void glue_chol6_inverse_lanes(const float* A /*LDS*/, float* inv /*LDS*/, int lane) {
   if (lane < 6) {
@@ -257,7 +279,10 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
     if (stamps && tid == 0) stamps[17] = __builtin_amdgcn_s_memrealtime();
   } else if (wid == 1) {
     // ---- gyroBiasCorrection up to inverse(Wxb) (core.cpp:264-276) ----
-    glue_gyro3(w.m3[0], ga.st_in, s_g, s_b, 2, lane);
+    if (ga.gp.has_pre)
+      glue_gyro3_from_pre(w.m3[0], ga.gp, 2, lane);
+    else
+      glue_gyro3(w.m3[0], ga.st_in, s_g, s_b, 2, lane);
     if (lane < 36) {  // Wxb = Wx with upd added to its lower right block (core.cpp:271-272)
       const int i = lane / 6, j = lane - 6 * i;
       const float v = w.W[lane];
@@ -267,7 +292,10 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
     glue_chol6_inverse_lanes(w.A[0], w.inv[0], lane);
   } else if (wid == 2) {
     // ---- W_Xgv after the correction (core.cpp:283) and its inverse (rebvio.cpp:201-202) ----
-    glue_gyro3(w.m3[1], ga.st_in, s_g, s_b, 1, lane);
+    if (ga.gp.has_pre)
+      glue_gyro3_from_pre(w.m3[1], ga.gp, 1, lane);
+    else
+      glue_gyro3(w.m3[1], ga.st_in, s_g, s_b, 1, lane);
     if (lane < 36) {
       const int i = lane / 6, j = lane - 6 * i;
       const float v = w.W[lane];

@@ -380,6 +380,21 @@ inline void sym6_solve(const float* A_, const float* b_, float* x_) {
   sym6_solve_ws(A_, b_, x_, ws);
 }
 
+// The data-independent part of gyroBiasCorrection below (same statements): pre[0] Wg, [1] Wb' , [2] Wg + Wb' (the information
+// matrix after the pair), [3] iWgWb, [4] upd, [5] (Wg iWgWb) Wb' - see GlueParams.
+RH_HD inline void gyro_pre(const M3& W_Bg, float s_g, float s_b, float pre[6][9]) {
+  const M3 Wg = invert3(diag3(s_g));
+  const M3 Wb = invert3(add(invert3(W_Bg), diag3(s_b)));
+  const M3 iWgWb = invert3(add(Wg, Wb));
+  const M3 upd = mul(Wg, sub(identity3(), mul(iWgWb, Wg)));
+  store3(Wg, pre[0]);
+  store3(Wb, pre[1]);
+  store3(add(Wg, Wb), pre[2]);
+  store3(iWgWb, pre[3]);
+  store3(upd, pre[4]);
+  store3(mul(mul(Wg, iWgWb), Wb), pre[5]);
+}
+
 // Core::gyroBiasCorrection (core.cpp:264-284); dgbias is zero on entry, as in the reference.
 RH_HD inline void gyro_bias_correction(float X[6], float Wx[36], M3& Wb, const M3& Rg, const M3& Rb, float dgbias_out[3]) {
   float dgbias[3] = {0, 0, 0};

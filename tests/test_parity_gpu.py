@@ -935,7 +935,7 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
     def run(lead, group, prio=None, stamps=False, extra=None):
         monkeypatch.setenv("REBVIO_HIP_LEAD", str(lead))
         monkeypatch.setenv("REBVIO_HIP_GROUP", str(group))
-        for name in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_BOUND_EVENTS"):
+        for name in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_BOUND_EVENTS", "REBVIO_HIP_GYRO_PRE"):
             monkeypatch.delenv(name, raising=False)
         for name, val in (extra or {}).items():
             monkeypatch.setenv(name, val)
@@ -960,8 +960,10 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
         assert run(lead, group, prio, stamps) == base, (lead, group, prio, stamps)
     # who launches the detect kernels (the caller itself, the default, or the context's worker thread) and how the streams'
     # events are recorded (bound to a kernel's completion signal, the default, or as marker packets) move no result either
+    # ... nor does who forms the data-independent 3x3 matrices of gyroBiasCorrection (the host from its shadow of W_Bg, the
+    # default, or the device glue itself)
     for extra in ({"REBVIO_HIP_DETECT_WORKER": "1"}, {"REBVIO_HIP_BOUND_EVENTS": "0"},
-                  {"REBVIO_HIP_DETECT_WORKER": "1", "REBVIO_HIP_BOUND_EVENTS": "0"}):
+                  {"REBVIO_HIP_DETECT_WORKER": "1", "REBVIO_HIP_BOUND_EVENTS": "0"}, {"REBVIO_HIP_GYRO_PRE": "0"}):
         assert run(5, 4, extra=extra) == base, extra
 
 

@@ -11,13 +11,18 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-NW = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-settle = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+_a = [a for a in sys.argv[1:] if not a.startswith("--")]
+K = int(_a[0]) if len(_a) > 0 else 20
+NW = int(_a[1]) if len(_a) > 1 else 40
+settle = int(_a[2]) if len(_a) > 2 else 1000
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from rebvio_amd import backend as B, synth  # noqa: E402
+from rebvio_amd import backend as B, shard, synth  # noqa: E402
+
+if "--no-bind" not in sys.argv:  # like bench.py: the CPUs of the GPU's NUMA node (the rate is host-sensitive: unbound -10..20 % on a two-socket box)
+    pr = torch.cuda.get_device_properties(0)
+    shard.bind_to_gpu_numa_node(f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0")
 
 W, H = 640, 480
 frames, cam = synth.render_stream(W, H, 24)
