@@ -1,6 +1,5 @@
-set -o pipefail
-for rep in 1 2; do
-for g in 1 0; do
-echo "gyro_pre=$g"; REBVIO_HIP_GYRO_PRE=$g timeout -k 10 120 python3 tools/host_jitter.py 8 2000 --bind 2>/dev/null | tail -1
-REBVIO_HIP_GYRO_PRE=$g timeout -k 10 120 python3 tools/short_window.py 20 40 2>/dev/null | tail -1
+for rep in 1 2 3; do
+for v in new old; do
+if [ $v = old ]; then export REBVIO_HIP_BATCH_LANE_READY=1; else unset REBVIO_HIP_BATCH_LANE_READY; fi
+echo -n "$v: "; timeout -k 10 120 python3 tools/batch_rate.py 8 1200 800 2>&1 | grep -h "lanes 8"
 done; done

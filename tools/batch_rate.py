@@ -12,7 +12,11 @@ warm = int(sys.argv[3]) if len(sys.argv) > 3 else 800
 prof = "--prof" in sys.argv
 
 import torch  # noqa: E402,F401
-from rebvio_amd import backend as B, synth  # noqa: E402
+from rebvio_amd import backend as B, shard, synth  # noqa: E402
+
+if "--no-bind" not in sys.argv:  # like bench.py: the CPUs of the GPU's NUMA node
+    _pr = torch.cuda.get_device_properties(0)
+    shard.bind_to_gpu_numa_node(f"{_pr.pci_domain_id:04x}:{_pr.pci_bus_id:02x}:{_pr.pci_device_id:02x}.0")
 
 W, H = 640, 480
 cam = synth.Camera.for_size(W, H)
