@@ -17,7 +17,7 @@ class Session;
 
 class FastGaussian {
  public:
-  // n must be 3 (the only value the reference uses, scale_space.cpp:186; the device path runs exactly three box passes)
+  // any n in 1..16 whose Kovesi widths stay in 3..11 (scale_space.cpp:14-41; the reference itself only constructs n = 3, :186)
   FastGaussian(rebvio::Camera::SharedPtr cam, types::Float sigma, int n = 3);
   FastGaussian() = delete;
   FastGaussian(const FastGaussian&) = delete;

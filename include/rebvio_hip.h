@@ -170,6 +170,9 @@ int rebvio_hip_search_match(rebvio_hip_ctx* ctx, rebvio_hip_map* searched, const
  * passes of the given (odd, 3..11) widths, as FastGaussian's constructor derives them from sigma (scale_space.cpp:14-41).
  * Test/diagnostic entry like rebvio_hip_scale_space. */
 int rebvio_hip_smooth(rebvio_hip_ctx* ctx, const float* img_host, const int widths3[3], float* out_host);
+/* The same for FastGaussian's general n (scale_space.cpp:14-41 takes any number of box passes; the reference itself only uses
+ * n = 3, scale_space.cpp:186): n in 1..16 passes of the given odd widths in 3..11. */
+int rebvio_hip_smooth_n(rebvio_hip_ctx* ctx, const float* img_host, const int* widths, int n, float* out_host);
 
 /* EdgeMap::rotateKeylines (edge_map.cpp:58-71); R row-major 3x3. */
 int rebvio_hip_rotate(rebvio_hip_ctx* ctx, rebvio_hip_map* m, const float R[9]);

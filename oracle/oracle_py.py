@@ -118,6 +118,7 @@ def lib(path: str | None = None):
         "orc_calculate_fj": (C.c_float, [vp, C.c_int, fp, fp, vp, C.c_float, C.c_float, ip, fp]),
         "orc_update_inverse_depth_arlu": (None, [vp, vp, fp]),
         "orc_smooth": (None, [vp, fp, C.c_float, C.c_int, fp, ip]),
+        "orc_smooth_n": (None, [vp, fp, C.c_float, C.c_int, fp, ip]),
         "orc_run_stream": (C.c_double, [vp, C.POINTER(C.c_uint8), ip, C.c_int, C.c_int, ip, ip, fp]),
         "orc_run_stream_ex": (C.c_double, [vp, C.POINTER(C.c_uint8), ip, C.c_int, C.c_int, ip, ip, fp, C.POINTER(C.c_double)]),
         "orc_stage_seconds": (None, [vp, C.POINTER(C.c_double), C.c_int]),
@@ -303,9 +304,12 @@ class Oracle:
     def smooth(self, img, sigma, n=3):
         img, pi = _f(img)
         out = np.empty((self.rows, self.cols), np.float32)
-        w = (C.c_int * 3)()
-        self.L.orc_smooth(self.h, pi, sigma, n, out.ctypes.data_as(C.POINTER(C.c_float)), w)
-        return out, list(w)
+        w = (C.c_int * max(n, 3))()
+        if n == 3:
+            self.L.orc_smooth(self.h, pi, sigma, n, out.ctypes.data_as(C.POINTER(C.c_float)), w)
+        else:
+            self.L.orc_smooth_n(self.h, pi, sigma, n, out.ctypes.data_as(C.POINTER(C.c_float)), w)
+        return out, list(w)[:n]
 
     def update_inverse_depth(self, vel):
         vel, pv = _f(vel)

@@ -670,8 +670,8 @@ inline int sab_gauss_newton(const SabCfg& cfg, float X[7], int iter_max) {
 struct BoxGaussian {
   int n = 3;
   float sigma = 0, sigma_true = 0;
-  int widths[3] = {0, 0, 0};
-  std::vector<float> divisors[3];
+  std::vector<int> widths;                   // [n] (the reference allocates new int[n_], scale_space.cpp:17)
+  std::vector<std::vector<float>> divisors;  // [n]
 };
 
 // FastGaussian::precomputeDivisors (scale_space.cpp:130-171)
@@ -702,6 +702,8 @@ void make_divisors(int rows, int cols, int d, std::vector<float>& div) {
 void make_filter(BoxGaussian& f, int rows, int cols, float sigma, int n) {
   f.n = n;
   f.sigma = sigma;
+  f.widths.assign((size_t)n, 0);
+  f.divisors.assign((size_t)n, std::vector<float>());
   float w_ideal = sqrt(12.0 * sigma * sigma / float(n + 1));
   int w_l = int(w_ideal);
   if (int(w_l / 2) * 2 == w_l) --w_l;
@@ -1907,7 +1909,18 @@ void orc_smooth(orc_ctx* c, const float* img, float sigma, int n, float* out, in
   smooth(c, f, img, o);
   std::memcpy(out, o.data(), o.size() * sizeof(float));
   if (widths_out)
-    for (int i = 0; i < 3; ++i) widths_out[i] = f.widths[i];
+    for (int i = 0; i < 3; ++i) widths_out[i] = i < n ? f.widths[i] : 0;
+}
+
+void orc_smooth_n(orc_ctx* c, const float* img, float sigma, int n, float* out, int* widths_out) {
+  // the same for any number of box passes (scale_space.cpp:14-41 takes n; the reference itself constructs n = 3 only)
+  BoxGaussian f;
+  make_filter(f, c->p.rows, c->p.cols, sigma, n);
+  std::vector<float> o;
+  smooth(c, f, img, o);
+  std::memcpy(out, o.data(), o.size() * sizeof(float));
+  if (widths_out)
+    for (int i = 0; i < n; ++i) widths_out[i] = f.widths[i];
 }
 
 void orc_stage_seconds(orc_ctx* c, double out[6], int reset) {

@@ -136,6 +136,7 @@ float orc_calculate_fj(orc_ctx* c, int f_inx, float* df_dx, float* df_dy, orc_ke
                        float* fi);
 void orc_update_inverse_depth_arlu(orc_ctx* c, orc_keyline* keyline, const float vel[3]);
 void orc_smooth(orc_ctx* c, const float* img, float sigma, int n, float* out, int widths_out[3]);
+void orc_smooth_n(orc_ctx* c, const float* img, float sigma, int n, float* out, int* widths_out /* [n] */);
 
 /* Persistent gyro-bias state of the glue (imu.hpp:180-183): reset to the reference's initial values */
 void orc_reset_state(orc_ctx* c);

@@ -82,6 +82,7 @@ SIGNATURES = {
     "rebvio_hip_map_distance_field": (C.c_int, [_vp, _ip, _ip]),
     "rebvio_hip_search_match": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, C.c_float, _ip]),
     "rebvio_hip_smooth": (C.c_int, [_vp, _fp, _ip, _fp]),
+    "rebvio_hip_smooth_n": (C.c_int, [_vp, _fp, _ip, C.c_int, _fp]),
     "rebvio_hip_rotate": (C.c_int, [_vp, _vp, _fp]),
     "rebvio_hip_quantile": (C.c_int, [_vp, _vp, C.c_float, C.c_int, _fp]),
     "rebvio_hip_try_vel": (C.c_int, [_vp, _vp, _fp, C.c_float, _fp, _fp]),
@@ -273,11 +274,16 @@ class Context:
         _chk(lib().rebvio_hip_scale_space(self.h, pi, *[o.ctypes.data_as(_fp) for o in outs]))
         return dict(scale0=outs[0], scale1=outs[1], dog=outs[2], mag=outs[3])
 
-    def smooth(self, img, widths3):
+    def smooth(self, img, widths):
+        """FastGaussian::smooth with the given box widths (three for the reference's own filters, any count for its general n)."""
         img, pi = _f(img)
-        w = (C.c_int * 3)(*[int(v) for v in widths3])
+        n = len(widths)
+        w = (C.c_int * n)(*[int(v) for v in widths])
         out = np.empty((self.rows, self.cols), np.float32)
-        _chk(lib().rebvio_hip_smooth(self.h, pi, w, out.ctypes.data_as(_fp)))
+        if n == 3:
+            _chk(lib().rebvio_hip_smooth(self.h, pi, w, out.ctypes.data_as(_fp)))
+        else:
+            _chk(lib().rebvio_hip_smooth_n(self.h, pi, w, n, out.ctypes.data_as(_fp)))
         return out
 
     def detect(self, img, ts_us=0) -> Map:

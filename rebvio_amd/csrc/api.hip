@@ -1460,10 +1460,11 @@ int rebvio_hip_search_match(rebvio_hip_ctx* c, rebvio_hip_map* searched, const r
   return 0;
 }
 
-int rebvio_hip_smooth(rebvio_hip_ctx* c, const float* img, const int widths3[3], float* out) {
+int rebvio_hip_smooth_n(rebvio_hip_ctx* c, const float* img, const int* widths, int n, float* out) {
   HIPCHK(hipSetDevice(c->device));
-  for (int k = 0; k < 3; ++k)
-    if (widths3[k] < 3 || widths3[k] > 11 || (widths3[k] & 1) == 0) return fail_msg("smooth: box widths must be odd and in 3..11", -3);
+  if (n < 1 || n > 16) return fail_msg("smooth: 1..16 box passes", -3);
+  for (int k = 0; k < n; ++k)
+    if (widths[k] < 3 || widths[k] > 11 || (widths[k] & 1) == 0) return fail_msg("smooth: box widths must be odd and in 3..11", -3);
   const size_t nb = (size_t)c->P.rows * c->P.cols * sizeof(float);
   if (!c->diag0) {
     HIPCHK(hipMalloc(&c->diag0, nb));
@@ -1475,15 +1476,14 @@ int rebvio_hip_smooth(rebvio_hip_ctx* c, const float* img, const int widths3[3],
   ScaleBufs sb = c->sb;
   sb.scale0 = c->diag0;
   sb.scale1 = c->diag1;
-  int w[2][3];
-  for (int f = 0; f < 2; ++f)
-    for (int k = 0; k < 3; ++k) w[f][k] = widths3[k];
-  launch_scale_space(c->s_det, c->K, c->img_dev, 0, sb, w, c->db.rowcount);  // both filter slots run the same box widths
+  launch_smooth_n(c->s_det, c->K, c->img_dev, sb, widths, n, c->db.rowcount);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, c->diag0, nb, hipMemcpyDeviceToHost, c->s_det));
   HIPCHK(hipStreamSynchronize(c->s_det));
   return 0;
 }
+
+int rebvio_hip_smooth(rebvio_hip_ctx* c, const float* img, const int widths3[3], float* out) { return rebvio_hip_smooth_n(c, img, widths3, 3, out); }
 
 int rebvio_hip_rotate(rebvio_hip_ctx* c, rebvio_hip_map* m, const float R[9]) {
   HIPCHK(hipSetDevice(c->device));

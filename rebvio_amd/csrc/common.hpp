@@ -148,6 +148,7 @@ void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, co
 void launch_copy_from_pinned(hipStream_t s, const void* src_pinned, void* dst_dev, size_t bytes);
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
                         const int widths[2][3], int* rowcount_to_zero, int part = 3);
+void launch_smooth_n(hipStream_t s, const KParams& p, const float* img, const ScaleBufs& sb, const int* widths, int n, int* rowcount_to_zero);
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
                      const DetState* det_in, DetState* det_out, const MapState* prev_st);
 // Tile grid of the keyline-driven distance-field build (shared by the binning pass in k_join_edges and the tile kernel).

@@ -1463,6 +1463,34 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
 #undef RH_COLSCAN
 }
 
+// FastGaussian(camera, sigma, n).smooth for any number of box passes (scale_space.cpp:173-182): createIntegralImage, then n - 1
+// times average + createIntegralImage, then the last average - the detector's kernels with ONE filter slot (grids of height 1)
+// and k_dog_mag as the last average (its scale0 output; DoG and gradient go to the scratch buffers and are ignored).
+void launch_smooth_n(hipStream_t s, const KParams& p, const float* img, const ScaleBufs& sb, const int* widths, int n, int* rowcount_to_zero) {
+  const int R = p.rows, C = p.cols;
+  const int Cp = (C + 3) & ~3;
+  const int ldw = lds_pitch(Cp);
+  const size_t shm = (size_t)kStrip * ldw * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowscan<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_colscan), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const dim3 g1(div_up(R, kStrip), 1), c1(div_up(Cp, kColStrip), 1);
+  const int ldh = lds_pitch(R + (4 - R % 4) % 4);
+  const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
+  float* cur = sb.a[0];
+  float* other = sb.b[0];
+  RH_LAUNCH(k_rowscan<1>, g1, dim3(256), shm, s, (const void*)img, (const void*)img, cur, cur, R, C, 0, 0, ldw);
+  RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, cur, cur, R, Cp, ldh);
+  for (int i = 0; i + 1 < n; ++i) {
+    RH_LAUNCH(k_rowscan<2>, g1, dim3(256), shm, s, (const void*)cur, (const void*)cur, other, other, R, C, widths[i], widths[i], ldw);
+    RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, other, other, R, Cp, ldh);
+    std::swap(cur, other);
+  }
+  const dim3 gt(div_up(C, 64), div_up(R, kTileRowsSingle));
+  RH_LAUNCH(k_dog_mag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)cur, (const float*)cur, widths[n - 1], widths[n - 1], sb.dog, sb.mag,
+            sb.scale0, sb.scale1, R, C, rowcount_to_zero);
+}
+
 // ---- batched launchers (lane = blockIdx.z): the same grids with a third dimension ------------------------------------------
 void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
                           const int widths[2][3], bool lens) {

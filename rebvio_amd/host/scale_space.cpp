@@ -43,9 +43,15 @@ std::vector<float> dense(const cv::Mat& m) {
 FastGaussian::FastGaussian(rebvio::Camera::SharedPtr cam, types::Float sigma, int n)
     : n_(n), sigma_(sigma), sigma_true_(0), widths_(nullptr), divisors_(nullptr), camera_(cam),
       session_(backend::Session::forCamera(*cam)) {
-  if (n != 3) throw std::invalid_argument("rebvio::FastGaussian: the gfx950 backend runs exactly three box passes (n == 3)");
+  if (n < 1 || n > 16) throw std::invalid_argument("rebvio::FastGaussian: 1..16 box passes");
   widths_ = new int[n_];
   hm::kovesi_widths(sigma_, n_, widths_, &sigma_true_);
+  for (int i = 0; i < n_; ++i)
+    if (widths_[i] < 3 || widths_[i] > 11) {
+      delete[] widths_;
+      widths_ = nullptr;
+      throw std::invalid_argument("rebvio::FastGaussian: sigma / n ask for a box width outside 3..11 (the device kernels' tile halo)");
+    }
   divisors_ = new cv::Mat[n_];
   for (int i = 0; i < n_; ++i) divisors_[i] = reciprocal_box_areas((int)cam->rows_, (int)cam->cols_, widths_[i]);
 }
@@ -59,7 +65,7 @@ cv::Mat FastGaussian::smooth(cv::Mat& image) {
   require_f32(image, *camera_, "FastGaussian::smooth: CV_32FC1 image of the camera's size expected");
   const std::vector<float> in = dense(image);
   cv::Mat out((int)camera_->rows_, (int)camera_->cols_, CV_32FC1);
-  check("rebvio_hip_smooth", rebvio_hip_smooth(session_->ctx(), in.data(), widths_, out.ptr<float>(0)));
+  check("rebvio_hip_smooth_n", rebvio_hip_smooth_n(session_->ctx(), in.data(), widths_, n_, out.ptr<float>(0)));
   return out;
 }
 

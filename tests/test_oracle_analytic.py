@@ -39,6 +39,30 @@ def test_kovesi_widths(orc_mod):
     assert [orc.L.orc_filter_width(orc.h, 1, k) for k in range(3)] == [9, 9, 9]  # sqrt(12) * 1.2599
 
 
+@pytest.mark.parametrize("sigma,n", [(3.56359, 1), (3.56359, 2), (2.2, 4), (3.0, 5)])
+def test_box_filter_with_n_passes_approximates_the_gaussian(orc_mod, sigma, n):
+    """FastGaussian for n other than 3 (scale_space.cpp:14-41): Kovesi's widths give the stated sigma_true, the smoothed constant
+    stays constant, and the filter's response to an impulse has the variance n passes of those boxes must have:
+    sum((w^2 - 1) / 12) per axis - an independent statement of what the n-pass loop of smooth() computes."""
+    h = w = 96
+    orc = orc_mod.Oracle(orc_mod.default_params(h, w))
+    flat, widths = orc.smooth(np.full((h, w), 64.0, np.float32), sigma, n)
+    assert len(widths) == n and all(x % 2 == 1 for x in widths)
+    assert np.abs(flat - 64.0).max() <= 64.0 * n * 3e-7
+    var_expected = sum((x * x - 1) / 12.0 for x in widths)
+    if n >= 3:  # (for fewer passes the reference's m = round(...) leaves [0, n] and every pass gets the wider box)
+        assert abs(var_expected - sigma * sigma) <= 0.6 * sigma  # Kovesi: within the rounding of m box widths
+    img = np.zeros((h, w), np.float32)
+    img[h // 2, w // 2] = 4096.0
+    out, _ = orc.smooth(img, sigma, n)
+    out = out.astype(np.float64)
+    assert abs(out.sum() - 4096.0) <= 4096.0 * 1e-5
+    yy, xx = np.mgrid[0:h, 0:w]
+    for axis, c in ((xx, w // 2), (yy, h // 2)):
+        var = ((axis - c) ** 2 * out).sum() / out.sum()
+        assert abs(var - var_expected) <= 1e-3 * var_expected, (var, var_expected, widths)
+
+
 def test_constant_image_has_no_keylines(orc_mod):
     orc = orc_mod.Oracle(orc_mod.default_params(96, 128))
     m = orc.detect(np.full((96, 128), 300.0, np.float32))

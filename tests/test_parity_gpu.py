@@ -116,6 +116,23 @@ def test_scale_space_bit_exact(orc_mod, B, c2_stream):
             assert _bits_equal(so[k], sg[k]), f"{k} differs in {(so[k] != sg[k]).sum()} pixels"
 
 
+@pytest.mark.parametrize("sigma,n", [(3.56359, 1), (3.56359, 2), (2.2, 4), (3.0, 5), (4.49, 3)])
+def test_fast_gaussian_with_any_number_of_box_passes(orc_mod, B, c2_stream, sigma, n):
+    """FastGaussian(camera, sigma, n).smooth for n other than the 3 the reference itself constructs (scale_space.cpp:14-41 takes
+    any n, :186 uses 3): createIntegralImage, n - 1 x (average + createIntegralImage), average - bit-exact against the
+    restatement, whose Kovesi widths the device entry is handed."""
+    frames, cam = c2_stream
+    orc = orc_mod.Oracle(params_for(orc_mod, cam))
+    ctx = B.Context(params_for(B, cam))
+    img = frames[2].astype(np.float32) * np.float32(3.0)
+    so, widths = orc.smooth(img, sigma, n)
+    assert len(widths) == n and all(3 <= w <= 11 and w % 2 == 1 for w in widths), widths
+    sg = ctx.smooth(img, widths)
+    assert _bits_equal(so, sg), f"n = {n}, widths {widths}: {(so != sg).sum()} pixels differ"
+    with pytest.raises(B.HipError, match="3..11"):
+        ctx.smooth(img, [13] * n)
+
+
 @pytest.mark.parametrize("width", [2048, 2044, 1300])
 def test_first_row_pass_is_exact_on_wide_bright_frames(orc_mod, B, width):
     """The first row pass of a MONO8 frame is a parallel prefix (its partial sums are integers below 2^24, any order gives

@@ -1,5 +1,3 @@
-for rep in 1 2 3; do
-for v in new old; do
-if [ $v = old ]; then export REBVIO_HIP_BATCH_LANE_READY=1; else unset REBVIO_HIP_BATCH_LANE_READY; fi
-echo -n "$v: "; timeout -k 10 120 python3 tools/batch_rate.py 8 1200 800 2>&1 | grep -h "lanes 8"
-done; done
+set -o pipefail
+O=gpurun_out/s2l; mkdir -p $O
+timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "fast_gaussian or scale_space or public_cpp or host_api" > $O/gputests.log 2>&1; echo "pytest rc=$?"; tail -5 $O/gputests.log
