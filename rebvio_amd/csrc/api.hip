@@ -320,6 +320,7 @@ struct rebvio_hip_ctx {
   // host shadow of the information matrix W_Bg the DEVICE glue works on (streaming driver, glue_params_pre)
   hm::M3 wbg_shadow{};
   bool wbg_shadow_valid = false;
+  bool fuse_dog = true;  // REBVIO_HIP_FUSE_DOG=0: k_dog_mag + k_keyline_flag instead of k_keyline_flag_ii
   bool gyro_pre_on = true;  // REBVIO_HIP_GYRO_PRE=0: the device forms the gyroBiasCorrection matrices itself
   // REBVIO_HIP_DETECT_WORKER=1: a worker thread launches the streaming driver's detect kernels. Off by default since round 3: the
   // runtime calls of two threads largely serialise AND slow each other down (detect launches 36 us per frame alone, 65 us beside
@@ -550,10 +551,11 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   HIPCHK(finish_stop_event(c->s_det, c->ev_scan[b]));
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
   HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
-  launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2);
+  launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2, c->fuse_dog);
   if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done_ref ? m->done_ref : m->done, 0));
   arm_stop_event(c->s_key, c->ev_flag[b]);
-  launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st);
+  const int fw[2] = {c->widths[0][2], c->widths[1][2]};
+  launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st, c->fuse_dog ? fw : nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(finish_stop_event(c->s_key, c->ev_flag[b]));  // (after join: coarser than needed, same stream order)
   c->ev_flag_used[b] = true;
@@ -1090,6 +1092,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   c->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
   if (const char* e = std::getenv("REBVIO_HIP_DETECT_WORKER")) c->det_worker = e[0] != '0';
   if (const char* e = std::getenv("REBVIO_HIP_GYRO_PRE")) c->gyro_pre_on = e[0] != '0';
+  if (const char* e = std::getenv("REBVIO_HIP_FUSE_DOG")) c->fuse_dog = e[0] != '0';
   HIPCHK(hipDeviceSynchronize());
   guard.c = nullptr;
   *out = c;

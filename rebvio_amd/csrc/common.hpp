@@ -147,10 +147,10 @@ void upload_tables(const float* recip128, const float* pinv75);
 void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, const int2* map, float* dst);
 void launch_copy_from_pinned(hipStream_t s, const void* src_pinned, void* dst_dev, size_t bytes);
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
-                        const int widths[2][3], int* rowcount_to_zero, int part = 3);
+                        const int widths[2][3], int* rowcount_to_zero, int part = 3, bool fuse_dog = false);
 void launch_smooth_n(hipStream_t s, const KParams& p, const float* img, const ScaleBufs& sb, const int* widths, int n, int* rowcount_to_zero);
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
-                     const DetState* det_in, DetState* det_out, const MapState* prev_st);
+                     const DetState* det_in, DetState* det_out, const MapState* prev_st, const int* fuse_widths = nullptr);
 // Tile grid of the keyline-driven distance-field build (shared by the binning pass in k_join_edges and the tile kernel).
 struct DfGrid {
   int T, ntx, nty;

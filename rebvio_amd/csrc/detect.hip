@@ -395,8 +395,13 @@ __global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict_
 // Narrow strips spread the staging traffic over many CUs. No global-memory latency sits on the chain.
 constexpr int kColStrip = 16;
 
-__device__ __forceinline__ void colscan_body(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh) {
+// zero != null: the first workgroup also clears zero[0 .. nzero) - the per-row candidate counters of the frame, for the fused
+// candidate kernel behind the last column pass (k_keyline_flag_ii; k_dog_mag does it on the unfused path)
+__device__ __forceinline__ void colscan_body(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C /* pitch */, int ldh,
+                                             int* __restrict__ zero = nullptr, int nzero = 0) {
   const uint2 vb = xcd_band_block();  // tile coordinates: contiguous bands of tiles per XCD (see xcd_band_block)
+  if (zero && vb.x == 0 && vb.y == 0)
+    for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
   extern __shared__ float4 smem4[];
   float* tile = reinterpret_cast<float*>(smem4);  // [kColStrip][ldh]
   float* __restrict__ buf = vb.y ? buf1 : buf0;
@@ -501,13 +506,15 @@ __device__ __forceinline__ void colscan_body(float* __restrict__ buf0, float* __
   }
 }
 
-__global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh) {
-  colscan_body(buf0, buf1, R, C, ldh);
+__global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float* __restrict__ buf1, int R, int C, int ldh, int* __restrict__ zero,
+                                                 int nzero) {
+  colscan_body(buf0, buf1, R, C, ldh, zero, nzero);
 }
-// batched form. which 0: a[0] alone; 1: b[0], b[1]; 2: a[0], a[1]
-__global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh) {
+// batched form. which 0: a[0] alone; 1: b[0], b[1]; 2: a[0], a[1]. zero_parity >= 0: clears the lane's row counters of that parity
+__global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh, int zero_parity) {
   const LaneStatic& L = ls[lane0 + blockIdx.z];
-  colscan_body(which == 1 ? gptr(L.sb[0]) : gptr(L.sa[0]), which == 0 ? gptr(L.sa[0]) : (which == 1 ? gptr(L.sb[1]) : gptr(L.sa[1])), R, C, ldh);
+  colscan_body(which == 1 ? gptr(L.sb[0]) : gptr(L.sa[0]), which == 0 ? gptr(L.sa[0]) : (which == 1 ? gptr(L.sb[1]) : gptr(L.sa[1])), R, C, ldh,
+               zero_parity >= 0 ? gptr(L.rowcount2[zero_parity]) : nullptr, R);
 }
 
 // ---- last box pass of both filters fused with DoG and squared gradient (scale_space.cpp:210-233) ------
@@ -739,6 +746,149 @@ __global__ __launch_bounds__(256) void k_keyline_flag_b(KParams p, const LaneSta
   keyline_flag_body<16>(gptr(L.dog2[d.parity]), gptr(L.mag2[d.parity]), p, gptr(L.det) + d.det_in, gptr(L.stash), gptr(L.bits), gptr(L.rowcount2[d.parity]));
 }
 
+// ---- candidate test + plane fit straight from the integral images: the last box pass, DoG and squared gradient of the tile
+// (k_dog_mag) are formed in LDS instead of travelling through two per-pixel arrays and a launch of their own ----------------
+// Tile = kFlagRows x 64 pixels; DoG is needed with a two-pixel ring (5 x 5 plane fit), the scale-0 average with the same ring
+// (its 3 x 3 gradient stencil sits inside it): both box averages are evaluated on (kFlagRows + 4) x 68 pixels from the two
+// integral-image tiles staged as in dog_mag_body - the same corners, operand order and reciprocals, hence the same DoG and
+// gradient bits as the unfused kernels, and from there on keyline_flag_body's statements.
+template <int kFlagRows>
+__device__ __forceinline__ void keyline_flag_ii_body(const float* __restrict__ II0, const float* __restrict__ II1, int d0, int d1, KParams p,
+                                                     const DetState* __restrict__ det_in, float4* __restrict__ stash,
+                                                     unsigned long long* __restrict__ bits, int* __restrict__ rowcount) {
+  const uint2 vb = xcd_band_block();
+  constexpr int kReg = kFlagRows + 4;              // rows of the DoG region
+  constexpr int kTRows = kReg + kDogMaxD;          // integral-image tile: kReg + 2 h + 1 rows, h <= 5
+  constexpr int kPitch = 68 + kDogMaxD + 1;        // 80 >= 68 + 2 h + 1 columns
+  __shared__ float t0[kTRows * kPitch];
+  __shared__ float t1[kTRows * kPitch];
+  __shared__ float sa[kReg][68];  // scale-0 averages
+  __shared__ float sd[kReg][68];  // DoG
+  const int R = p.rows, C = p.cols;
+  const int ld = (C + 3) & ~3;  // pitch of the integral images
+  const int c0 = vb.x * 64, r0 = vb.y * kFlagRows;
+  const int h0 = d0 >> 1, h1 = d1 >> 1;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  // region rows r0-2 .. r0+kFlagRows+1, columns c0-2 .. c0+65 -> integral rows / columns from (r0-2) - h - 1, (c0-2) - h - 1
+  const int ro0 = r0 - 3 - h0, co0 = c0 - 3 - h0, nr0 = kReg + 2 * h0 + 1, nc0 = 68 + 2 * h0 + 1;
+  const int ro1 = r0 - 3 - h1, co1 = c0 - 3 - h1, nr1 = kReg + 2 * h1 + 1, nc1 = 68 + 2 * h1 + 1;
+  constexpr int kIt = (kTRows + 3) / 4;  // tile rows per wave (every load of both tiles in flight before the first LDS write)
+  float va[kIt], vb2[kIt], wa[kIt], wb[kIt];
+  const int ca0 = min(max(co0 + tx, 0), C - 1), cb0 = min(max(co0 + tx + 64, 0), C - 1);
+  const int ca1 = min(max(co1 + tx, 0), C - 1), cb1 = min(max(co1 + tx + 64, 0), C - 1);
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    const int lr = ty + 4 * k;
+    const float* __restrict__ row0 = II0 + (size_t)min(max(ro0 + lr, 0), R - 1) * ld;  // (clamped positions are never used)
+    const float* __restrict__ row1 = II1 + (size_t)min(max(ro1 + lr, 0), R - 1) * ld;
+    va[k] = row0[ca0];
+    vb2[k] = row0[cb0];
+    wa[k] = row1[ca1];
+    wb[k] = row1[cb1];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    const int lr = ty + 4 * k;
+    if (lr < nr0) {
+      t0[lr * kPitch + tx] = va[k];
+      if (tx + 64 < nc0) t0[lr * kPitch + tx + 64] = vb2[k];
+    }
+    if (lr < nr1) {
+      t1[lr * kPitch + tx] = wa[k];
+      if (tx + 64 < nc1) t1[lr * kPitch + tx + 64] = wb[k];
+    }
+  }
+  __syncthreads();
+  // (pointer arithmetic only: box_avg indexes [r * pitch + c] with image coordinates)
+  const float* v0 = t0 - ((ptrdiff_t)ro0 * kPitch + co0);
+  const float* v1 = t1 - ((ptrdiff_t)ro1 * kPitch + co1);
+  // a region none of whose box sums touches the image border takes box_avg's interior case directly (see dog_mag_body)
+  const bool in0 = r0 - 2 >= h0 + 1 && r0 + kFlagRows + 1 < R - h0 && c0 - 2 >= h0 + 1 && c0 + 65 < C - h0;
+  const bool in1 = r0 - 2 >= h1 + 1 && r0 + kFlagRows + 1 < R - h1 && c0 - 2 >= h1 + 1 && c0 + 65 < C - h1;
+  const float rc0 = c_recip[d0 * d0], rc1 = c_recip[d1 * d1];
+  for (int lr = ty; lr < kReg; lr += 4) {
+    const int r = r0 + lr - 2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int lc = tx + 64 * half;
+      if (lc >= 68) break;
+      const int c = c0 + lc - 2;
+      float a0 = 0.0f, dg = 0.0f;
+      if (in0 && in1) {
+        const float* q1 = v0 + (r + h0) * kPitch + c;
+        const float* q2 = v0 + (r - h0 - 1) * kPitch + c;
+        a0 = (((q1[h0] - q1[-h0 - 1]) - q2[h0]) + q2[-h0 - 1]) * rc0;
+        const float* s1 = v1 + (r + h1) * kPitch + c;
+        const float* s2 = v1 + (r - h1 - 1) * kPitch + c;
+        const float a1 = (((s1[h1] - s1[-h1 - 1]) - s2[h1]) + s2[-h1 - 1]) * rc1;
+        dg = a1 - a0;
+      } else if (r >= 0 && r < R && c >= 0 && c < C) {
+        a0 = box_avg(v0, r, c, d0, R, C, kPitch);
+        dg = box_avg(v1, r, c, d1, R, C, kPitch) - a0;
+      }
+      sa[lr][lc] = a0;
+      sd[lr][lc] = dg;
+    }
+  }
+  __syncthreads();
+  const int c = c0 + tx;
+  const float thr = servo_threshold(p, *det_in);
+  const float pn_threshold = float((2.0 * 2 + 1.0) * (2.0 * 2 + 1.0)) * p.pos_neg_threshold;
+  const float gradient_threshold_squared = (thr * kMaxImageValue * p.dog_threshold) * (thr * kMaxImageValue * p.dog_threshold);
+  const float mag_threshold = (thr * kMaxImageValue) * (thr * kMaxImageValue);
+#pragma unroll
+  for (int k = 0; k < kFlagRows / 4; ++k) {
+    const int lr = ty + 4 * k, r = r0 + lr;
+    if (r >= R) break;  // (whole wave)
+    bool cand = false;
+    float4 fit = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= 2 && r < R - 2 && c >= 2 && c < C - 2) {
+      // calculateGradientMagnitude (scale_space.cpp:221-232) of this pixel
+      const float dx = sa[lr + 2][tx + 3] - sa[lr + 2][tx + 1];
+      const float dy = sa[lr + 3][tx + 2] - sa[lr + 1][tx + 2];
+      const float mg = dx * dx + dy * dy;
+      if (!(mg < mag_threshold)) {
+        int pn = 0;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 25; ++q) {
+          const float y = sd[lr + q / 5][tx + q % 5];
+          pn = (y > 0.0f) ? pn + 1 : pn - 1;
+          s0 += c_pinv[q] * y;
+          s1 += c_pinv[25 + q] * y;
+          s2 += c_pinv[50 + q] * y;
+        }
+        if (!(fabsf((float)pn) > pn_threshold)) {
+          const float g2 = s0 * s0 + s1 * s1;
+          const float tmp = s2 / g2;
+          const float xs = -s0 * tmp;
+          const float ys = -s1 * tmp;
+          if (!(fabsf(xs) > 0.5f || fabsf(ys) > 0.5f)) {
+            if (!(g2 < gradient_threshold_squared)) {
+              cand = true;
+              fit = make_float4(s0, s1, xs, ys);
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long b = __ballot(cand);
+    if (c < C && cand) stash[(size_t)r * C + c] = fit;
+    if (tx == 0) {
+      bits[(size_t)r * p.nseg + vb.x] = b;
+      const int n = __popcll(b);
+      if (n) atomicAdd(&rowcount[r], n);
+    }
+  }
+}
+
+template <int TR>
+__global__ __launch_bounds__(256) void k_keyline_flag_ii(const float* __restrict__ II0, const float* __restrict__ II1, int d0, int d1, KParams p,
+                                                         const DetState* __restrict__ det_in, float4* __restrict__ stash,
+                                                         unsigned long long* __restrict__ bits, int* __restrict__ rowcount) {
+  keyline_flag_ii_body<TR>(II0, II1, d0, d1, p, det_in, stash, bits, rowcount);
+}
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1416,7 +1566,7 @@ void launch_front_end_u8(hipStream_t s, const KParams& p, const uint8_t* src, co
 // part: 1 = everything up to the row pass of the third box filter (five kernels), 2 = its column pass + k_dog_mag, 3 = both.
 // The streaming driver runs part 2 on the keyline stream: the scan stream is the busiest of a frame's three.
 void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int img_is_u8, const ScaleBufs& sb,
-                        const int widths[2][3], int* rowcount_to_zero, int part) {
+                        const int widths[2][3], int* rowcount_to_zero, int part, bool fuse_dog) {
   const int R = p.rows, C = p.cols;
   const int Cp = (C + 3) & ~3;  // pitch of the scan buffers sb.a / sb.b
   const int ldw_abs = lds_pitch(Cp);
@@ -1434,7 +1584,7 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
   const dim3 c1(div_up(Cp, kColStrip), 1), c2(div_up(Cp, kColStrip), 2);
   const int ldh = lds_pitch(R + (4 - R % 4) % 4);
   const size_t cshm = (size_t)ldh * kColStrip * sizeof(float);
-#define RH_COLSCAN(one, b0, b1) RH_LAUNCH(k_colscan, (one) ? c1 : c2, dim3(256), cshm, s, b0, b1, R, Cp, ldh)
+#define RH_COLSCAN(one, b0, b1) RH_LAUNCH(k_colscan, (one) ? c1 : c2, dim3(256), cshm, s, b0, b1, R, Cp, ldh, (int*)nullptr, 0)
   if (part & 1) {
     // pass 1: both filters share the integral image of the input (scale_space.cpp:175)
     if (img_is_u8)
@@ -1454,7 +1604,11 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
       RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R, C, widths[0][1],
                 widths[1][1], ldw);
   }
-  if (part & 2) {
+  if ((part & 2) && fuse_dog) {
+    // the candidate kernel forms the last box pass, DoG and gradient itself (launch_keylines, k_keyline_flag_ii): only the
+    // column pass remains here, and it clears the frame's row counters
+    RH_LAUNCH_LAST(k_colscan, c2, dim3(256), cshm, s, sb.a[0], sb.a[1], R, Cp, ldh, rowcount_to_zero, R);
+  } else if (part & 2) {
     RH_COLSCAN(false, sb.a[0], sb.a[1]);
     const dim3 gt(div_up(C, 64), div_up(R, kTileRowsSingle));
     RH_LAUNCH_LAST(k_dog_mag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2], widths[1][2], sb.dog,
@@ -1480,10 +1634,10 @@ void launch_smooth_n(hipStream_t s, const KParams& p, const float* img, const Sc
   float* cur = sb.a[0];
   float* other = sb.b[0];
   RH_LAUNCH(k_rowscan<1>, g1, dim3(256), shm, s, (const void*)img, (const void*)img, cur, cur, R, C, 0, 0, ldw);
-  RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, cur, cur, R, Cp, ldh);
+  RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, cur, cur, R, Cp, ldh, (int*)nullptr, 0);
   for (int i = 0; i + 1 < n; ++i) {
     RH_LAUNCH(k_rowscan<2>, g1, dim3(256), shm, s, (const void*)cur, (const void*)cur, other, other, R, C, widths[i], widths[i], ldw);
-    RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, other, other, R, Cp, ldh);
+    RH_LAUNCH(k_colscan, c1, dim3(256), cshm, s, other, other, R, Cp, ldh, (int*)nullptr, 0);
     std::swap(cur, other);
   }
   const dim3 gt(div_up(C, 64), div_up(R, kTileRowsSingle));
@@ -1512,7 +1666,7 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
   const unsigned z = (unsigned)lanes;
   const dim3 g1(div_up(R, kStrip), 1, z), g2(div_up(R, kStrip), 2, z);
   const dim3 c1(div_up(Cp, kColStrip), 1, z), c2(div_up(Cp, kColStrip), 2, z);
-#define RH_COLSCAN_B(which) RH_LAUNCH(k_colscan_b, (which) == 0 ? c1 : c2, dim3(256), cshm, s, ls, lane0, which, R, Cp, ldh)
+#define RH_COLSCAN_B(which) RH_LAUNCH(k_colscan_b, (which) == 0 ? c1 : c2, dim3(256), cshm, s, ls, lane0, which, R, Cp, ldh, -1)
   if (lens) {  // x3 + undistort of every lane's frame (rebvio.cpp:43-47), then the first pass on the fp32 result
     RH_LAUNCH(k_front_end_u8_b, dim3(div_up(R * C, 256), 1, z), dim3(256), 0, s, ls, dyn, lane0, R, C);
     RH_LAUNCH(k_rowscan_b<1>, g1, dim3(256), shm, s, ls, dyn, lane0, 3, R, C, 0, 0, ldw);
@@ -1561,11 +1715,15 @@ void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneSta
 }
 
 void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const DetectBufs& db, const MapDev& m,
-                     const DetState* det_in, DetState* det_out, const MapState* prev_st) {
+                     const DetState* det_in, DetState* det_out, const MapState* prev_st, const int* fuse_widths) {
   const DfGrid dg = df_grid(p.rows, p.cols);
   const dim3 gt(div_up(p.cols, 64), div_up(p.rows, kTileRowsSingle));
-  RH_LAUNCH(k_keyline_flag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in, db.stash, db.bits,
-            db.rowcount);
+  if (fuse_widths)  // sb.a[] hold the third filter pass's integral images (launch_scale_space with fuse_dog)
+    RH_LAUNCH(k_keyline_flag_ii<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], fuse_widths[0], fuse_widths[1], p,
+              det_in, db.stash, db.bits, db.rowcount);
+  else
+    RH_LAUNCH(k_keyline_flag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.dog, (const float*)sb.mag, p, det_in, db.stash, db.bits,
+              db.rowcount);
   RH_LAUNCH(k_keyline_emit<kTileRowsSingle>, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash, (const unsigned long long*)db.bits,
             (const int*)db.rowcount, det_in, det_out, prev_st, 0, dg.ntx * dg.nty);
   RH_LAUNCH_LAST(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, m, dg.T, dg.ntx, dg.nty);
