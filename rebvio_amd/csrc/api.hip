@@ -982,8 +982,10 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     HIPCHK(hipMalloc(&c->sb.a[f], Pp * sizeof(float)));
     HIPCHK(hipMalloc(&c->sb.b[f], Pp * sizeof(float)));
   }
-  HIPCHK(hipMalloc(&c->sb.dog, Pn * sizeof(float)));
-  HIPCHK(hipMalloc(&c->sb.mag, Pn * sizeof(float)));
+  // (DoG / gradient buffers have the size of an integral image, padded pitch: a batch's fused path keeps the third pass's
+  // integral images of a step parity in them)
+  HIPCHK(hipMalloc(&c->sb.dog, Pp * sizeof(float)));
+  HIPCHK(hipMalloc(&c->sb.mag, Pp * sizeof(float)));
   HIPCHK(hipMalloc(&c->db.stash, Pn * sizeof(float4)));
   HIPCHK(hipMalloc(&c->db.bits, (size_t)p->rows * K.nseg * sizeof(unsigned long long)));
   HIPCHK(hipMalloc(&c->db.rowcount, (size_t)p->rows * sizeof(int)));
@@ -1000,8 +1002,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     HIPCHK(hipMalloc(&c->sa2[1][f], Pp * sizeof(float)));
   }
   for (int i = 1; i < kDetPar; ++i) {
-    HIPCHK(hipMalloc(&c->dog2[i], Pn * sizeof(float)));
-    HIPCHK(hipMalloc(&c->mag2[i], Pn * sizeof(float)));
+    HIPCHK(hipMalloc(&c->dog2[i], Pp * sizeof(float)));
+    HIPCHK(hipMalloc(&c->mag2[i], Pp * sizeof(float)));
     HIPCHK(hipMalloc(&c->rowcount2[i], (size_t)p->rows * sizeof(int)));
     HIPCHK(hipMemset(c->rowcount2[i], 0, (size_t)p->rows * sizeof(int)));
   }
@@ -2423,6 +2425,7 @@ struct rebvio_hip_batch {
   bool dbg = false;
   std::atomic<uint64_t> t_det_ns{0};
   bool det_worker = true;  // REBVIO_HIP_DETECT_WORKER
+  bool fuse_dog = false;   // REBVIO_HIP_BATCH_FUSE_DOG=1
   double t_trk_enq = 0, t_slot_wait = 0;
   int dm_head_form = 0;   // REBVIO_HIP_BATCH_DM_HEAD: 0 by lane count, 1 thread per keyline, 2 eight lanes per keyline
   bool poisoned = false;  // a step failed half way (some lanes prepared, others not): every later call is refused
@@ -2481,12 +2484,17 @@ int batch_detect_launch(rebvio_hip_batch* b, const rebvio_hip_batch::DetStep& j)
   const int B = b->B, par = j.par;
   if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->st.s_det, b->ev_flag[par], 0));
   arm_stop_event(b->st.s_det, b->ev_scan[par]);
-  launch_scale_space_b(b->st.s_det, b->K, 0, B, b->ls_dev, j.dyn, b->lane[0]->widths, j.lens);
+  // the fused candidate kernel moves the last box pass from the scan stream to the keyline stream: measured SLOWER for batches
+  // (8 lanes 42.4 k -> 39.7 k frames/s, 4 lanes 32.9 k -> 32.2 k), like the single stream's other moves of scan work to the
+  // keyline stream - opt-in here (REBVIO_HIP_BATCH_FUSE_DOG=1), the default for one stream
+  const bool fuse = b->fuse_dog;
+  launch_scale_space_b(b->st.s_det, b->K, 0, B, b->ls_dev, j.dyn, b->lane[0]->widths, j.lens, fuse);
   HIPCHK(finish_stop_event(b->st.s_det, b->ev_scan[par]));
   HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan[par], 0));
   if (j.reuse_done) HIPCHK(hipStreamWaitEvent(b->st.s_key, j.reuse_done, 0));
   arm_stop_event(b->st.s_key, b->ev_flag[par]);
-  launch_keylines_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
+  const int fw[2] = {b->lane[0]->widths[0][2], b->lane[0]->widths[1][2]};
+  launch_keylines_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn, fuse ? fw : nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(finish_stop_event(b->st.s_key, b->ev_flag[par]));
   b->ev_flag_used[par] = true;
@@ -2753,6 +2761,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   b->lm_lanes_per_launch = lm_lanes_per_launch;
   b->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
   if (const char* e = std::getenv("REBVIO_HIP_DETECT_WORKER")) b->det_worker = e[0] != '0';
+  if (const char* e = std::getenv("REBVIO_HIP_BATCH_FUSE_DOG")) b->fuse_dog = e[0] == '1';
   struct Guard {
     rebvio_hip_batch* b;
     ~Guard() {

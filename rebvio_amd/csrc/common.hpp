@@ -385,8 +385,9 @@ __device__ __forceinline__ uint2 xcd_band_block() {
 
 #endif
 void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
-                          const int widths[2][3], bool lens);
-void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
+                          const int widths[2][3], bool lens, bool fuse_dog = false);
+void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
+                       const int* fuse_widths = nullptr);
 void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn);
 void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, int lanes_per_launch, const LaneStatic* ls, const MapDev* maptab,
                        const LaneDynB& dyn, int calls, int spec, const GlueParams& gp);

@@ -385,6 +385,15 @@ __global__ __launch_bounds__(256) void k_rowscan_b(const LaneStatic* __restrict_
   const void* s1 = first ? s0 : (stage == 1 ? (const void*)gptr(L.sa[0]) : (const void*)gptr(L.sb[1]));
   float* o0 = stage == 1 ? gptr(L.sb[0]) : gptr(L.sa[0]);
   float* o1 = first ? gptr(L.sa[0]) : (stage == 1 ? gptr(L.sb[1]) : gptr(L.sa[1]));
+  if (stage == 4) {  // stage 2 for the fused candidate kernel: that one reads the third pass's integral images on the keyline stream
+    // while this stream already scans the next step - they go to the step parity's DoG / gradient buffers, which the fused
+    // path does not use otherwise (same size, same hand-over events)
+    const int par = dyn.v[lane].parity;
+    s0 = gptr(L.sb[0]);
+    s1 = gptr(L.sb[1]);
+    o0 = gptr(L.dog2[par]);
+    o1 = gptr(L.mag2[par]);
+  }
   rowscan_body<MODE>(s0, s1, o0, o1, R, Cimg, d0, d1, ldw);
 }
 
@@ -513,6 +522,10 @@ __global__ __launch_bounds__(256) void k_colscan(float* __restrict__ buf0, float
 // batched form. which 0: a[0] alone; 1: b[0], b[1]; 2: a[0], a[1]. zero_parity >= 0: clears the lane's row counters of that parity
 __global__ __launch_bounds__(256) void k_colscan_b(const LaneStatic* __restrict__ ls, int lane0, int which, int R, int C, int ldh, int zero_parity) {
   const LaneStatic& L = ls[lane0 + blockIdx.z];
+  if (which == 3) {  // the third pass's images of the fused path (k_rowscan_b stage 4), row counters of the same parity cleared
+    colscan_body(gptr(L.dog2[zero_parity]), gptr(L.mag2[zero_parity]), R, C, ldh, gptr(L.rowcount2[zero_parity]), R);
+    return;
+  }
   colscan_body(which == 1 ? gptr(L.sb[0]) : gptr(L.sa[0]), which == 0 ? gptr(L.sa[0]) : (which == 1 ? gptr(L.sb[1]) : gptr(L.sa[1])), R, C, ldh,
                zero_parity >= 0 ? gptr(L.rowcount2[zero_parity]) : nullptr, R);
 }
@@ -889,6 +902,13 @@ __global__ __launch_bounds__(256) void k_keyline_flag_ii(const float* __restrict
                                                          unsigned long long* __restrict__ bits, int* __restrict__ rowcount) {
   keyline_flag_ii_body<TR>(II0, II1, d0, d1, p, det_in, stash, bits, rowcount);
 }
+__global__ __launch_bounds__(256) void k_keyline_flag_ii_b(KParams p, const LaneStatic* __restrict__ ls, LaneDynB dyn, int d0, int d1) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  keyline_flag_ii_body<16>(gptr(L.dog2[d.parity]), gptr(L.mag2[d.parity]), d0, d1, p, gptr(L.det) + d.det_in, gptr(L.stash), gptr(L.bits),
+                           gptr(L.rowcount2[d.parity]));
+}
+
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1647,7 +1667,7 @@ void launch_smooth_n(hipStream_t s, const KParams& p, const float* img, const Sc
 
 // ---- batched launchers (lane = blockIdx.z): the same grids with a third dimension ------------------------------------------
 void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes, const LaneStatic* ls, const LaneDynB& dyn,
-                          const int widths[2][3], bool lens) {
+                          const int widths[2][3], bool lens, bool fuse_dog) {
   const int R = p.rows, C = p.cols;
   const int Cp = (C + 3) & ~3;
   const int ldw_abs = lds_pitch(Cp);
@@ -1676,16 +1696,25 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
   RH_COLSCAN_B(0);
   RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 1, R, C, widths[0][0], widths[1][0], ldw);
   RH_COLSCAN_B(1);
+  if (fuse_dog) {  // k_keyline_flag_ii_b forms the last box pass, DoG and gradient itself (launch_keylines_b)
+    RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 4, R, C, widths[0][1], widths[1][1], ldw);
+    RH_LAUNCH_LAST(k_colscan_b, c2, dim3(256), cshm, s, ls, lane0, 3, R, Cp, ldh, (int)dyn.v[lane0].parity);
+    return;
+  }
   RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 2, R, C, widths[0][1], widths[1][1], ldw);
   RH_COLSCAN_B(2);
-#undef RH_COLSCAN_B
   RH_LAUNCH_LAST(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 16), z), dim3(64, 4), 0, s, ls, dyn, lane0, widths[0][2], widths[1][2], R, C);
+#undef RH_COLSCAN_B
 }
 
-void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn) {
+void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
+                       const int* fuse_widths) {
   const unsigned z = (unsigned)lanes;
   const DfGrid dg = df_grid(p.rows, p.cols);
-  RH_LAUNCH(k_keyline_flag_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, dyn);
+  if (fuse_widths)
+    RH_LAUNCH(k_keyline_flag_ii_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, dyn, fuse_widths[0], fuse_widths[1]);
+  else
+    RH_LAUNCH(k_keyline_flag_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, dyn);
   RH_LAUNCH(k_keyline_emit_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, maptab, dyn, 0, dg.ntx * dg.nty);
   RH_LAUNCH_LAST(k_join_edges_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, maptab, dyn, dg.T, dg.ntx,
             dg.nty);

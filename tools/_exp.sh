@@ -1,6 +1,5 @@
 set -o pipefail
-O=gpurun_out/s2n; mkdir -p $O
+O=gpurun_out/s2p; mkdir -p $O
 timeout -k 10 700 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/gputests.log
-for rep in 1 2; do for v in 1 0; do
-echo "fuse_dog=$v"; REBVIO_HIP_FUSE_DOG=$v REBVIO_HIP_DEBUG=1 timeout -k 10 120 python3 tools/short_window.py 20 40 2>&1 | grep -v amdgpu | tail -3
-done; done
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err && python3 -c "
+import json; d=json.loads(open('$O/bench_driver.json').read().strip().splitlines()[-1]); print('driver flags', d['value'], d['config'].get('long_window',{}).get('value'), d['config']['pcie_inclusive_fps'], d['config']['host_class_fps'], [(x['lanes'],x['value']) for x in d.get('streams_per_gpu',[])], d['cpu_baseline']['value'])"
