@@ -1017,7 +1017,12 @@ __device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const La
   ga.st_out = gptr(L.gstate) + ((d.gpar & 1) ^ 1);
   ga.rec = gptr(L.rec[d.slot]);
   ga.gd_copy = gptr(L.glue_dev) + d.slot;
-  ga.gp = gp;
+  // (only the scalars: a batch forms the gyroBiasCorrection matrices on the device - has_pre = 0 as a constant lets the compiler
+  // drop the by-value matrices; copying them put the whole struct into scratch memory, 280 bytes per lane of every workgroup)
+  ga.gp.frame_dt = gp.frame_dt;
+  ga.gp.gyro_std_dev = gp.gyro_std_dev;
+  ga.gp.gyro_bias_std_dev = gp.gyro_bias_std_dev;
+  ga.gp.has_pre = 0;
   return ga;
 }
 

@@ -1,5 +1,5 @@
-set -o pipefail
-O=gpurun_out/s2p; mkdir -p $O
-timeout -k 10 700 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/gputests.log
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err && python3 -c "
-import json; d=json.loads(open('$O/bench_driver.json').read().strip().splitlines()[-1]); print('driver flags', d['value'], d['config'].get('long_window',{}).get('value'), d['config']['pcie_inclusive_fps'], d['config']['host_class_fps'], [(x['lanes'],x['value']) for x in d.get('streams_per_gpu',[])], d['cpu_baseline']['value'])"
+for rep in 1 2 3; do
+echo -n "b8: "; timeout -k 10 120 python3 tools/batch_rate.py 8 1200 800 2>&1 | grep "lanes 8"
+echo -n "b4: "; timeout -k 10 120 python3 tools/batch_rate.py 4 1200 800 2>&1 | grep "lanes 4"
+done
+timeout -k 10 300 python -m pytest tests -m gpu -x -q -k "batch or lanes" 2>&1 | tail -2
