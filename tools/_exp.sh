@@ -1,5 +1,3 @@
-for rep in 1 2 3; do
-echo -n "b8: "; timeout -k 10 120 python3 tools/batch_rate.py 8 1200 800 2>&1 | grep "lanes 8"
-echo -n "b4: "; timeout -k 10 120 python3 tools/batch_rate.py 4 1200 800 2>&1 | grep "lanes 4"
+for m in spec seq; do
+echo "LM=$m"; REBVIO_HIP_LM=$m REBVIO_HIP_LM_STAMPS=1 timeout -k 10 120 python3 bench.py --no-cpu-baseline --lanes 0 --no-host-class --no-pcie --steps 600 2>&1 >/dev/null | grep "of which\|end of an LM"
 done
-timeout -k 10 300 python -m pytest tests -m gpu -x -q -k "batch or lanes" 2>&1 | tail -2
