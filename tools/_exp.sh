@@ -1,3 +1,5 @@
-for m in spec seq; do
-echo "LM=$m"; REBVIO_HIP_LM=$m REBVIO_HIP_LM_STAMPS=1 timeout -k 10 120 python3 bench.py --no-cpu-baseline --lanes 0 --no-host-class --no-pcie --steps 600 2>&1 >/dev/null | grep "of which\|end of an LM"
-done
+set -o pipefail
+O=gpurun_out/s2q; mkdir -p $O
+timeout -k 10 420 python3 tools/fuzz_parity.py --trials 400 --seed 47 > $O/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -4 $O/fuzz.txt
+timeout -k 10 200 python3 tools/stress_stream.py 100 > $O/soak.txt 2>&1; echo "soak rc=$?"; tail -3 $O/soak.txt
+timeout -k 10 200 python3 tools/stress_stream.py 60 1 > $O/soak_jumps.txt 2>&1; echo "soak jumps rc=$?"; tail -3 $O/soak_jumps.txt
