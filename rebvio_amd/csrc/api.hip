@@ -245,8 +245,11 @@ struct rebvio_hip_ctx {
   unsigned long long* lm_xch = nullptr;
   unsigned lm_tag_base = 0;
   bool lm_spec = true;          // the speculative kernel may be used ...
-  bool lm_spec_forced = false;  // ... always (REBVIO_HIP_LM=spec), instead of by the stream's recent miss rate
-  float lm_miss_ema = 0.f;
+  bool lm_spec_forced = false;  // ... always (REBVIO_HIP_LM=spec / spec3), instead of by the stream's recent miss rates
+  int lm_spec_forced_kf = 2;    // first speculative evaluation of the forced form
+  int lm_mix = 0;               // REBVIO_HIP_LM=mix<seed> (seed >= 1): see lm_kernel_choice
+  float lm_miss_ema = 0.f;      // recent rate of "a step after the first was accepted" (the hypothesis of kf = 2 failed)
+  float lm_miss3_ema = 0.f;     // ... "a step after the second was accepted" (the hypothesis of kf = 3 failed)
   int* lm_bar_err = nullptr;  // pinned, zero-copy
   unsigned long long* lm_stamps = nullptr;  // pinned; REBVIO_HIP_LM_STAMPS diagnostic (phase stamps of workgroup 0)
   double lm_stamp_acc[64]{};
@@ -692,9 +695,27 @@ void sum_xrv(const float* h_xrv, int nblocks, float Wx[36], float JtF[6], int* n
 // costs more than it saves (measured there: 3.7 % slower than the sequential kernel; 4-5 % faster on consecutive frames;
 // break-even near one miss in six). Both kernels give the same bits, so the choice follows the recent miss rate of the
 // stream (exponential average over ~16 pairs, known with a lag of two pairs in the streaming driver).
+// 1 = k_lm_chain, 2 / 3 = the speculative kernel with its first speculative evaluation at that index: the earliest hypothesis
+// the stream's recent accept masks have been supporting (a failed hypothesis costs a roll-back: break-even near one miss in six)
+int lm_kernel_choice(const rebvio_hip_ctx* c) {
+  if (c->lm_mix) {  // REBVIO_HIP_LM=mix<seed>: a pseudo-random kernel per pair (tests: every sequence of choices gives the same records)
+    unsigned x = (unsigned)c->pair_seq * 2654435761u + (unsigned)c->lm_mix * 40503u;
+    x ^= x >> 15;
+    x *= 2246822519u;
+    x ^= x >> 13;
+    return 1 + (int)(x % 3u);
+  }
+  if (!c->lm_spec) return 1;
+  if (c->lm_spec_forced) return c->lm_spec_forced_kf;
+  if (c->lm_miss_ema < 0.17f) return 2;
+  if (c->lm_miss3_ema < 0.17f) return 3;
+  return 1;
+}
 void note_accept_mask(rebvio_hip_ctx* c, int mask) {
   const float miss = (mask >> 1) != 0 ? 1.0f : 0.0f;  // an accept after the second evaluation = a failed hypothesis
   c->lm_miss_ema += (miss - c->lm_miss_ema) * (1.0f / 16.0f);
+  const float miss3 = (mask >> 2) != 0 ? 1.0f : 0.0f;
+  c->lm_miss3_ema += (miss3 - c->lm_miss3_ema) * (1.0f / 16.0f);
 }
 
 void lm_to_out(const LmState& s, float vel[3], float Rvel[9], float* F, int* mask, float* srm) {
@@ -780,8 +801,7 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
       c->lm_stamp_spec = spec;
     }
   }
-  const bool spec_now = c->lm_spec && (c->lm_spec_forced || c->lm_miss_ema < 0.17f);
-  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, spec_now ? 2 : 1, first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
+  launch_lm_chain(c->s_trk, c->K, om->d, nm->d, calls, lm_kernel_choice(c), first, c->lm + calls + 1, c->lm_xch, c->lm_tag_base, c->lm_bar_err, c->hist,
                   xrv_dst, slot, c->hist, c->lm_stamps, c->lm_threads, ga);
   c->lm_tag_base += 2u * ((unsigned)calls + 1u);  // (the speculative kernel numbers repeated evaluations in a second range)
   if (c->lm_tag_base > 0xFFFFFF00u) {  // tags must stay unique and non-zero: restart the sequence on clean exchange words
@@ -1037,7 +1057,9 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   if (const char* e = std::getenv("REBVIO_HIP_LM")) {
     c->lm_persistent = std::strcmp(e, "percall") != 0;
     c->lm_spec = std::strcmp(e, "seq") != 0;
-    c->lm_spec_forced = std::strcmp(e, "spec") == 0;
+    c->lm_spec_forced = std::strcmp(e, "spec") == 0 || std::strcmp(e, "spec3") == 0;
+    c->lm_spec_forced_kf = std::strcmp(e, "spec3") == 0 ? 3 : 2;
+    if (std::strncmp(e, "mix", 3) == 0) c->lm_mix = std::max(1, std::atoi(e + 3));
   }
   HIPCHK(hipMalloc(&c->lm, 16 * sizeof(LmState)));
   HIPCHK(hipMemset(c->lm, 0, 16 * sizeof(LmState)));
@@ -2638,11 +2660,18 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
         c->lm_tag_base = 0;
       }
     }
-    bool spec_now = b->lane[0]->lm_spec;  // one launch for all lanes: speculative while every lane's recent miss rate allows it
-    if (spec_now && !b->lane[0]->lm_spec_forced)
-      for (auto* c : b->lane) spec_now = spec_now && c->lm_miss_ema < 0.17f;
+    // one launch for all lanes: the most cautious of the lanes' choices (1 sequential; otherwise the LATEST first speculative
+    // evaluation any lane asks for)
+    int spec_now = 2;
+    for (auto* c : b->lane) {
+      const int ch = lm_kernel_choice(c);
+      if (ch == 1 || spec_now == 1)
+        spec_now = 1;
+      else
+        spec_now = std::max(spec_now, ch);
+    }
     const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
-    launch_lm_chain_b(s, b->K, b->B, b->lm_lanes_per_launch, b->ls_dev, b->maptab_dev, dyn, calls, spec_now ? 1 : 0, glue_params(b->lane[0], frame_dt));
+    launch_lm_chain_b(s, b->K, b->B, b->lm_lanes_per_launch, b->ls_dev, b->maptab_dev, dyn, calls, spec_now, glue_params(b->lane[0], frame_dt));
     const int gate = (int)b->P.global_min_matches_threshold;
     if (g == nsteps - 1) arm_stop_event(s, b->slot_ev[slot]);  // the group's event on its last kernel's completion signal
     launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);

@@ -1332,7 +1332,11 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
                                                    LmState* __restrict__ st_out, unsigned long long* __restrict__ xch, unsigned tag_base,
                                                    int* __restrict__ bar_err, const int* __restrict__ hist, unsigned frame_count,
                                                    float* __restrict__ xrv_part, PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
-                                                   unsigned long long* __restrict__ stamps, int slow_poll, const GlueArgs ga) {
+                                                   unsigned long long* __restrict__ stamps, int slow_poll, const GlueArgs ga, int kf) {
+  // kf = index of the first speculative evaluation: evaluations 0 .. kf - 1 run one per exchange round, kf .. calls - 1 in one
+  // pass under the hypothesis "all rejected". kf = 2: the steady state of a young stream (accept mask 00001); kf = 3: what the
+  // same stream settles into once its depths have converged (00011 on every pair from frame ~6000 on) - four
+  // exchange rounds instead of the six of k_lm_chain or of a roll-back.
   constexpr int kChainGroups = kChainThreads / 256;
   constexpr int kWaves = kChainThreads / 64;
   __shared__ GlueLds gw;
@@ -1490,7 +1494,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   };
   auto normal_pass = [&](int call, int phase) {
     if (call >= 1) {
-      collect(call - 1, tag_of(call - 1, (phase == 1 && call - 1 >= fa + 3) ? 1 : 0));
+      collect(call - 1, tag_of(call - 1, (phase == 1 && call - 1 >= fa + kf + 1) ? 1 : 0));
       if (tid < 64) lm_step_wave(s, red, call, false, lm_inv[0], tid);
       __syncthreads();
     }
@@ -1503,7 +1507,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     do_eval(call, tag_of(call, phase), pj, ge, call == calls - 1);
   };
 
-  const int nspec = calls - 2;  // evaluations 2 .. calls - 1 (the launcher guarantees 2 <= nspec <= kSpecMax)
+  const int nspec = calls - kf;  // evaluations kf .. calls - 1 (the launcher guarantees 2 <= nspec <= kSpecMax)
   // diagnostic: from the end of the previous launch (its last stamp) to the start of this one = the pair's second half with
   // every stream operation between the kernels; summed on the device (the launches of a stream are serialised)
   if (stamps && blockIdx.x == 0 && tid == 0) {
@@ -1533,11 +1537,11 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   if (lm_live) {
     normal_pass(0, 0);
     RH_STAMP(2);
-    normal_pass(1, 0);
+    for (int call = 1; call < kf; ++call) normal_pass(call, 0);
     RH_STAMP(3);
-    collect(1, tag_of(1, 0));
+    collect(kf - 1, tag_of(kf - 1, 0));
     if (tid < 64) {
-      lm_step_wave(s, red, 2, false, lm_inv[0], tid);
+      lm_step_wave(s, red, kf, false, lm_inv[0], tid);
       if (tid == 0) stc[0] = s;
     }
     __syncthreads();
@@ -1556,7 +1560,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         float fake[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) fake[i] = __uint_as_float(0x7FC00000u);
-        lm_step_book(t, fake, 3 + g);
+        lm_step_book(t, fake, kf + 1 + g);
         float M[9];
         lm_step_matrix(t, M);
         const float d = glue_det3(M);
@@ -1624,7 +1628,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
           whask[k][wid] = mm ? 1 : 0;
           wlastk[k][wid] = fi_wlast;
         }
-        if (2 + k == calls - 1 && idx < n) {  // the side effects of the last evaluation (forwardMatch, edge_map.cpp:78-96)
+        if (kf + k == calls - 1 && idx < n) {  // the side effects of the last evaluation (forwardMatch, edge_map.cpp:78-96)
           if (mt[k].matched) {
             const unsigned long long key = ((unsigned long long)order_key(in.rs.x) << 32) | (unsigned)idx;
             fwd_key_max(&nm.fwd_key[mt[k].mfwd], key);
@@ -1639,10 +1643,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     vm_drain();
     RH_STAMP(7);
     __syncthreads();
-    // thread kChainThreads - 1 - k: hand-off behind evaluation 2 + k (carry-in of evaluation 3 + k), as in do_eval
+    // thread kChainThreads - 1 - k: hand-off behind evaluation kf + k (carry-in of evaluation kf + 1 + k), as in do_eval
     if (tid >= kChainThreads - (nspec - 1)) {
       const int k = kChainThreads - 1 - tid;
-      const int call = 2 + k;
+      const int call = kf + k;
       const unsigned tag = tag_of(call, 0);
       int own_has = 0;
       float own_last = 0.f;
@@ -1677,7 +1681,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
           }
       }
     }
-    if (tid < kChainGroups) carryk[0][tid] = carry_in[tid];  // evaluation 2: from the records of evaluation 1 (collect above)
+    if (tid < kChainGroups) carryk[0][tid] = carry_in[tid];  // evaluation kf: from the records of evaluation kf - 1 (collect above)
     __syncthreads();
     RH_STAMP(8);
     float res_hist[kSpecMax];
@@ -1715,7 +1719,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     if (tid < kChainGroups * 16) {
       const int g = tid >> 4, q = tid & 15;
       for (int k = 0; k < nspec; ++k) {
-        const int call = 2 + k;
+        const int call = kf + k;
         const unsigned tag = tag_of(call, 0);
         unsigned long long* out = set_words(call) + ((size_t)blockIdx.x * kChainGroups + g) * kPartStride;
         if (q < 10) {
@@ -1749,8 +1753,8 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
           const int i = min(i0 + j * kChainThreads + tid, total - 1);
           const int set = i / cap, w = i - set * cap;
           ok8[j] = i0 + j * kChainThreads + tid < total && (w & (kPartStride - 1)) < 12;
-          w8[j] = set_words(2 + set) + w;
-          t8[j] = tag_of(2 + set, 0);
+          w8[j] = set_words(kf + set) + w;
+          t8[j] = tag_of(kf + set, 0);
         }
         xch_wait_many<8>(w8, t8, ok8, o8, bar_err, slow_poll);
 #pragma unroll
@@ -1793,7 +1797,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       }
       __syncthreads();
     } else {
-      // evaluation 2 + fa was accepted: go on from there the ordinary way. Roll back, clear the keys the speculative last
+      // evaluation kf + fa was accepted: go on from there the ordinary way. Roll back, clear the keys the speculative last
       // evaluation published, and let nobody publish a repeated evaluation before everybody has read the speculative sets.
       __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the keys other workgroups issued before their last record set
       if (tid == 0) s = stc[fa];
@@ -1811,8 +1815,8 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       for (int i = tid; i < live_wgs; i += kChainThreads) (void)xch_wait(xch_sync + i, tag_final, bar_err, slow_poll);
       __syncthreads();
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      for (int call = 3 + fa; call < calls; ++call) normal_pass(call, 1);
-      collect(calls - 1, tag_of(calls - 1, (calls - 1 >= fa + 3) ? 1 : 0));
+      for (int call = kf + 1 + fa; call < calls; ++call) normal_pass(call, 1);
+      collect(calls - 1, tag_of(calls - 1, (calls - 1 >= fa + kf + 1) ? 1 : 0));
       if (tid == 0) lm_step(s, red, calls, true);
       __syncthreads();
     }
@@ -1891,21 +1895,21 @@ __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec(KParams p, MapD
                                                                  unsigned tag_base, int* __restrict__ bar_err, const int* __restrict__ hist,
                                                                  float* __restrict__ xrv_part, PairSlot* __restrict__ slot,
                                                                  int* __restrict__ hist_to_zero, unsigned long long* __restrict__ stamps,
-                                                                 GlueArgs ga) {
+                                                                 GlueArgs ga, int kf) {
   lm_chain_spec_body<kChainThreads>(p, om, nm, calls, st_in, st_out, xch, tag_base, bar_err, hist, 0u, xrv_part, slot, hist_to_zero, stamps,
-                                    0, ga);
+                                    0, ga, kf);
 }
 template <int kChainThreads>
 __global__ __launch_bounds__(kChainThreads) void k_lm_chain_spec_b(KParams p, const LaneStatic* __restrict__ ls,
                                                                    const MapDev* __restrict__ maptab, LaneDynB dyn, int calls, int slow_poll,
-                                                                   GlueParams gp, int lane0) {
+                                                                   GlueParams gp, int lane0, int kf) {
   const int lane = lane0 + (int)blockIdx.z;  // a launch carries the lanes that fit the device together (launch_lm_chain_b)
   const LaneStatic& L = ls[lane];
   const LaneDyn d = dyn.v[lane];
   PairSlot* slot = gptr(L.slot[d.slot]);
   lm_chain_spec_body<kChainThreads>(p, global_map(lane_map(maptab, lane, d.om, d.om_swap)), global_map(lane_map(maptab, lane, d.nm, d.nm_swap)), calls,
                                     gptr(L.lm_zero), gptr(L.lm) + calls + 1, gptr(L.lm_xch), d.tag_base, gptr(L.lm_bar_err), gptr(L.hist), 0u, gptr(L.xrv_part), slot, gptr(L.hist),
-                                    nullptr, slow_poll, lane_glue_args(L, d, calls, gp));
+                                    nullptr, slow_poll, lane_glue_args(L, d, calls, gp), kf);
 }
 
 template <int kChainThreads>
@@ -2806,23 +2810,26 @@ static size_t lm_spec_shm(int kmax, int calls) {
   const int groups = std::min(div_up(kmax, 256), kMaxRecBlocks);
   return (size_t)(calls - 2) * groups * kPartStride * sizeof(float);
 }
-static bool lm_spec_usable(int kmax, int calls) {
-  return calls - 2 >= 2 && calls - 2 <= kSpecMax && calls <= kMaxLmCalls && lm_spec_shm(kmax, calls) <= 40 * 1024;
+static bool lm_spec_usable(int kmax, int calls, int kf = 2) {
+  return calls - kf >= 2 && calls - 2 <= kSpecMax && calls <= kMaxLmCalls && lm_spec_shm(kmax, calls) <= 40 * 1024;
 }
 
 void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int calls, int do_ext, LmState* st_in,
                      LmState* st_out, unsigned long long* xch, unsigned tag_base, int* bar_err, const int* hist, float* xrv_part,
                      PairSlot* slot, int* hist_to_zero, unsigned long long* stamps, int threads, const GlueArgs& ga) {
   const dim3 grid((p.kmax + threads - 1) / threads);
-  if (do_ext == 2 && threads <= 512 && lm_spec_usable(p.kmax, calls)) {
+  // do_ext: 1 = k_lm_chain; 2 / 3 = the speculative kernel with its first speculative evaluation at index 2 / 3 (lm_chain_spec_body)
+  if (do_ext >= 2 && threads <= 512 && lm_spec_usable(p.kmax, calls, do_ext)) {
+    const int kf = do_ext;
     if (threads == 256)
       RH_LAUNCH(k_lm_chain_spec<256>, grid, dim3(256), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out,
-                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps, ga);
+                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps, ga, kf);
     else
       RH_LAUNCH(k_lm_chain_spec<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, oldm, newm, calls, (const LmState*)st_in, st_out,
-                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps, ga);
+                xch, tag_base, bar_err, hist, xrv_part, slot, hist_to_zero, stamps, ga, kf);
     return;
   }
+  if (do_ext >= 2) do_ext = 2;  // (k_lm_chain reads do_ext as "with forwardMatch / extRotVel")
   switch (threads) {
     case 256:
       RH_LAUNCH(k_lm_chain<256>, grid, dim3(256), 0, s, p, oldm, newm, calls, do_ext, (const LmState*)st_in, st_out, xch, tag_base,
@@ -2932,11 +2939,11 @@ void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, int lanes_per
   // wider batch takes several launches back to back.
   const int slow_poll = lanes >= 3 ? 1 : 0;
   const int per = std::max(1, std::min(lanes, lanes_per_launch));
-  const bool use_spec = spec && lm_spec_usable(p.kmax, calls);
+  const bool use_spec = spec >= 2 && lm_spec_usable(p.kmax, calls, spec);  // spec: 0 / 1 = k_lm_chain_b, 2 / 3 = first speculative evaluation
   for (int l0 = 0; l0 < lanes; l0 += per) {
     const dim3 grid((p.kmax + 511) / 512, 1, (unsigned)std::min(per, lanes - l0));
     if (use_spec)
-      RH_LAUNCH(k_lm_chain_spec_b<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, ls, maptab, dyn, calls, slow_poll, gp, l0);
+      RH_LAUNCH(k_lm_chain_spec_b<512>, grid, dim3(512), lm_spec_shm(p.kmax, calls), s, p, ls, maptab, dyn, calls, slow_poll, gp, l0, spec);
     else
       RH_LAUNCH(k_lm_chain_b<512>, grid, dim3(512), 0, s, p, ls, maptab, dyn, calls, slow_poll, gp, l0);
   }

@@ -1,5 +1,2 @@
-set -o pipefail
-O=gpurun_out/s2q; mkdir -p $O
-timeout -k 10 420 python3 tools/fuzz_parity.py --trials 400 --seed 47 > $O/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -4 $O/fuzz.txt
-timeout -k 10 200 python3 tools/stress_stream.py 100 > $O/soak.txt 2>&1; echo "soak rc=$?"; tail -3 $O/soak.txt
-timeout -k 10 200 python3 tools/stress_stream.py 60 1 > $O/soak_jumps.txt 2>&1; echo "soak jumps rc=$?"; tail -3 $O/soak_jumps.txt
+O=gpurun_out/s2u; mkdir -p $O
+for i in 1 2 3 4 5 6 7 8; do timeout -k 10 300 python -m pytest tests -m gpu -q > $O/gputests_$i.log 2>&1; echo "run $i rc=$? $(tail -1 $O/gputests_$i.log)"; done
