@@ -105,11 +105,6 @@ thread_local ProfOpen t_open;
 }  // namespace
 
 namespace rh {
-thread_local ArmedStop t_armed_stop;
-bool bound_events_enabled() {  // (read per call, a few times per frame: tests switch it between contexts of one process)
-  const char* e = std::getenv("REBVIO_HIP_BOUND_EVENTS");
-  return !(e && e[0] == '0');
-}
 // selection by exact name, or by prefix when the selector ends with '*'
 static bool prof_name_selected(const std::string& only, const char* name) {
   if (!only.empty() && only.back() == '*') return std::strncmp(only.c_str(), name, only.size() - 1) == 0;
@@ -549,24 +544,21 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   // the DoG / gradient kernel run at the head of the keyline stream.
   // Their inputs sb.a[] are then read while the scan stream already works on the next frame, hence the pair per parity;
   // the frame after next waits for ev_flag[b] (recorded behind them) above.
-  arm_stop_event(c->s_det, c->ev_scan[b]);
   launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount, 1);
-  HIPCHK(finish_stop_event(c->s_det, c->ev_scan[b]));
+  HIPCHK(hipEventRecord(c->ev_scan[b], c->s_det));
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
   HIPCHK(hipStreamWaitEvent(c->s_key, c->ev_scan[b], 0));
   launch_scale_space(c->s_key, c->K, img, is_u8, sb, c->widths, db.rowcount, 2, c->fuse_dog);
   if (m->has_done) HIPCHK(hipStreamWaitEvent(c->s_key, m->done_ref ? m->done_ref : m->done, 0));
-  arm_stop_event(c->s_key, c->ev_flag[b]);
   const int fw[2] = {c->widths[0][2], c->widths[1][2]};
   launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st, c->fuse_dog ? fw : nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(finish_stop_event(c->s_key, c->ev_flag[b]));  // (after join: coarser than needed, same stream order)
+  HIPCHK(hipEventRecord(c->ev_flag[b], c->s_key));  // (after join: coarser than needed, same stream order)
   c->ev_flag_used[b] = true;
   // distance field of this map, behind its keylines on the same stream (stream order is the dependency)
-  arm_stop_event(c->s_key, m->ready);
   launch_df_build(c->s_key, c->K, m->d, j.det_out, true);
   HIPCHK(hipGetLastError());
-  HIPCHK(finish_stop_event(c->s_key, m->ready));
+  HIPCHK(hipEventRecord(m->ready, c->s_key));
   m->enqueued.store(1, std::memory_order_release);
   return 0;
 }
@@ -2054,8 +2046,6 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     if (rc) return rc;
     launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
     const int gate = (int)c->P.global_min_matches_threshold;
-    // the group's event rides on its last kernel's own completion signal (no marker packet behind it)
-    if (g == npairs - 1) arm_stop_event(s, c->slot_ev[slot]);
     launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
     std::swap(nm->d.rs, nm->d.rs_tmp);
     std::swap(nm->d.grad, nm->d.grad_tmp);
@@ -2070,7 +2060,7 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     last_slot = slot;
     c->pair_seq++;
   }
-  HIPCHK(finish_stop_event(s, c->slot_ev[last_slot]));
+  HIPCHK(hipEventRecord(c->slot_ev[last_slot], s));
   for (int g = 0; g < npairs; ++g) {
     c->inflight[c->inflight.size() - 1 - (size_t)g].ev_slot = last_slot;
     release_map(c->frames[(size_t)g], c->slot_ev[last_slot]);  // stream-ordered: reusable once the group has drained
@@ -2505,25 +2495,22 @@ void batch_release_map(rebvio_hip_map* m, bool record_done, hipEvent_t done_ref 
 int batch_detect_launch(rebvio_hip_batch* b, const rebvio_hip_batch::DetStep& j) {
   const int B = b->B, par = j.par;
   if (b->ev_flag_used[par]) HIPCHK(hipStreamWaitEvent(b->st.s_det, b->ev_flag[par], 0));
-  arm_stop_event(b->st.s_det, b->ev_scan[par]);
   // the fused candidate kernel moves the last box pass from the scan stream to the keyline stream: measured SLOWER for batches
   // (8 lanes 42.4 k -> 39.7 k frames/s, 4 lanes 32.9 k -> 32.2 k), like the single stream's other moves of scan work to the
   // keyline stream - opt-in here (REBVIO_HIP_BATCH_FUSE_DOG=1), the default for one stream
   const bool fuse = b->fuse_dog;
   launch_scale_space_b(b->st.s_det, b->K, 0, B, b->ls_dev, j.dyn, b->lane[0]->widths, j.lens, fuse);
-  HIPCHK(finish_stop_event(b->st.s_det, b->ev_scan[par]));
+  HIPCHK(hipEventRecord(b->ev_scan[par], b->st.s_det));
   HIPCHK(hipStreamWaitEvent(b->st.s_key, b->ev_scan[par], 0));
   if (j.reuse_done) HIPCHK(hipStreamWaitEvent(b->st.s_key, j.reuse_done, 0));
-  arm_stop_event(b->st.s_key, b->ev_flag[par]);
   const int fw[2] = {b->lane[0]->widths[0][2], b->lane[0]->widths[1][2]};
   launch_keylines_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn, fuse ? fw : nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(finish_stop_event(b->st.s_key, b->ev_flag[par]));
+  HIPCHK(hipEventRecord(b->ev_flag[par], b->st.s_key));
   b->ev_flag_used[par] = true;
-  arm_stop_event(b->st.s_key, b->ev_ready[j.step % rebvio_hip_batch::kReadyRing]);
   launch_df_build_b(b->st.s_key, b->K, B, b->ls_dev, b->maptab_dev, j.dyn);
   HIPCHK(hipGetLastError());
-  HIPCHK(finish_stop_event(b->st.s_key, b->ev_ready[j.step % rebvio_hip_batch::kReadyRing]));
+  HIPCHK(hipEventRecord(b->ev_ready[j.step % rebvio_hip_batch::kReadyRing], b->st.s_key));
   for (int l = 0; l < B; ++l) {
     // The single-map entries (size, download, ...) wait on the map's own event. Letting the step's one event stand for every
     // lane's map (eight marker packets fewer on the keyline stream) was measured SLOWER, 42.5 k -> 41.9 k frames/s at 8 lanes,
@@ -2673,7 +2660,6 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
     const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
     launch_lm_chain_b(s, b->K, b->B, b->lm_lanes_per_launch, b->ls_dev, b->maptab_dev, dyn, calls, spec_now, glue_params(b->lane[0], frame_dt));
     const int gate = (int)b->P.global_min_matches_threshold;
-    if (g == nsteps - 1) arm_stop_event(s, b->slot_ev[slot]);  // the group's event on its last kernel's completion signal
     launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);
     HIPCHK(hipGetLastError());
     for (int l = 0; l < b->B; ++l) {  // (a lane whose pair is skipped for a NaN velocity still gets its next rotation applied)
@@ -2692,7 +2678,7 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
     b->pair_seq++;
     last_slot = slot;
   }
-  HIPCHK(finish_stop_event(s, b->slot_ev[last_slot]));
+  HIPCHK(hipEventRecord(b->slot_ev[last_slot], s));
   for (int g = 0; g < nsteps; ++g) b->inflight[b->inflight.size() - 1 - (size_t)g].ev_slot = last_slot;
   for (auto& of : olds)
     for (auto* m : of.m) batch_release_map(m, false, b->slot_ev[last_slot]);  // the group's one event covers every old map

@@ -2,7 +2,6 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <string>
 #include <stdint.h>
@@ -408,44 +407,6 @@ struct ProfScope {
   do {                                                                   \
     ::rh::ProfScope _ps(stream, #kernel);                                \
     hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);   \
-  } while (0)
-
-// Events bound to a kernel's own completion signal. hipEventRecord puts a marker packet of its own behind the kernel, and on
-// this runtime every packet that is not a kernel costs the stream ~5 us; hipExtLaunchKernelGGL's stopEvent
-// binds the event to the dispatch packet itself (system-scope release at the kernel's end, like a recorded event). A caller
-// arms an event for a stream, the LAST launch of the helper it then calls takes it (RH_LAUNCH_LAST), and
-// finish_stop_event() records it the ordinary way when no launch did (paths that end in a kernel launched with RH_LAUNCH,
-// REBVIO_HIP_BOUND_EVENTS=0).
-struct ArmedStop {
-  hipStream_t s = nullptr;
-  hipEvent_t ev = nullptr;
-};
-extern thread_local ArmedStop t_armed_stop;
-bool bound_events_enabled();
-inline void arm_stop_event(hipStream_t s, hipEvent_t ev) {
-  if (bound_events_enabled()) t_armed_stop = ArmedStop{s, ev};
-}
-inline hipEvent_t take_stop_event(hipStream_t s) {
-  if (!t_armed_stop.ev || t_armed_stop.s != s) return nullptr;
-  const hipEvent_t ev = t_armed_stop.ev;
-  t_armed_stop = ArmedStop{};
-  return ev;
-}
-inline hipError_t finish_stop_event(hipStream_t s, hipEvent_t ev) {
-  if (t_armed_stop.ev == ev && t_armed_stop.s == s && ev) {  // nobody took it
-    t_armed_stop = ArmedStop{};
-    return hipEventRecord(ev, s);
-  }
-  if (!bound_events_enabled()) return hipEventRecord(ev, s);
-  return hipSuccess;
-}
-#define RH_LAUNCH_LAST(kernel, grid, block, shm, stream, ...)                                         \
-  do {                                                                                                \
-    ::rh::ProfScope _ps(stream, #kernel);                                                             \
-    if (hipEvent_t _stop = ::rh::take_stop_event(stream))                                             \
-      hipExtLaunchKernelGGL(kernel, grid, block, shm, stream, nullptr, _stop, 0, __VA_ARGS__);        \
-    else                                                                                              \
-      hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                              \
   } while (0)
 
 }  // namespace rh

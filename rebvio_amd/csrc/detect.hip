@@ -1617,21 +1617,17 @@ void launch_scale_space(hipStream_t s, const KParams& p, const void* img, int im
                        C, widths[0][0], widths[1][0], ldw);
     RH_COLSCAN(false, sb.b[0], sb.b[1]);
     // pass 3: filter f averages its own integral image
-    if (part == 1)  // the scan stream's last kernel of the frame: an armed event rides on it (common.hpp)
-      RH_LAUNCH_LAST(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R, C, widths[0][1],
-                     widths[1][1], ldw);
-    else
-      RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R, C, widths[0][1],
-                widths[1][1], ldw);
+    RH_LAUNCH(k_rowscan<2>, g2, dim3(256), shm, s, (const void*)sb.b[0], (const void*)sb.b[1], sb.a[0], sb.a[1], R, C, widths[0][1],
+              widths[1][1], ldw);
   }
   if ((part & 2) && fuse_dog) {
     // the candidate kernel forms the last box pass, DoG and gradient itself (launch_keylines, k_keyline_flag_ii): only the
     // column pass remains here, and it clears the frame's row counters
-    RH_LAUNCH_LAST(k_colscan, c2, dim3(256), cshm, s, sb.a[0], sb.a[1], R, Cp, ldh, rowcount_to_zero, R);
+    RH_LAUNCH(k_colscan, c2, dim3(256), cshm, s, sb.a[0], sb.a[1], R, Cp, ldh, rowcount_to_zero, R);
   } else if (part & 2) {
     RH_COLSCAN(false, sb.a[0], sb.a[1]);
     const dim3 gt(div_up(C, 64), div_up(R, kTileRowsSingle));
-    RH_LAUNCH_LAST(k_dog_mag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2], widths[1][2], sb.dog,
+    RH_LAUNCH(k_dog_mag<kTileRowsSingle>, gt, dim3(64, 4), 0, s, (const float*)sb.a[0], (const float*)sb.a[1], widths[0][2], widths[1][2], sb.dog,
               sb.mag, sb.scale0, sb.scale1, R, C, rowcount_to_zero);
   }
 #undef RH_COLSCAN
@@ -1698,12 +1694,12 @@ void launch_scale_space_b(hipStream_t s, const KParams& p, int lane0, int lanes,
   RH_COLSCAN_B(1);
   if (fuse_dog) {  // k_keyline_flag_ii_b forms the last box pass, DoG and gradient itself (launch_keylines_b)
     RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 4, R, C, widths[0][1], widths[1][1], ldw);
-    RH_LAUNCH_LAST(k_colscan_b, c2, dim3(256), cshm, s, ls, lane0, 3, R, Cp, ldh, (int)dyn.v[lane0].parity);
+    RH_LAUNCH(k_colscan_b, c2, dim3(256), cshm, s, ls, lane0, 3, R, Cp, ldh, (int)dyn.v[lane0].parity);
     return;
   }
   RH_LAUNCH(k_rowscan_b<2>, g2, dim3(256), shm, s, ls, dyn, lane0, 2, R, C, widths[0][1], widths[1][1], ldw);
   RH_COLSCAN_B(2);
-  RH_LAUNCH_LAST(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 16), z), dim3(64, 4), 0, s, ls, dyn, lane0, widths[0][2], widths[1][2], R, C);
+  RH_LAUNCH(k_dog_mag_b, dim3(div_up(C, 64), div_up(R, 16), z), dim3(64, 4), 0, s, ls, dyn, lane0, widths[0][2], widths[1][2], R, C);
 #undef RH_COLSCAN_B
 }
 
@@ -1716,7 +1712,7 @@ void launch_keylines_b(hipStream_t s, const KParams& p, int lanes, const LaneSta
   else
     RH_LAUNCH(k_keyline_flag_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, dyn);
   RH_LAUNCH(k_keyline_emit_b, dim3(div_up(p.cols, 64), div_up(p.rows, 16), z), dim3(64, 4), 0, s, p, ls, maptab, dyn, 0, dg.ntx * dg.nty);
-  RH_LAUNCH_LAST(k_join_edges_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, maptab, dyn, dg.T, dg.ntx,
+  RH_LAUNCH(k_join_edges_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, maptab, dyn, dg.T, dg.ntx,
             dg.nty);
 }
 
@@ -1732,14 +1728,14 @@ void launch_df_build_b(hipStream_t s, const KParams& p, int lanes, const LaneSta
         (void)hipGetLastError();
       have[0] = shm;
     }
-    RH_LAUNCH_LAST(k_df_lists_b<32>, grid, dim3(kDfsThreads), shm, s, p, ls, maptab, dyn);
+    RH_LAUNCH(k_df_lists_b<32>, grid, dim3(kDfsThreads), shm, s, p, ls, maptab, dyn);
   } else {
     if (shm > have[1]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_df_lists_b<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         (void)hipGetLastError();
       have[1] = shm;
     }
-    RH_LAUNCH_LAST(k_df_lists_b<64>, grid, dim3(kDfsThreads), shm, s, p, ls, maptab, dyn);
+    RH_LAUNCH(k_df_lists_b<64>, grid, dim3(kDfsThreads), shm, s, p, ls, maptab, dyn);
   }
 }
 
@@ -1755,7 +1751,7 @@ void launch_keylines(hipStream_t s, const KParams& p, const ScaleBufs& sb, const
               db.rowcount);
   RH_LAUNCH(k_keyline_emit<kTileRowsSingle>, gt, dim3(64, 4), 0, s, p, m, (const float4*)db.stash, (const unsigned long long*)db.bits,
             (const int*)db.rowcount, det_in, det_out, prev_st, 0, dg.ntx * dg.nty);
-  RH_LAUNCH_LAST(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, m, dg.T, dg.ntx, dg.nty);
+  RH_LAUNCH(k_join_edges, dim3(div_up(p.kmax, 256)), dim3(256), (size_t)dg.ntx * dg.nty * sizeof(int), s, p, m, dg.T, dg.ntx, dg.nty);
 }
 
 void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const DetState* det_prev, bool mask_is_current) {
@@ -1773,10 +1769,10 @@ void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const Det
     const size_t shm = (((size_t)dg.T * (dg.T + 1) + 3) & ~(size_t)3) * sizeof(unsigned) + list_bytes;
     if (dg.T == 32) {
       want(reinterpret_cast<const void*>(&k_df_lists<32>), shm, &attr_shm[0]);
-      RH_LAUNCH_LAST(k_df_lists<32>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
+      RH_LAUNCH(k_df_lists<32>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
     } else {  // (cols <= 4096 and rows <= 2548 keep 64-pixel tiles below kDfMaxTiles)
       want(reinterpret_cast<const void*>(&k_df_lists<64>), shm, &attr_shm[1]);
-      RH_LAUNCH_LAST(k_df_lists<64>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
+      RH_LAUNCH(k_df_lists<64>, dim3(dg.ntx, dg.nty), dim3(kDfsThreads), shm, s, p, m, det_prev RH_DFS_STAMP_PASS);
     }
     return;
   }
@@ -1785,7 +1781,7 @@ void launch_df_build(hipStream_t s, const KParams& p, const MapDev& m, const Det
   // memory-side atomic rate, a larger grid only takes CUs and memory queues from the latency-critical streams
   const long long threads = (long long)p.kmax * p.df_nr;
   const unsigned blocks = (unsigned)std::min<long long>((threads + 255) / 256, 128);
-  RH_LAUNCH_LAST(k_df_build, dim3(blocks), dim3(256), 0, s, p, m, det_prev);
+  RH_LAUNCH(k_df_build, dim3(blocks), dim3(256), 0, s, p, m, det_prev);
 }
 
 void launch_df_decode(hipStream_t s, const KParams& p, const MapDev& m, int* id_out, int* dist_out) {

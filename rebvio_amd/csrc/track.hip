@@ -2927,7 +2927,7 @@ void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, con
 void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* work_n_reset,
                                int* hist) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-  RH_LAUNCH_LAST(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(z), gate, work_n_reset, 0, mat3(I), hist,
+  RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(z), gate, work_n_reset, 0, mat3(I), hist,
                  p.quantile_num_bins, g_dev);
 }
 
@@ -2981,7 +2981,7 @@ void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStat
   else
     RH_LAUNCH(k_directed_match_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   RH_LAUNCH(k_directed_match_tail_b, dim3(dm_tail_blocks(p.kmax), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
-  RH_LAUNCH_LAST(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
+  RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
 }
 
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp, int gate) {

@@ -956,7 +956,7 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
     def run(lead, group, prio=None, stamps=False, extra=None):
         monkeypatch.setenv("REBVIO_HIP_LEAD", str(lead))
         monkeypatch.setenv("REBVIO_HIP_GROUP", str(group))
-        for name in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_BOUND_EVENTS", "REBVIO_HIP_GYRO_PRE", "REBVIO_HIP_FUSE_DOG"):
+        for name in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_GYRO_PRE", "REBVIO_HIP_FUSE_DOG"):
             monkeypatch.delenv(name, raising=False)
         for name, val in (extra or {}).items():
             monkeypatch.setenv(name, val)
@@ -979,13 +979,11 @@ def test_streaming_results_do_not_depend_on_pipeline_depth(B, c2_stream, monkeyp
     for lead, group, prio, stamps in ((5, 1, None, False), (5, 4, None, False), (8, 2, None, False), (12, 6, None, False), (5, 4, "flat", False),
                                       (5, 3, None, True)):
         assert run(lead, group, prio, stamps) == base, (lead, group, prio, stamps)
-    # who launches the detect kernels (the caller itself, the default, or the context's worker thread) and how the streams'
-    # events are recorded (bound to a kernel's completion signal, the default, or as marker packets) move no result either
-    # ... nor does who forms the data-independent 3x3 matrices of gyroBiasCorrection (the host from its shadow of W_Bg, the
-    # default, or the device glue itself)
-    for extra in ({"REBVIO_HIP_DETECT_WORKER": "1"}, {"REBVIO_HIP_BOUND_EVENTS": "0"},
-                  {"REBVIO_HIP_DETECT_WORKER": "1", "REBVIO_HIP_BOUND_EVENTS": "0"}, {"REBVIO_HIP_GYRO_PRE": "0"},
-                  {"REBVIO_HIP_FUSE_DOG": "0"}):  # k_dog_mag + k_keyline_flag instead of the fused candidate kernel
+    # who launches the detect kernels (the caller itself, the default, or the context's worker thread) moves no result either,
+    # nor does who forms the data-independent 3x3 matrices of gyroBiasCorrection (the host from its shadow of W_Bg, the
+    # default, or the device glue itself), nor the fused candidate kernel against k_dog_mag + k_keyline_flag
+    for extra in ({"REBVIO_HIP_DETECT_WORKER": "1"}, {"REBVIO_HIP_GYRO_PRE": "0"}, {"REBVIO_HIP_FUSE_DOG": "0"},
+                  {"REBVIO_HIP_DETECT_WORKER": "1", "REBVIO_HIP_GYRO_PRE": "0", "REBVIO_HIP_FUSE_DOG": "0"}):
         assert run(5, 4, extra=extra) == base, extra
 
 
@@ -1186,10 +1184,10 @@ def _batch_records(B, cam, streams, order, lens=None, **kw):
 
 @pytest.mark.parametrize("L,env", [(3, {}), (4, {}), (8, {}), (4, {"REBVIO_HIP_LM": "seq"}), (4, {"REBVIO_HIP_LM": "spec3"}), (2, {"REBVIO_HIP_BATCH_DM_HEAD": "thread"}),
                                    (5, {"REBVIO_HIP_BATCH_DM_HEAD": "wide", "REBVIO_HIP_BATCH_LEAD": "6", "REBVIO_HIP_BATCH_GROUP": "3"}),
-                                   (3, {"REBVIO_HIP_DETECT_WORKER": "0", "REBVIO_HIP_BOUND_EVENTS": "0", "REBVIO_HIP_FUSE_DOG": "0"}),
+                                   (3, {"REBVIO_HIP_DETECT_WORKER": "0", "REBVIO_HIP_FUSE_DOG": "0"}),
                                    (3, {"REBVIO_HIP_BATCH_FUSE_DOG": "1"})],
                          ids=["3-lanes", "4-lanes", "8-lanes", "4-lanes-seq-lm", "4-lanes-spec3-lm", "2-lanes-thread-head", "5-lanes-wide-head-lead6-group3",
-                              "3-lanes-caller-launches-marker-events-unfused-dog",
+                              "3-lanes-caller-launches-unfused-dog",
                               "3-lanes-fused-candidate-kernel"])
 def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, env):
     """rebvio_hip_batch_*: L camera streams advanced in lock-step by batched launches (lane = blockIdx.z) produce, lane by lane,
@@ -1207,7 +1205,7 @@ def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, e
         monkeypatch.setenv(k, v)
     got = _batch_records(B, cam, streams, order)
     for k in env:
-        if k.startswith("REBVIO_HIP_BATCH") or k in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_BOUND_EVENTS", "REBVIO_HIP_FUSE_DOG"):
+        if k.startswith("REBVIO_HIP_BATCH") or k in ("REBVIO_HIP_DETECT_WORKER", "REBVIO_HIP_FUSE_DOG"):
             monkeypatch.delenv(k)
     want = [_stand_alone_records(B, cam, streams[s], order) for s in range(L)]
     for s in range(L):
