@@ -4,6 +4,7 @@
 //   host_math_dump <mode> in.f32 out.f32
 //   sab   : a_v3 a_s3 G x_p7 Pp49 Rv9 Rs9 Rg X7            -> JtJ49 JtF7 Xgn7 iterations1
 //   gbc   : X6 Wx36 Wb9 Rg9 Rb9                            -> X6 Wx36 Wb9 dg3          (Core::gyroBiasCorrection + the C-ABI's hostmath form)
+//   gpre  : W_Bg9 s_g s_b n                                 -> n x (gyro_pre's W_Bg9, gyro_bias_correction's W_Bg9)
 //   chol6 : A36                                            -> inv36
 //   so3   : w3 a3 b3                                       -> exp(w)9 ln(exp(w))3 R(a->b)9 hostmath exp(w)9
 #include <cstdio>
@@ -76,6 +77,25 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) out.push_back(Wb(i, j));
     for (int i = 0; i < 3; ++i) out.push_back(dg[i]);
+  } else if (mode == "gpre") {
+    // in: W_Bg9 s_g s_b n; out per step k < n: pre[2] of hm::gyro_pre (the information matrix after the pair) and the W_Bg that
+    // hm::gyro_bias_correction leaves for the same inputs (9 + 9 floats), the shadow advanced like the streaming driver does
+    if (in.size() != 12) return 3;
+    hm::M3 shadow = hm::load3(p), W = hm::load3(p);
+    const float s_g = p[9], s_b = p[10];
+    const int n = (int)p[11];
+    for (int k = 0; k < n; ++k) {
+      float pre[6][9];
+      hm::gyro_pre(shadow, s_g, s_b, pre);
+      shadow = hm::load3(pre[2]);
+      float X[6] = {0.01f, -0.02f, 0.005f, 1e-3f, -2e-3f, 5e-4f}, Wx[36], dg[3];
+      for (int i = 0; i < 36; ++i) Wx[i] = (i % 7 == 0) ? 1000.0f + 10.0f * (float)k : 1.0f;
+      hm::gyro_bias_correction(X, Wx, W, hm::diag3(s_g), hm::diag3(s_b), dg);
+      for (int i = 0; i < 9; ++i) out.push_back(pre[2][i]);
+      float w9[9];
+      hm::store3(W, w9);
+      for (int i = 0; i < 9; ++i) out.push_back(w9[i]);
+    }
   } else if (mode == "chol6") {
     if (in.size() != 36) return 3;
     float h[36];  // what the host classes and the C-ABI glue use for TooN::Cholesky<6,float>::get_inverse (rebvio.cpp:198)

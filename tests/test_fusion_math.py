@@ -187,6 +187,23 @@ def test_gyro_bias_correction_is_the_joint_minimiser(tool, seed):
     assert np.abs(Wx1 - want).max() <= 1e-5 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("seed", [3, 4])
+def test_host_shadow_of_the_gyro_information_matrix_tracks_the_filter(tool, seed):
+    """The streaming driver hands the data-independent 3x3 matrices of gyroBiasCorrection to the device glue by value, formed
+    from a HOST shadow of W_Bg that it advances with hm::gyro_pre (api.hip glue_params_pre). That is only right if the shadow
+    follows the filter's own W_Bg bit for bit, pair after pair, whatever the pair's data (here: a different W_Xv every step):
+    W_Bg <- Wg + invert(invert(W_Bg) + Rb) (core.cpp:266-267,282)."""
+    rng = np.random.default_rng(seed)
+    A = rng.normal(0, 1, (3, 3))
+    W0 = np.asarray((A @ A.T + np.eye(3)) * 1e4, np.float32)
+    dt = 0.05
+    s_g, s_b = np.float32((1.7e-4 * dt) ** 2 * 1e6), np.float32((1.9e-5 * dt) ** 2 * 1e6)
+    n = 200
+    out = tool("gpre", np.concatenate([W0.ravel(), [s_g, s_b, n]])).astype(np.float32).reshape(n, 2, 9)
+    assert np.array_equal(out[:, 0].view(np.uint32), out[:, 1].view(np.uint32))
+    assert np.isfinite(out).all() and not np.array_equal(out[0, 0], out[-1, 0])  # the matrix does move
+
+
 @pytest.mark.parametrize("seed", [10, 11])
 def test_cholesky6_inverse_against_numpy(tool, seed):
     rng = np.random.default_rng(seed)
