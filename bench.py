@@ -346,7 +346,7 @@ def main():
     t0 = time.perf_counter()
     for j in range(steps):
         out, n = push(k)
-        push_done[j] = time.perf_counter()  # a push returns once the pair in flight has been completed (one host sync per frame)
+        push_done[j] = time.perf_counter()  # (a push queues the frame's detect kernels and whatever pairs can start; it blocks only on result slots)
         statuses.append(out.status)
         matches.append(out.klm_num)
         k += 1
