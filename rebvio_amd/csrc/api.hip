@@ -2187,8 +2187,9 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
     if (c->lm_stamps[46]) {
       const double m = 0.01 / (double)c->lm_stamps[46];
       std::fprintf(stderr, "[rebvio_hip]   of which: LM end -> head start %.2f  head start -> tail start %.2f  tail start -> regularize/EKF start %.2f  "
-                   "regularize/EKF start -> next LM start %.2f\n", (double)c->lm_stamps[42] * m, (double)c->lm_stamps[43] * m, (double)c->lm_stamps[44] * m,
-                   (double)c->lm_stamps[45] * m);
+                   "regularize/EKF start -> next LM start %.2f (of which the LM kernel's own prologue: keyline loads + sigma quantile %.2f)\n",
+                   (double)c->lm_stamps[42] * m, (double)c->lm_stamps[43] * m, (double)c->lm_stamps[44] * m, (double)c->lm_stamps[45] * m,
+                   (double)c->lm_stamps[56] * m);
     }
   } else if (c->lm_stamps && c->lm_stamp_n) {
     const int calls = (int)c->P.iterations + 1;

@@ -1363,6 +1363,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   __shared__ float carryk[kSpecMax + 1][kChainGroups];
 
   const int tid = threadIdx.x;
+  const unsigned long long t_entry = (stamps && blockIdx.x == 0 && tid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostic
   const int idx = blockIdx.x * kChainThreads + tid;
   const int lane = tid & 63, wid = tid >> 6, grp = tid >> 8, wig = wid & 3;
   const int nwg = gridDim.x;
@@ -1530,6 +1531,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         stamps[44] += t3 - t2;
         stamps[45] += now - t3;
         stamps[46] += 1ull;
+        stamps[56] += now - t_entry;  // kernel entry -> here: the keyline loads and the sigma quantile ahead of the first evaluation
       }
     }
   }
