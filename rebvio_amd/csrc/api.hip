@@ -31,6 +31,14 @@ struct SharedStreams {
 };
 thread_local const SharedStreams* t_adopt_streams = nullptr;
 
+// REBVIO_HIP_DM_HEAD / REBVIO_HIP_BATCH_DM_HEAD -> form of the directedMatch launch (track.hip: dm_head_wide, dm_compact)
+int dm_form_by_name(const char* e) {
+  static const char* const names[] = {"", "thread", "wide", "compact", "compact128", "compact1", "compact64"};
+  for (int i = 1; i < 7; ++i)
+    if (std::strcmp(e, names[i]) == 0) return i;
+  return 0;
+}
+
 int fail(const char* what, hipError_t e) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
   return -(int)e - 1000;
@@ -1040,8 +1048,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipHostMalloc(&c->lm_bar_err, 8 * sizeof(int), hipHostMallocDefault));
   std::memset(c->lm_bar_err, 0, 8 * sizeof(int));
   if (std::getenv("REBVIO_HIP_LM_STAMPS")) {
-    HIPCHK(hipHostMalloc(&c->lm_stamps, 64 * sizeof(unsigned long long), hipHostMallocDefault));
-    std::memset(c->lm_stamps, 0, 64 * sizeof(unsigned long long));
+    HIPCHK(hipHostMalloc(&c->lm_stamps, 128 * sizeof(unsigned long long), hipHostMallocDefault));
+    std::memset(c->lm_stamps, 0, 128 * sizeof(unsigned long long));
     K.dbg = c->lm_stamps;
   }
   // REBVIO_HIP_LM = percall (one kernel per evaluation) | seq (persistent kernel, one evaluation per exchange round) |
@@ -1087,7 +1095,7 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
     if (v == 256 || v == 512 || v == 1024) c->lm_threads = v;
   }
   if (const char* e = std::getenv("REBVIO_HIP_DM_HEAD"))  // directedMatch head form (track.hip, dm_head_wide): thread | wide; default by map size
-    c->dm_head_form = std::strcmp(e, "thread") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
+    c->dm_head_form = dm_form_by_name(e);
   HIPCHK(hipHostMalloc(&c->h_lm, 2 * sizeof(LmState), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_part, part_call_stride(c) * sizeof(float), hipHostMallocDefault));
   HIPCHK(hipHostMalloc(&c->h_xrv, (size_t)c->maxblocks * kXrvStride * sizeof(float), hipHostMallocDefault));
@@ -1623,7 +1631,7 @@ int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_
   HIPCHK(trk_wait_ready(c->s_trk, nm));
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, vel, Rvel, Rback, vel_r, Rvel_r);
-  HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 3 * sizeof(int), c->s_trk));
+  HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 4 * sizeof(int), c->s_trk));  // dm_matches, dm_kf, reg_count, dm_queued
   launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, c->dm_work, c->dm_work_n, nullptr, c->dm_head_form);
   HIPCHK(hipMemsetAsync(c->dm_work_n, 0, sizeof(int), c->s_trk));
   HIPCHK(hipGetLastError());
@@ -2190,6 +2198,16 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
                    "regularize/EKF start -> next LM start %.2f (of which the LM kernel's own prologue: keyline loads + sigma quantile %.2f)\n",
                    (double)c->lm_stamps[42] * m, (double)c->lm_stamps[43] * m, (double)c->lm_stamps[44] * m, (double)c->lm_stamps[45] * m,
                    (double)c->lm_stamps[56] * m);
+    }
+    if (c->lm_stamps[64]) {
+      const unsigned long long* d = c->lm_stamps;
+      const double m = 1.0 / (double)d[64];
+      std::fprintf(stderr, "[rebvio_hip]   directedMatch (compact) per launch: keylines %.0f  t_steps > %d: %.0f  matched in the head %.0f  long searches %.0f  "
+                   "head candidates %.0f  long-search candidates %.0f | waves with long searches %.1f  with > 16: %.1f  > 32: %.1f  max per wave %llu\n",
+                   d[65] * m, 4, d[66] * m, d[74] * m, d[67] * m, d[68] * m, d[69] * m, d[73] * m, d[71] * m, d[72] * m, d[70]);
+      std::fprintf(stderr, "[rebvio_hip]   t_steps histogram (per launch):");
+      for (int i = 0; i < 48; ++i) std::fprintf(stderr, " %d:%.0f", i, d[80 + i] * m);
+      std::fprintf(stderr, "\n");
     }
   } else if (c->lm_stamps && c->lm_stamp_n) {
     const int calls = (int)c->P.iterations + 1;
@@ -2854,7 +2872,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_LEAD")) b->lead = std::min(8, std::max(3, std::atoi(e)));
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_GROUP")) b->group = std::min(4, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_DM_HEAD"))
-    b->dm_head_form = std::strcmp(e, "thread") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
+    b->dm_head_form = dm_form_by_name(e);
   HIPCHK(hipDeviceSynchronize());
   guard.b = nullptr;
   *out = b;

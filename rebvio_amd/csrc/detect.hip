@@ -1004,6 +1004,7 @@ __device__ __forceinline__ void keyline_emit_body(KParams p, MapDev m, const flo
       m.st->dm_matches = 0;
       m.st->dm_kf = 0;
       m.st->reg_count = 0;
+      m.st->dm_queued = 0;
       det_out->threshold = servo_threshold(p, *det_in);
       det_out->count = n;
       det_out->auto_threshold = prev_auto;

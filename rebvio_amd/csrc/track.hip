@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_rotate(KParams p, MapDev m, Mat3 R, int
     m.st->dm_matches = 0;
     m.st->dm_kf = 0;
     m.st->reg_count = 0;
+    m.st->dm_queued = 0;
   }
   if (idx < n) {
     rotate_one(R, p.fm, pi, rs, g);
@@ -2536,6 +2537,366 @@ __global__ __launch_bounds__(256) void k_directed_match_tail_b(KParams p, const 
                            max_radius, gptr(L.dm_work), gptr(L.dm_work_n), 1, z9, gptr(L.glue_dev) + d.slot);
 }
 
+// ---- directedMatch, compact form (round 4): ONE launch, dense lanes in every expensive phase -------------------------------
+// The two-launch forms above spend most of their instructions on mostly idle lanes: a probe finds a keyline of the old map on
+// ~5 % of the pixels it looks at (1.5 of the eight head probes of a keyline, 2 of a long search's ~35), yet the candidate
+// fetch + second rotateKeylines + acceptance test (six IEEE divisions, a double-accumulated 3x3 product: ~350 instructions)
+// runs once per probe SLOT of the wave, and the long searches take a second launch whose waves hold one keyline each behind
+// a queue. Here a wave owns 64 / kLPK keylines of the new map through the whole of searchMatch (edge_map.cpp:101-184), kLPK
+// lanes per keyline:
+//   phase 1  the kLPK lanes of a keyline share the first kHeadSteps steps (2 * kHeadSteps / kLPK independent mask loads per
+//            lane); the wave's candidates are COMPACTED into an LDS list {old keyline, owner, slot} and tested 64 at a time,
+//            one candidate per lane; an accepted candidate bids for its owner with an LDS atomicMin on (slot, list position):
+//            the smallest slot index is the reference's first hit; the winner's rotated fields are staged per owner in LDS and
+//            committed by the owner's first lane.
+//   phase 2  the keylines still open after that (long searches: t_steps > kHeadSteps, nothing accepted; 2 600 of 15 000 in the
+//            steady state, mean t_steps 20) are searched up to kDmcOpen at a time: two lanes of each walk the reference's two
+//            +-1.0f chains (edge_map.cpp:149-150: repeated ++tp / --tn, not dq_rho +- k) into LDS, then ALL 64 lanes share the
+//            batch's probe slots, the candidates are compacted and tested as in phase 1.
+// Testing every candidate of a keyline instead of stopping at the first accepted one changes nothing (the minimum slot wins)
+// and costs little: the tests are what is dense now. Everything is wave-local (no workgroup barrier before the counters).
+// kLPK = 4 is the low-latency choice of one stream (938 waves of 16 keylines: a wave's long searches fit one batch - the
+// 64-keyline form measured 29 us for phase 2 because waves with 40+ open keylines search them 16 at a time, one after the other);
+// kLPK = 1 executes the fewest instructions (batches, large maps).
+constexpr int kDmcWin = 40;        // probe steps per long-search window
+constexpr int kDmcWinPitch = 41;   // LDS pitch of one chain window (odd: the owners' rows start in different banks)
+constexpr int kDmcOpen = 16;       // open keylines a wave searches together
+constexpr int kDmcList = kDmcOpen * 2 * kDmcWin;  // candidate list capacity of a wave (phase 1 needs at most 64 * 2 * kHeadSteps = 512)
+constexpr int kDmcNone = 0x7fffffff;
+static_assert(kDmcList >= 64 * 2 * kHeadSteps, "phase 1 list");
+template <int kKPW>  // keylines per wave (owners)
+struct DmcWave {
+  unsigned list[kDmcList];           // candidate: old keyline (16 bits) | owner (6) | slot in the reference's probe order, 2 * step + side (10)
+  float t1[kKPW * 2 * kHeadSteps];   // phase 1: t of the candidate's probe (phase 2 reads it from seq)
+  float4 q_a[kKPW];                  // per owner, what the acceptance test needs of the query keyline: norm_t, sigma2_t, gradient
+  float q_gn[kKPW];                  // ... and its norm
+  int best[kKPW];                    // per owner: min over accepted candidates of slot << 16 | list position
+  float w_f[7][kKPW];                // staged winner per owner: pos_img, (rho, sigma_rho), gradient, norm (rotated) ...
+  int w_i[3][kKPW];                  // ... matches, match_id_keyframe, old keyline index
+  float4 s_a[kDmcOpen];              // probe geometry of the open keylines: t_x, t_y, pi0x, pi0y
+  float4 s_b[kDmcOpen];              // dq_min, dq_max, t_steps (int bits), -
+  float seq[kDmcOpen][2][kDmcWinPitch];  // [open keyline][0: tn, 1: tp][step - window start]
+};
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  *total = __shfl(incl, 63);
+  return incl - v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+// Acceptance test of one candidate (edge_map.cpp:170-177) on the two query scalars it needs of the probe geometry.
+__device__ __forceinline__ bool search_accept_q(const KParams& p, float norm_t, float sigma2_t, float t, float2 cg, float cgn, float2 crs,
+                                                float2 gq, float gnq) {
+  SearchSetup S;
+  S.norm_t = norm_t;
+  S.sigma2_t = sigma2_t;
+  return search_accept(p, S, t, cg, cgn, crs, gq, gnq);
+}
+// Test the T listed candidates of a wave, 64 at a time; accepted ones bid for their owner, the current best of an owner is staged.
+template <bool kPhase2, class DmcWaveT>
+__device__ __forceinline__ void dmc_test_list(const KParams& p, const MapDev& om, DmcWaveT& W, int T, int lane, int rot, const Mat3& R0,
+                                              int step0) {
+  for (int e0 = 0; e0 < T; e0 += 64) {
+    const int e = e0 + lane;
+    bool acc = false;
+    OldKl ck{};
+    int owner = 0, bid = 0, c = -1;
+    if (e < T) {
+      const unsigned ent = W.list[e];
+      c = (int)(ent >> 16);
+      owner = (int)((ent >> 10) & 63u);
+      const int slot = (int)(ent & 1023u);
+      const float t = kPhase2 ? W.seq[owner][slot & 1][(slot >> 1) - step0] : W.t1[e];
+      ck = load_old(om, c, rot, R0, p.fm);
+      const float4 qa = W.q_a[owner];
+      acc = search_accept_q(p, qa.x, qa.y, t, ck.g, ck.gn, ck.rs, make_float2(qa.z, qa.w), W.q_gn[owner]);
+      bid = (slot << 16) | e;
+      if (acc) atomicMin(&W.best[owner], bid);
+    }
+    wave_lds_sync();
+    if (acc && W.best[owner] == bid) {  // best so far of this owner (a later 64 may still replace it: same wave, program order)
+      W.w_f[0][owner] = ck.pi.x; W.w_f[1][owner] = ck.pi.y; W.w_f[2][owner] = ck.rs.x; W.w_f[3][owner] = ck.rs.y;
+      W.w_f[4][owner] = ck.g.x; W.w_f[5][owner] = ck.g.y; W.w_f[6][owner] = ck.gn;
+      W.w_i[0][owner] = (int)ck.matches; W.w_i[1][owner] = ck.kf; W.w_i[2][owner] = c;
+    }
+    wave_lds_sync();
+  }
+}
+template <class DmcWaveT>
+__device__ __forceinline__ int dmc_commit(MapDev& nm, const MapDev& om, DmcWaveT& W, int owner, int idx, int* kf) {
+  OldKl k;
+  k.pi = make_float2(W.w_f[0][owner], W.w_f[1][owner]);
+  k.rs = make_float2(W.w_f[2][owner], W.w_f[3][owner]);
+  k.g = make_float2(W.w_f[4][owner], W.w_f[5][owner]);
+  k.gn = W.w_f[6][owner];
+  k.matches = (unsigned)W.w_i[0][owner];
+  k.kf = W.w_i[1][owner];
+  const int found = W.w_i[2][owner];
+  search_commit(nm, om, idx, found, k, kf);
+  return found;
+}
+
+template <int kThreads, int kLPK>
+__device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_, float max_radius,
+                                                      int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
+  static_assert(kLPK == 1 || kLPK == 2 || kLPK == 4 || kLPK == 8, "lanes per keyline");
+  constexpr int kWaves = kThreads / 64;
+  constexpr int kKPW = 64 / kLPK;                 // keylines per wave
+  constexpr int kHP = 2 * kHeadSteps / kLPK;      // head probes per lane
+  constexpr int kBatch = kKPW < kDmcOpen ? kKPW : kDmcOpen;
+  static_assert(kMaxRecBlocks * 256 <= 65536, "old keyline index in 16 bits of a list entry");
+  __shared__ DmcWave<kKPW> lds[kWaves];
+  const uint2 vb = xcd_band_block();
+  if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[48] = __builtin_amdgcn_s_memrealtime();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int kl = lane / kLPK, sub = lane % kLPK;  // keyline of the wave, lane of the keyline
+  DmcWave<kKPW>& W = lds[wid];
+  const int idx = (vb.x * kWaves + wid) * kKPW + kl;
+  // bound-free early loads (arrays padded to the grid), issued before the parameter block is read
+  const float2 pi = nm.pos_img[idx];
+  const float2 rsq = nm.rs[idx];
+  const float2 gq = nm.grad[idx];
+  const float gnq = nm.gnorm[idx];
+  const int n = nm.st->n;
+  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
+  if (A.skip) return;
+  const bool live = idx < n;
+  SearchSetup S{};
+  if (live) S = search_setup(p, pi, rsq, gq, gnq, A.vel, A.Rvel, A.Rback, max_radius);
+  // ---- phase 1: the first kHeadSteps steps (edge_map.cpp:149-181). Slot 2 * step + side belongs to lane slot / kHP of the keyline;
+  // every lane walks both chains through all kHeadSteps steps (8 adds) and keeps the values of its own slots.
+  float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
+  float tq[kHP];
+  int cand[kHP];
+  {
+    int prow[kHP], pcol[kHP];
+#pragma unroll
+    for (int h = 0; h < kHP; ++h) {
+      prow[h] = -1;
+      pcol[h] = 0;
+      tq[h] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kHeadSteps; ++j) {
+      const bool active = live && j < S.t_steps;
+#pragma unroll
+      for (int i_idx = 0; i_idx < 2; ++i_idx) {
+        const int slot = 2 * j + i_idx;
+        const int h = slot % kHP;  // compile-time after unrolling
+        if (slot / kHP == sub) {
+          const float t = i_idx ? tp : tn;
+          const bool ok = active && (i_idx ? !(t > S.dq_max) : !(t < S.dq_min));
+          if (ok) {
+            const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
+            const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
+            if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) {
+              prow[h] = row;
+              pcol[h] = col;
+            }
+          }
+          tq[h] = t;
+        }
+      }
+      tp += 1.0f;
+      tn -= 1.0f;
+    }
+#pragma unroll
+    for (int h = 0; h < kHP; ++h) cand[h] = (prow[h] >= 0) ? om.mask[(size_t)prow[h] * p.cols + pcol[h]] : -1;
+  }
+  if (sub == 0) {
+    W.best[kl] = kDmcNone;
+    W.q_a[kl] = make_float4(S.norm_t, S.sigma2_t, gq.x, gq.y);
+    W.q_gn[kl] = gnq;
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int h = 0; h < kHP; ++h) cnt += (cand[h] >= 0) ? 1 : 0;
+  int T = 0;
+  int pos = wave_excl_scan_i(cnt, lane, &T);
+#pragma unroll
+  for (int h = 0; h < kHP; ++h) {
+    if (cand[h] >= 0) {
+      W.list[pos] = ((unsigned)cand[h] << 16) | ((unsigned)kl << 10) | (unsigned)(sub * kHP + h);
+      W.t1[pos] = tq[h];
+      ++pos;
+    }
+  }
+  wave_lds_sync();
+  dmc_test_list<false>(p, om, W, T, lane, A.rot, A.R0, 0);
+  int found = -1, kf = 0;
+  if (sub == 0 && W.best[kl] != kDmcNone) found = dmc_commit(nm, om, W, kl, idx, &kf);
+  // ---- phase 2: long searches still open (flagged on the first lane of the keyline)
+  const bool open = live && sub == 0 && found < 0 && S.t_steps > kHeadSteps;
+  const unsigned long long open_mask = __ballot(open);
+  const int n_open = __popcll(open_mask);
+  if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[49] = __builtin_amdgcn_s_memrealtime();
+  if (p.dbg) {  // REBVIO_HIP_LM_STAMPS: shape of the workload (printed by rebvio_hip_flush)
+    const int c_live = __popcll(__ballot(live && sub == 0)), c_long = __popcll(__ballot(live && sub == 0 && S.t_steps > kHeadSteps));
+    const int c_f1 = __popcll(__ballot(found >= 0));
+    if (live && sub == 0) atomicAdd(&p.dbg[80 + max(0, min(S.t_steps, 47))], 1ull);
+    if (lane == 0) {
+      if (vb.x == 0 && wid == 0) atomicAdd(&p.dbg[64], 1ull);
+      atomicAdd(&p.dbg[65], (unsigned long long)c_live);
+      atomicAdd(&p.dbg[66], (unsigned long long)c_long);
+      atomicAdd(&p.dbg[67], (unsigned long long)n_open);
+      atomicAdd(&p.dbg[68], (unsigned long long)T);
+      atomicMax(&p.dbg[70], (unsigned long long)n_open);
+      if (n_open > 16) atomicAdd(&p.dbg[71], 1ull);
+      if (n_open > 32) atomicAdd(&p.dbg[72], 1ull);
+      if (n_open > 0) atomicAdd(&p.dbg[73], 1ull);
+      atomicAdd(&p.dbg[74], (unsigned long long)c_f1);
+    }
+  }
+  // rank of this lane's keyline among the open ones (the same for all lanes of the keyline)
+  const int rank = __popcll(open_mask & ((1ull << (kl * kLPK)) - 1ull));
+  const bool kl_open = ((open_mask >> (kl * kLPK)) & 1ull) != 0ull;
+  for (int b0 = 0; b0 < n_open; b0 += kBatch) {
+    wave_lds_sync();  // (the previous batch's tables are still being read until here)
+    const bool mine = kl_open && rank >= b0 && rank < b0 + kBatch;  // all lanes of the batch's keylines
+    const int jj = rank - b0;
+    const int nb = min(kBatch, n_open - b0);
+    if (mine && sub == 0) {
+      W.s_a[jj] = make_float4(S.t_x, S.t_y, S.pi0x, S.pi0y);
+      W.s_b[jj] = make_float4(S.dq_min, S.dq_max, __int_as_float(S.t_steps), 0.f);
+      W.q_a[jj] = make_float4(S.norm_t, S.sigma2_t, gq.x, gq.y);
+      W.q_gn[jj] = gnq;
+      W.best[jj] = kDmcNone;
+    }
+    const int tmax = wave_max_i(mine ? S.t_steps : 0);
+    for (int step0 = kHeadSteps; step0 < tmax; step0 += kDmcWin) {
+      // the chains continue through this window (tn, tp stand at step0): with two or more lanes per keyline lane 0 walks tn and
+      // lane 1 tp (x - 1.0f and x + (-1.0f) are the same IEEE operation), a lone lane walks both
+      const int wlen = min(kDmcWin, tmax - step0);
+      if (kLPK >= 2) {
+        const bool writer = mine && sub < 2;
+        float x = sub == 1 ? tp : tn;
+        const float d = sub == 1 ? 1.0f : -1.0f;
+        float* dst = &W.seq[writer ? jj : 0][sub == 1 ? 1 : 0][0];
+        for (int s = 0; s < wlen; ++s) {
+          if (writer) dst[s] = x;
+          x += d;
+        }
+        if (mine && sub == 0) tn = x;
+        if (mine && sub == 1) tp = x;
+      } else {
+        for (int s = 0; s < wlen; ++s) {
+          if (mine) {  // (the owners of later batches keep their chains at step kHeadSteps)
+            W.seq[jj][0][s] = tn;
+            W.seq[jj][1][s] = tp;
+            tp += 1.0f;
+            tn -= 1.0f;
+          }
+        }
+      }
+      wave_lds_sync();
+      // probe slots of the batch, dealt to all 64 lanes: q -> (open keyline j, side, step); the first kDmcWin of a keyline's
+      // 2 * kDmcWin slots walk tn, the others tp, so that neighbouring lanes probe neighbouring pixels of one line
+      constexpr int kProbeIters = (kBatch * 2 * kDmcWin + 63) / 64;
+      int pc[kProbeIters];
+      unsigned pm[kProbeIters];
+      constexpr int per = 2 * kDmcWin;
+      const int nslots = nb * per;
+#pragma unroll
+      for (int i = 0; i < kProbeIters; ++i) {
+        const int q = i * 64 + lane;
+        int cd = -1;
+        unsigned mt = 0u;
+        if (i * 64 < nslots && q < nslots) {
+          const int j = q / per, s = q - j * per;
+          const int side = s >= kDmcWin ? 1 : 0, so = s - side * kDmcWin;
+          const int step = step0 + so;
+          const float4 sb = W.s_b[j];
+          if (so < wlen && step < __float_as_int(sb.z) && W.best[j] == kDmcNone) {
+            const float t = W.seq[j][side][so];
+            if (side ? !(t > sb.y) : !(t < sb.x)) {
+              const float4 sa = W.s_a[j];
+              const int row = cvtt_f32(roundf(sa.y * t + sa.w));
+              const int col = cvtt_f32(roundf(sa.x * t + sa.z));
+              if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) {
+                cd = om.mask[(size_t)row * p.cols + col];
+                mt = ((unsigned)j << 10) | (unsigned)(2 * step + side);
+              }
+            }
+          }
+        }
+        pc[i] = cd;
+        pm[i] = mt;
+      }
+      int c2 = 0;
+#pragma unroll
+      for (int i = 0; i < kProbeIters; ++i) c2 += (pc[i] >= 0) ? 1 : 0;
+      int T2 = 0;
+      int pos2 = wave_excl_scan_i(c2, lane, &T2);
+#pragma unroll
+      for (int i = 0; i < kProbeIters; ++i) {
+        if (pc[i] >= 0) {
+          W.list[pos2] = ((unsigned)pc[i] << 16) | pm[i];
+          ++pos2;
+        }
+      }
+      wave_lds_sync();
+      if (p.dbg && lane == 0) atomicAdd(&p.dbg[69], (unsigned long long)T2);
+      dmc_test_list<true>(p, om, W, T2, lane, A.rot, A.R0, step0);
+    }
+    if (mine && sub == 0 && W.best[jj] != kDmcNone) found = dmc_commit(nm, om, W, jj, idx, &kf);
+  }
+  // counters: wave -> workgroup (LDS) -> one global atomic per workgroup and counter (see k_directed_match)
+  const int c_found = __popcll(__ballot(found >= 0));
+  const int c_kf = __popcll(__ballot(kf != 0));
+  if (kWaves == 1) {
+    if (lane == 0) {
+      if (c_found) atomicAdd(&nm.st->dm_matches, c_found);
+      if (c_kf) atomicAdd(&nm.st->dm_kf, c_kf);
+      if (n_open) atomicAdd(&nm.st->dm_queued, n_open);
+    }
+  } else {
+    __shared__ int b_cnt[3];
+    if (threadIdx.x < 3) b_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0) {
+      if (c_found) atomicAdd(&b_cnt[0], c_found);
+      if (c_kf) atomicAdd(&b_cnt[1], c_kf);
+      if (n_open) atomicAdd(&b_cnt[2], n_open);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (b_cnt[0]) atomicAdd(&nm.st->dm_matches, b_cnt[0]);
+      if (b_cnt[1]) atomicAdd(&nm.st->dm_kf, b_cnt[1]);
+      if (b_cnt[2]) atomicAdd(&nm.st->dm_queued, b_cnt[2]);
+    }
+  }
+}
+
+template <int kThreads, int kLPK>
+__global__ __launch_bounds__(kThreads) void k_directed_match_c(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
+                                                               float max_radius, int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
+  directed_match_c_body<kThreads, kLPK>(p, nm, om, vel_, Rvel_, Rback_, max_radius, rot_, R0_, gd);
+}
+template <int kThreads, int kLPK>
+__global__ __launch_bounds__(kThreads) void k_directed_match_c_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
+                                                                 LaneDynB dyn, float max_radius) {
+  const LaneStatic& L = ls[blockIdx.z];
+  const LaneDyn d = dyn.v[blockIdx.z];
+  const Vec3 z3{};
+  const Mat3 z9{};
+  directed_match_c_body<kThreads, kLPK>(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)),
+                                        global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9, max_radius, 1, z9,
+                                        gptr(L.glue_dev) + d.slot);
+}
+
 // ---- EdgeMap::searchMatch as a public single-keyline call (edge_map.hpp:93-94, edge_map.cpp:101-184) ----------------
 // One lane walks the reference's alternating probe sequence with the same set-up / acceptance code as the directedMatch
 // kernels (vel / Rvel as given: directedMatch rotates them by Rback before it calls searchMatch, edge_map.cpp:193-194).
@@ -2871,6 +3232,18 @@ static int dm_tail_blocks(int kmax) { return std::max(512, std::min(1024, kmax /
 // eightfold redundant probe set-up: a win while the launch is latency-bound on a mostly idle chip (16k keylines: 11.6 vs
 // 13.8 us), a loss once the eight-fold grid fills it (64k keylines: 36 vs 24 us). head_form: 0 by map size, 1 thread per
 // keyline, 2 eight lanes per keyline (REBVIO_HIP_DM_HEAD, read when the context is created).
+// head_form 3 / 4 / 5 / 6: the compact one-launch form (k_directed_match_c): 4 lanes per keyline in 256- / 128- / 64-thread
+// workgroups (3, 4, 6), one lane per keyline in 64-thread workgroups (5)
+static bool dm_compact(int head_form) { return head_form >= 3 && head_form <= 6; }
+#define RH_DMC_DISPATCH(KERNEL, head_form, kmax, zdim, stream, ...)                                                              \
+  do {                                                                                                                           \
+    switch (head_form) {                                                                                                         \
+      case 3: RH_LAUNCH((KERNEL<256, 4>), dim3(div_up(kmax, 64), 1, zdim), dim3(256), 0, stream, __VA_ARGS__); break;            \
+      case 4: RH_LAUNCH((KERNEL<128, 4>), dim3(div_up(kmax, 32), 1, zdim), dim3(128), 0, stream, __VA_ARGS__); break;            \
+      case 6: RH_LAUNCH((KERNEL<64, 4>), dim3(div_up(kmax, 16), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;              \
+      default: RH_LAUNCH((KERNEL<64, 1>), dim3(div_up(kmax, 64), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;             \
+    }                                                                                                                            \
+  } while (0)
 static bool dm_head_wide(int kmax, int head_form) {
   if (head_form) return head_form == 2;
   return kmax <= 32768;
@@ -2883,6 +3256,11 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
   const int rot = R0_on_the_fly ? 1 : 0;
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
+  if (dm_compact(head_form)) {
+    RH_DMC_DISPATCH(k_directed_match_c, head_form, p.kmax, 1, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius, rot, R0,
+                    (const GlueDev*)nullptr);
+    return;
+  }
   if (dm_head_wide(p.kmax, head_form))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback),
               max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr);
@@ -2898,6 +3276,10 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
 void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
                                int* work, int* work_n, int head_form) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+  if (dm_compact(head_form)) {
+    RH_DMC_DISPATCH(k_directed_match_c, head_form, p.kmax, 1, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, 1, mat3(I), gd);
+    return;
+  }
   if (dm_head_wide(p.kmax, head_form))
     RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
               work, work_n, 1, mat3(I), gd);
@@ -2978,6 +3360,11 @@ void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStat
   // full and the thread-per-keyline form (an eighth of the waves) is the cheaper one (REBVIO_HIP_BATCH_DM_HEAD=wide|thread,
   // read when the batch is created)
   const bool wide = head_form ? head_form == 2 : (lanes < 4 && p.kmax <= 32768);
+  if (dm_compact(head_form)) {
+    RH_DMC_DISPATCH(k_directed_match_c_b, head_form, p.kmax, z, s, p, ls, maptab, dyn, max_radius);
+    RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
+    return;
+  }
   if (wide)
     RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
   else

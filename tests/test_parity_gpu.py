@@ -347,8 +347,10 @@ def c3_stream():
 KW_C3 = dict(keylines_ref=60000, keylines_max=64000, threshold=0.006)
 
 
-@pytest.mark.parametrize("config,head", [("c2", None), ("c2", "thread"), ("c3", None), ("c3", "wide")],
-                         ids=["c2-default(wide)", "c2-thread-head", "c3-64k-default(thread)", "c3-64k-wide-head"])
+@pytest.mark.parametrize("config,head", [("c2", None), ("c2", "thread"), ("c3", None), ("c3", "wide"), ("c2", "compact"), ("c2", "compact128"),
+                                         ("c2", "compact64"), ("c2", "compact1"), ("c3", "compact"), ("c3", "compact1")],
+                         ids=["c2-default(wide)", "c2-thread-head", "c3-64k-default(thread)", "c3-64k-wide-head", "c2-compact", "c2-compact128",
+                              "c2-compact64", "c2-compact1", "c3-64k-compact", "c3-64k-compact1"])
 def test_directed_match_regularize_ekf_bit_exact(orc_mod, B, c2_stream, c3_stream, monkeypatch, config, head):
     """directedMatch / searchMatch (edge_map.cpp:101-218), regularize1Iter, depth EKF on maps synced from the oracle: every
     keyline field bit-exact, counters equal - for BOTH forms of the directedMatch head (eight lanes per keyline,
