@@ -86,13 +86,14 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         "k_ext_rot_vel": 130 * N,
         "k_directed_match": 192 * N,
         "k_directed_match8": 192 * N,     # eight lanes per keyline: same compulsory bytes
+        "k_directed_match_c": 192 * N,    # one-launch compact form (round 4): head probes and long searches, same compulsory bytes
         "k_regularize": 60 * N,
         "k_depth_ekf": 48 * N,
     }
-    base = kernel.split("<")[0] if kernel.startswith(("k_lm_chain", "k_df_tiles", "k_df_lists")) else kernel
+    base = kernel.split("<")[0] if kernel.startswith(("k_lm_chain", "k_df_tiles", "k_df_lists", "k_directed_match_c")) else kernel
     # same work under other names: the speculative LM kernel, the four-column column pass, the batched (_b) forms
     base = {"k_lm_chain_spec": "k_lm_chain", "k_lm_chain_spec_b": "k_lm_chain", "k_lm_chain_b": "k_lm_chain",
-            "k_colscan4": "k_colscan"}.get(base, base)
+            "k_colscan4": "k_colscan", "k_directed_match_c_b": "k_directed_match_c"}.get(base, base)
     return float(table.get(base, 0))
 
 
@@ -147,6 +148,8 @@ def self_launch(n: int, argv) -> int:
     `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE itself and never comes here.)"""
     import socket
     import subprocess
+    if "--no-cpu-baseline" not in argv:
+        build_cpu_oracle()  # once, before the ranks exist: they find it up to date (and would serialise on its lock otherwise)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -164,6 +167,27 @@ def self_launch(n: int, argv) -> int:
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     return 0
+
+
+def build_cpu_oracle():
+    """The -march=native build of the CPU restatement for THIS host (oracle_py.build: file lock around make, real prerequisites,
+    the library renamed into place), or None when it cannot be built - the baseline leg then uses the portable build."""
+    from oracle import oracle_py as O
+    try:
+        return O.build(native=True)
+    except Exception as e:
+        print(f"native CPU oracle not built ({e}); using the portable build", file=sys.stderr)
+        return None
+
+
+def build_cpu_oracle_ranked(rank, world, barrier):
+    """N ranks under a launcher: rank 0 builds, the others wait at a barrier and then find the library up to date."""
+    path = build_cpu_oracle() if rank == 0 else None
+    if world > 1:
+        barrier()
+        if rank != 0:
+            path = build_cpu_oracle()
+    return path
 
 
 def main():
@@ -221,9 +245,21 @@ def main():
         if world > 1:
             dist.barrier()
         tmax = shard.max_over_ranks(float(rank + 1), world, "cpu")
+        # the CPU-baseline leg's build + load path, as every rank of a real run takes it (no GPU needed)
+        oracle_ok = 0.0
+        if not args.no_cpu_baseline:
+            from oracle import oracle_py as O
+            path = build_cpu_oracle_ranked(rank, world, dist.barrier)
+            try:
+                O.Oracle(O.default_params(48, 64), path)
+                oracle_ok = 1.0
+            except Exception as e:
+                print(f"[rank {rank}] CPU oracle not loadable: {e}", file=sys.stderr)
+        loaded = shard.sum_over_ranks(oracle_ok, world, "cpu") if world > 1 else oracle_ok
         if rank == 0:
             os.dup2(real_stdout, 1)
-            print(json.dumps({"metric": "control plane rehearsal", "value": None, "n_gpus": world, "max_over_ranks": tmax}),
+            print(json.dumps({"metric": "control plane rehearsal", "value": None, "n_gpus": world, "max_over_ranks": tmax,
+                              "cpu_oracle_loaded_ranks": int(loaded)}),
                   flush=True)
             os.dup2(2, 1)
         if world > 1:
@@ -393,6 +429,7 @@ def main():
     # time; rank 0 reports the sum. (N = 1: rank 0's own leg below, with the serial figure and the stage split.)
     cpu_multi = None
     if world > 1 and not args.no_cpu_baseline:
+        build_cpu_oracle_ranked(rank, world, dist.barrier)  # rank 0 builds, the others find it up to date
         mine = cpu_baseline(frames, cam, cfg, args.base_frames, min(args.cpu_seconds, 10.0), serial_leg=False)
         tot = shard.sum_over_ranks(mine["value"], world, "cuda" if backend_name == "nccl" else "cpu")
         cpu_multi = {"value": tot, "unit": "frames/s", "cores": 2 * world, "kind": "port",
@@ -600,14 +637,16 @@ def cpu_baseline(frames, cam, cfg, base_frames, seconds, serial_leg=True):
     leg's own, and every rate is frames actually run / seconds measured."""
     from oracle import oracle_py as O
     from rebvio_amd import synth
-    try:
-        path = O.build(native=True)  # -O3 -march=native for the machine the bench runs on
-    except Exception:
-        path = None
+    path = build_cpu_oracle()  # -O3 -march=native for the machine the bench runs on (a no-op when a rank built it already)
     kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=cfg["keylines_ref"], keylines_max=cfg["keylines_max"])
     p = O.default_params(cam.height, cam.width, **kw)
     probe_idx = synth.pingpong_indices(base_frames, 24)
-    probe = O.Oracle(p, path).run_stream(frames, probe_idx, threads=2)
+    try:
+        probe = O.Oracle(p, path).run_stream(frames, probe_idx, threads=2)
+    except OSError as e:  # the native library could not be loaded (built for another host, or damaged): the portable build
+        print(f"native CPU oracle not loadable ({e}); using the portable build", file=sys.stderr)
+        path = None
+        probe = O.Oracle(p, path).run_stream(frames, probe_idx, threads=2)
     per = probe["seconds"] / probe["frames"]
     n2 = int(min(max(seconds * (2.0 / 3.0) / per, 30), 1000))
     idx2 = synth.pingpong_indices(base_frames, n2)

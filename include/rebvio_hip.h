@@ -318,6 +318,16 @@ int rebvio_hip_test_glue(rebvio_hip_ctx* ctx, const float vel[3], const float Jt
                          rebvio_hip_pair_out* out_dev, float* state_dev, float* second_dev, rebvio_hip_pair_out* out_host,
                          float* state_host, float* second_host);
 
+/* Test hook for the sequence stamps of the host-visible pair records. Every pair the library queues carries a non-zero sequence
+ * number; the pair's kernels store it as the LAST word of each record they write into host-visible memory (result slot, glue
+ * record), and every entry that reads such a record - rebvio_hip_track_pair, _track_pair_begin, _push_frame_u8(_device),
+ * _next_record's producer, _flush and the batch forms - compares it first: a record read before its pair wrote it (a completion
+ * event or a synchronisation that reported too early) fails with status -12 instead of handing out stale poses. This hook hands
+ * the kernels of the NEXT pair (batch: the last lane of the next step) a wrong number, which is exactly what such a record looks
+ * like to the reader. */
+int rebvio_hip_test_forge_record_stamp(rebvio_hip_ctx* ctx);
+int rebvio_hip_batch_test_forge_record_stamp(rebvio_hip_batch* b);
+
 /* Per-kernel device timing of the last N launches of each kernel, measured with HIP events on the
  * stream the kernel runs on. names: '\n'-separated. Used by bench.py's roofline leg. */
 int rebvio_hip_profile_enable(rebvio_hip_ctx* ctx, int on); /* 0 off, 1 every launch, N>1 every N-th launch */

@@ -49,11 +49,38 @@ class VioOut(C.Structure):
                 ("sab_active", C.c_int)]
 
 
+def host_cpu_tag() -> str:
+    """A short tag of this host's CPU (model name + feature flags): -march=native code is only valid where it was built."""
+    import hashlib
+    import platform
+    text = platform.machine()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith(("model name", "flags")):
+                    text += ln
+                if ln.startswith("flags"):
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1(text.encode()).hexdigest()[:12]
+
+
 def build(native: bool = False) -> str:
-    """Compile the oracle with gcc (oracle/Makefile) and return the .so path."""
-    target = ["native"] if native else []
-    subprocess.run(["make", "-s", "-C", _HERE] + target, check=True)
-    sub = "_build/native" if native else "_build"
+    """Compile the oracle with gcc (oracle/Makefile) and return the .so path. Safe to call from several processes at once
+    (the ranks of `bench.py --gpus N`): the make run is serialised by a file lock, the targets have real prerequisites (the
+    second caller finds the library up to date) and the Makefile renames a finished library into place."""
+    import fcntl
+    tag = host_cpu_tag()
+    target = ["native", f"NATIVE_TAG={tag}"] if native else []
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(os.path.join(_HERE, "_build", ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-s", "-C", _HERE] + target, check=True)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+    sub = f"_build/native-{tag}" if native else "_build"
     return os.path.join(_HERE, sub, "librebvio_oracle.so")
 
 

@@ -115,6 +115,8 @@ SIGNATURES = {
     "rebvio_hip_batch_flush": (C.c_int, [_vp]),
     "rebvio_hip_test_glue": (C.c_int, [_vp, _fp, _fp, C.c_float, C.c_float, C.c_int, _fp, C.c_int, C.c_float, _fp, _fp, _fp,
                                       C.POINTER(PairOut), _fp, _fp, C.POINTER(PairOut), _fp, _fp]),
+    "rebvio_hip_test_forge_record_stamp": (C.c_int, [_vp]),
+    "rebvio_hip_batch_test_forge_record_stamp": (C.c_int, [_vp]),
     "rebvio_hip_profile_enable": (C.c_int, [_vp, C.c_int]),
     "rebvio_hip_profile_select": (C.c_int, [_vp, C.c_char_p]),
     "rebvio_hip_profile_reset": (C.c_int, [_vp]),

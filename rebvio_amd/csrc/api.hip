@@ -33,8 +33,8 @@ thread_local const SharedStreams* t_adopt_streams = nullptr;
 
 // REBVIO_HIP_DM_HEAD / REBVIO_HIP_BATCH_DM_HEAD -> form of the directedMatch launch (track.hip: dm_head_wide, dm_compact)
 int dm_form_by_name(const char* e) {
-  static const char* const names[] = {"", "thread", "wide", "compact", "compact128", "compact1", "compact64"};
-  for (int i = 1; i < 7; ++i)
+  static const char* const names[] = {"", "thread", "wide", "compact", "compact128", "compact1", "compact64", "compact8", "compact8s"};
+  for (int i = 1; i < 9; ++i)
     if (std::strcmp(e, names[i]) == 0) return i;
   return 0;
 }
@@ -255,6 +255,8 @@ struct rebvio_hip_ctx {
   float lm_miss3_ema = 0.f;     // ... "a step after the second was accepted" (the hypothesis of kf = 3 failed)
   int* lm_bar_err = nullptr;  // pinned, zero-copy
   unsigned long long* lm_stamps = nullptr;  // pinned; REBVIO_HIP_LM_STAMPS diagnostic (phase stamps of workgroup 0)
+  unsigned long long* dm_stats = nullptr;   // device; REBVIO_HIP_DM_STATS diagnostic (workload shape + per-wave phase times of k_directed_match_c)
+  size_t dm_stats_words = 0;
   double lm_stamp_acc[64]{};
   uint64_t lm_stamp_n = 0;
   bool lm_stamp_spec = false;
@@ -286,8 +288,16 @@ struct rebvio_hip_ctx {
   int min_pool = 0;               // edge maps to allocate before one is reused (see acquire_map)
   int lead = 5;                   // detected frames queued when a pair is started (REBVIO_HIP_LEAD 3..12, see push_frame)
   int group = 4;                  // pairs queued together (REBVIO_HIP_GROUP 1..6, see stream_enqueue_group)
+  // Sequence stamps of the host-visible records (PairSlot::seq, GlueRec::seq_gs / seq_out): every pair that is queued takes
+  // the next non-zero value, its kernels store it behind everything else they write into the records, and whoever reads a
+  // record compares. A record read before its pair ran (an event or a synchronisation that reported too early - seen once with
+  // kernel-bound stop events) still holds its previous user's stamp: status -12 instead of silently stale poses.
+  uint32_t stamp_seq = 0;         // last value handed out
+  uint32_t last_stamp = 0;        // stamp of the pair enqueue_pair_lm queued last
+  bool forge_stamp = false;       // rebvio_hip_test_forge_record_stamp: the next pair's kernels are handed a wrong stamp
   struct InFlight {               // a pair whose kernels are queued and whose record has not been read yet
     rebvio_hip_map* nm = nullptr;
+    uint32_t seq = 0;             // its sequence stamp
     int slot = -1;
     int ev_slot = -1;             // the slot whose event stands for this pair's completion (its group's last pair)
     float frame_dt = 0.f;
@@ -757,13 +767,27 @@ void enqueue_lm_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm,
 // xrv_dst: where the extRotVel block records go - the pinned slot's tail (per-pair API: the host sums them) or device
 // memory (streaming driver: the device glue sums them).
 // ga.lm != null: the pair's glue runs on the device behind the extRotVel sums (streaming driver).
+uint32_t next_stamp(uint32_t* counter) {
+  if (++*counter == 0u) ++*counter;  // (zero is what a never-written record holds)
+  return *counter;
+}
+constexpr int kStaleRecord = -12;
+const char* const kStaleRecordMsg = "a pair's record was read before the device had written it (sequence stamp mismatch)";
+
 int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3], PairSlot* slot, float* xrv_dst,
-                    const GlueArgs& ga) {
+                    const GlueArgs& ga_in) {
   const int calls = (int)c->P.iterations + 1;
+  GlueArgs ga = ga_in;
+  c->last_stamp = next_stamp(&c->stamp_seq);
+  ga.seq = c->last_stamp;
+  if (c->forge_stamp) {  // test hook: what a record looks like when it is read before its pair wrote it
+    ga.seq ^= 0x40000000u;
+    c->forge_stamp = false;
+  }
   if (!c->lm_persistent) {
     enqueue_lm_chain(c, om, nm, vel0);
     launch_ext_rot_vel(c->s_trk, c->K, om->d, nm->d, 1, 1, calls, c->lm + calls, c->lm + calls + 1,
-                       c->part + (size_t)(calls - 1) * part_call_stride(c), xrv_dst, vel0, slot, c->hist);
+                       c->part + (size_t)(calls - 1) * part_call_stride(c), xrv_dst, vel0, slot, c->hist, ga.seq);
     if (ga.lm) launch_pair_glue(c->s_trk, nm->d, ga);
     return 0;
   }
@@ -1048,9 +1072,15 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipHostMalloc(&c->lm_bar_err, 8 * sizeof(int), hipHostMallocDefault));
   std::memset(c->lm_bar_err, 0, 8 * sizeof(int));
   if (std::getenv("REBVIO_HIP_LM_STAMPS")) {
-    HIPCHK(hipHostMalloc(&c->lm_stamps, 128 * sizeof(unsigned long long), hipHostMallocDefault));
-    std::memset(c->lm_stamps, 0, 128 * sizeof(unsigned long long));
+    HIPCHK(hipHostMalloc(&c->lm_stamps, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    std::memset(c->lm_stamps, 0, 64 * sizeof(unsigned long long));
     K.dbg = c->lm_stamps;
+    if (std::getenv("REBVIO_HIP_DM_STATS")) {
+      c->dm_stats_words = 16 * (size_t)(p->keylines_max / 8 + 130);
+      HIPCHK(hipMalloc(&c->dm_stats, c->dm_stats_words * sizeof(unsigned long long)));
+      HIPCHK(hipMemset(c->dm_stats, 0, c->dm_stats_words * sizeof(unsigned long long)));
+      K.dm_stats = c->dm_stats;
+    }
   }
   // REBVIO_HIP_LM = percall (one kernel per evaluation) | seq (persistent kernel, one evaluation per exchange round) |
   // anything else / unset: persistent kernel with the speculative reject chain (track.hip, k_lm_chain_spec)
@@ -1196,6 +1226,7 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   if (c->glue_dev) (void)hipFree(c->glue_dev);
   if (c->lm_bar_err) (void)hipHostFree(c->lm_bar_err);
   if (c->lm_stamps) (void)hipHostFree(c->lm_stamps);
+  if (c->dm_stats) (void)hipFree(c->dm_stats);
   for (auto& e : c->bf_done)
     if (e) (void)hipEventDestroy(e);
   if (c->h_bf) (void)hipHostFree(c->h_bf);
@@ -1765,6 +1796,7 @@ int rebvio_hip_track_pair(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map*
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
+  if (slot->seq != c->last_stamp) return fail_msg(kStaleRecordMsg, kStaleRecord);
   nm->n_host = slot->new_st.n;
   nm->thr_host = slot->new_st.threshold;
   const GlueOut g = pair_glue(c, slot->lm, slot->xrv, nm->n_host, frame_dt, R, out);
@@ -1833,6 +1865,7 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   c->t_begin_enq += std::chrono::duration<double, std::micro>(tb1 - tb0).count();
   c->t_begin_wait += std::chrono::duration<double, std::micro>(tb2 - tb1).count();
   c->t_begin_n++;
+  if (slot->seq != c->last_stamp) return fail_msg(kStaleRecordMsg, kStaleRecord);
   if (prev_from_slot) {
     c->h_bf[pr] = slot->old_st;
     c->bf_have[pr] = true;
@@ -1944,8 +1977,9 @@ namespace {
 // read from the NEXT pair's slot (its first kernel copies its old map's state record), so pair k is reported once pair
 // k + 1's event has fired; rebvio_hip_flush() fetches the last pair's counters itself.
 
-void stream_finish_record(rebvio_hip_ctx* c, const rebvio_hip_ctx::InFlight& a, const MapState& st) {
+int stream_finish_record(rebvio_hip_ctx* c, const rebvio_hip_ctx::InFlight& a, const MapState& st) {
   const GlueRec* r = c->rec[a.slot];
+  if (r->seq_out != a.seq || r->seq_gs != a.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);
   rebvio_hip_ctx::Done d;
   d.out = r->out;
   if (d.out.status != 1) {
@@ -1962,6 +1996,7 @@ void stream_finish_record(rebvio_hip_ctx* c, const rebvio_hip_ctx::InFlight& a, 
   note_accept_mask(c, d.out.lm_accept_mask);
   c->t_queued += (double)st.dm_queued;
   c->done.push_back(d);
+  return 0;
 }
 
 // Reports the pairs whose successor has completed; `need` > 0: blocks until at least that many have been reported.
@@ -1979,7 +2014,9 @@ int stream_harvest(rebvio_hip_ctx* c, int need) {
       HIPCHK(q);
     }
     if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
-    stream_finish_record(c, a, c->slot[b.slot]->old_st);
+    if (c->slot[b.slot]->seq != b.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);  // (pair a's counters ride in pair b's slot)
+    const int frc = stream_finish_record(c, a, c->slot[b.slot]->old_st);
+    if (frc) return frc;
     c->inflight.pop_front();
     --need;
   }
@@ -2061,6 +2098,7 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     HIPCHK(hipGetLastError());
     rebvio_hip_ctx::InFlight f;
     f.nm = nm;
+    f.seq = c->last_stamp;
     f.slot = slot;
     f.ev_slot = -1;
     f.frame_dt = frame_dt;
@@ -2087,7 +2125,9 @@ int stream_drain(rebvio_hip_ctx* c) {
     if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
     HIPCHK(hipMemcpyAsync(&c->h_st[1], a.nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
     HIPCHK(hipStreamSynchronize(c->s_trk));
-    stream_finish_record(c, a, c->h_st[1]);
+    if (c->slot[a.slot]->seq != a.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);
+    const int frc = stream_finish_record(c, a, c->h_st[1]);
+    if (frc) return frc;
     c->inflight.pop_front();
   }
   return 0;
@@ -2164,6 +2204,15 @@ int rebvio_hip_push_frame_u8(rebvio_hip_ctx* c, const uint8_t* frame_host, size_
 
 uint64_t rebvio_hip_pairs_started(rebvio_hip_ctx* c) { return c->pair_seq; }
 
+// Test hook: the kernels of the NEXT pair this context queues (per-pair API or streaming driver) are handed a wrong sequence
+// stamp, so its records look exactly like records read before the pair wrote them; the call that reads them must fail with -12.
+int rebvio_hip_test_forge_record_stamp(rebvio_hip_ctx* c) {
+  if (!c) return -3;
+  c->forge_stamp = true;
+  return 0;
+}
+
+
 int rebvio_hip_next_record(rebvio_hip_ctx* c, rebvio_hip_pair_out* out, int* keylines) {
   if (c->done.empty()) return 0;
   if (out) *out = c->done.front().out;
@@ -2199,15 +2248,33 @@ int rebvio_hip_flush(rebvio_hip_ctx* c) {
                    (double)c->lm_stamps[42] * m, (double)c->lm_stamps[43] * m, (double)c->lm_stamps[44] * m, (double)c->lm_stamps[45] * m,
                    (double)c->lm_stamps[56] * m);
     }
-    if (c->lm_stamps[64]) {
-      const unsigned long long* d = c->lm_stamps;
-      const double m = 1.0 / (double)d[64];
-      std::fprintf(stderr, "[rebvio_hip]   directedMatch (compact) per launch: keylines %.0f  t_steps > %d: %.0f  matched in the head %.0f  long searches %.0f  "
-                   "head candidates %.0f  long-search candidates %.0f | waves with long searches %.1f  with > 16: %.1f  > 32: %.1f  max per wave %llu\n",
-                   d[65] * m, 4, d[66] * m, d[74] * m, d[67] * m, d[68] * m, d[69] * m, d[73] * m, d[71] * m, d[72] * m, d[70]);
-      std::fprintf(stderr, "[rebvio_hip]   t_steps histogram (per launch):");
-      for (int i = 0; i < 48; ++i) std::fprintf(stderr, " %d:%.0f", i, d[80 + i] * m);
-      std::fprintf(stderr, "\n");
+    if (c->dm_stats) {  // per-wave records of the LAST k_directed_match_c launch
+      std::vector<unsigned long long> h(c->dm_stats_words);
+      (void)hipMemcpy(h.data(), c->dm_stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      const size_t nw = std::min((size_t)h[0], c->dm_stats_words / 16 - 1);
+      double sum[14] = {0}, mx[14] = {0}, slow = 0;
+      size_t with_open = 0;
+      for (size_t w = 0; w < nw; ++w) {
+        const unsigned long long* r = &h[16 * (w + 1)];
+        double tot = 0;
+        for (int i = 0; i < 14; ++i) {
+          sum[i] += (double)r[i];
+          mx[i] = std::max(mx[i], (double)r[i]);
+          if (i < 7) tot += (double)r[i];
+        }
+        slow = std::max(slow, tot);
+        with_open += r[11] ? 1 : 0;
+      }
+      if (nw) {
+        static const char* const seg[7] = {"set-up + head probes issued", "mask loads back + scan", "head candidates tested", "chains walked",
+                                           "long probes issued", "mask loads back + scan", "long candidates tested"};
+        std::fprintf(stderr, "[rebvio_hip]   directedMatch (compact), last launch, %zu waves: keylines %.0f  t_steps > 4: %.0f  matched in the head %.0f  long "
+                     "searches %.0f (max per wave %.0f, waves with any %zu)  head candidates %.0f (max %.0f)  long-search candidates %.0f (max %.0f)\n",
+                     nw, sum[8], sum[9], sum[10], sum[11], mx[11], with_open, sum[12], mx[12], sum[13], mx[13]);
+        std::fprintf(stderr, "[rebvio_hip]   per wave, us mean / max:");
+        for (int i = 0; i < 7; ++i) std::fprintf(stderr, "  %s %.2f / %.2f", seg[i], sum[i] * 0.01 / (double)nw, mx[i] * 0.01);
+        std::fprintf(stderr, "  | slowest wave %.2f\n", slow * 0.01);
+      }
     }
   } else if (c->lm_stamps && c->lm_stamp_n) {
     const int calls = (int)c->P.iterations + 1;
@@ -2317,6 +2384,7 @@ int rebvio_hip_test_glue(rebvio_hip_ctx* c, const float vel[3], const float JtJ6
   ga.st_out = d_st + 1;
   ga.rec = d_rec;
   ga.gd_copy = d_gl;
+  ga.seq = 1u;
   ga.gp = glue_params(c, frame_dt);
   launch_pair_glue(c->s_trk, fake, ga);
   HIPCHK(hipGetLastError());
@@ -2438,6 +2506,7 @@ struct rebvio_hip_batch {
   std::deque<Frame> frames;
   struct InFlight {  // a step's pairs (one per lane) whose kernels are queued and whose records have not been read yet
     Frame nf;
+    uint32_t seq = 0;  // the step's sequence stamp (all lanes)
     int slot = -1;
     int ev_slot = -1;  // the slot whose event stands for this step's completion (its group's last step)
   };
@@ -2448,6 +2517,8 @@ struct rebvio_hip_batch {
   std::deque<InFlight> inflight;
   std::deque<Done> done;
   uint64_t pair_seq = 0;
+  uint32_t stamp_seq = 0;   // sequence stamps of the lanes' records, one value per step (rebvio_hip_ctx::stamp_seq)
+  bool forge_stamp = false;
   int lead = 4;
   int group = 2;          // steps queued together (REBVIO_HIP_BATCH_GROUP 1..4, see stream_enqueue_group)
   int lm_lanes_per_launch = 1;  // lanes whose LM workgroups the device holds together (lm_chain_b_max_lanes)
@@ -2563,7 +2634,11 @@ void batch_det_worker(rebvio_hip_batch* b) {
   }
 }
 
-void batch_finish_records(rebvio_hip_batch* b, const rebvio_hip_batch::InFlight& a, const MapState* st_of_lane /*[B]*/) {
+int batch_finish_records(rebvio_hip_batch* b, const rebvio_hip_batch::InFlight& a, const MapState* st_of_lane /*[B]*/) {
+  for (int l = 0; l < b->B; ++l) {
+    const GlueRec* r = b->lane[l]->rec[a.slot];
+    if (r->seq_out != a.seq || r->seq_gs != a.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);
+  }
   rebvio_hip_batch::Done d;
   d.out.resize((size_t)b->B);
   d.keylines.resize((size_t)b->B);
@@ -2586,6 +2661,7 @@ void batch_finish_records(rebvio_hip_batch* b, const rebvio_hip_batch::InFlight&
     note_accept_mask(c, o.lm_accept_mask);
   }
   b->done.push_back(std::move(d));
+  return 0;
 }
 
 // as stream_harvest, for all lanes of a step at once (one event per step)
@@ -2605,9 +2681,11 @@ int batch_harvest(rebvio_hip_batch* b, int need) {
     }
     for (int l = 0; l < b->B; ++l) {
       if (*b->lane[l]->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
+      if (b->lane[l]->slot[n.slot]->seq != n.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);  // (step a's counters ride in step n's slots)
       st[(size_t)l] = b->lane[l]->slot[n.slot]->old_st;
     }
-    batch_finish_records(b, a, st.data());
+    const int frc = batch_finish_records(b, a, st.data());
+    if (frc) return frc;
     b->inflight.pop_front();
     --need;
   }
@@ -2635,11 +2713,13 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
     const rebvio_hip_batch::Frame of = b->frames[0], nf = b->frames[1];
     const int slot = (int)(b->pair_seq % rebvio_hip_ctx::kSlots);
     const int gpar = (int)(b->pair_seq & 1);
+    const uint32_t step_seq = next_stamp(&b->stamp_seq);
     LaneDynB dyn{};
     for (int l = 0; l < b->B; ++l) {
       rebvio_hip_ctx* c = b->lane[l];
       rebvio_hip_map *om = of.m[l], *nm = nf.m[l];
       c->df_map = nm;
+      dyn.v[l].seq = (b->forge_stamp && l == b->B - 1) ? (step_seq ^ 0x40000000u) : step_seq;
       if (!om->pre_rotated) {  // first pair of the lane: no second half has applied the prior rotation yet; the host's state goes up
         const hm::M3 R = prior_rotation(c, nullptr);
         GlueState& gs = c->h_gstate[gpar];
@@ -2687,8 +2767,10 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
       std::swap(nm->d.grad, nm->d.grad_tmp);
       nm->pre_rotated = true;
     }
+    b->forge_stamp = false;
     rebvio_hip_batch::InFlight f;
     f.nf = nf;
+    f.seq = step_seq;
     f.slot = slot;
     f.ev_slot = -1;
     b->inflight.push_back(f);
@@ -2713,9 +2795,11 @@ int batch_drain(rebvio_hip_batch* b) {
     std::vector<MapState> st((size_t)b->B);
     for (int l = 0; l < b->B; ++l) {
       if (*b->lane[l]->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
+      if (b->lane[l]->slot[a.slot]->seq != a.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);
       HIPCHK(hipMemcpy(&st[(size_t)l], a.nf.m[l]->d.st, sizeof(MapState), hipMemcpyDeviceToHost));
     }
-    batch_finish_records(b, a, st.data());
+    const int frc = batch_finish_records(b, a, st.data());
+    if (frc) return frc;
     b->inflight.pop_front();
   }
   return 0;
@@ -2880,6 +2964,13 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
 }
 
 int rebvio_hip_batch_lanes(rebvio_hip_batch* b) { return b->B; }
+
+// as rebvio_hip_test_forge_record_stamp, for the last lane of the next step
+int rebvio_hip_batch_test_forge_record_stamp(rebvio_hip_batch* b) {
+  if (!b) return -3;
+  b->forge_stamp = true;
+  return 0;
+}
 rebvio_hip_ctx* rebvio_hip_batch_lane(rebvio_hip_batch* b, int lane) { return (lane >= 0 && lane < b->B) ? b->lane[lane] : nullptr; }
 
 int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* frames_dev, uint64_t ts_us, rebvio_hip_pair_out* out,

@@ -99,6 +99,7 @@ struct KParams {
   int nseg;  // ceil(cols / 64)
   int df_nr; // 2 * search_range
   unsigned long long* dbg;  // REBVIO_HIP_LM_STAMPS: pinned stamp buffer (null otherwise); [48..50] = start of the pair's second-half kernels
+  unsigned long long* dm_stats;  // REBVIO_HIP_DM_STATS: device buffer, one 16-word record per wave of k_directed_match_c (workload + phase times)
 };
 
 // Levenberg-Marquardt state of minimizeVel kept on the device (core.cpp:150-189).
@@ -178,6 +179,8 @@ struct PairSlot {
   LmState lm;          // final minimizeVel state
   MapState new_st;     // snapshot of the new map's scalars
   MapState old_st;     // snapshot of the old map's scalars (directedMatch / regularize counters of the previous pair)
+  unsigned seq;        // sequence stamp of the pair that wrote this slot: the LAST word its kernel stores (system-scope release), so a
+  unsigned pad_[3];    // host that reads the slot before the pair has run sees the previous user's stamp and reports -12
   float xrv[1];        // [nblocks][kXrvStride] block records follow
 };
 // Result of the host glue of one pair (rebvio.cpp:186-233) as the second half of the pair step reads it from memory
@@ -205,6 +208,7 @@ struct GlueState {
 struct GlueRec {
   rebvio_hip_pair_out out;  // counters / status are filled in by the host from the map state records
   GlueState gs;             // state AFTER this pair (the host mirrors it: rebvio_hip_get_gyro_state)
+  unsigned seq_gs, seq_out; // sequence stamps behind `gs` and behind `out` (two waves of the glue write them; see PairSlot::seq)
 };
 
 struct GlueParams {
@@ -229,11 +233,12 @@ struct GlueArgs {
   GlueState* st_out;       // ... and after it (the other parity slot: late workgroups still read st_in)
   GlueRec* rec;            // pinned host record of this pair
   GlueDev* gd_copy;        // device copy of the second half's inputs for the kernels queued behind the head
+  unsigned seq;            // the pair's sequence stamp (PairSlot::seq, GlueRec::seq_gs / seq_out); also used when lm == null
   GlueParams gp;
 };
 void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
-                        float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero);
+                        float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero, unsigned seq = 0u);
 void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm);
 // Persistent minimizeVel (+ forwardMatch + extRotVel when do_ext): one launch; the workgroups exchange their records
 // through `xch` ([2][record groups][kPartStride] 64-bit words {tag, value}). The caller passes tag_base = tags consumed so
@@ -313,6 +318,7 @@ struct LaneDyn {
   unsigned char parity, det_in, det_out, slot;
   unsigned char gpar;           // parity slot of the glue state this pair reads (it writes the other one)
   unsigned tag_base;
+  unsigned seq;                 // the pair's sequence stamp (PairSlot::seq, GlueRec::seq_gs / seq_out)
 };
 struct LaneDynB {
   LaneDyn v[kMaxLanes];
@@ -331,6 +337,12 @@ __host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int l
   }
   return m;
 }
+#if defined(__HIPCC__)
+// Sequence stamp of a host-visible record: stored behind everything else the writer stored (system-scope release).
+__device__ __forceinline__ void stamp_release(unsigned* w, unsigned seq) {
+  __hip_atomic_store(w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 #if defined(__HIPCC__)
 // ---- pointers that reach a kernel through a table in memory -----------------------------------------------------------------
 // A pointer passed as a kernel argument (alone or inside a by-value struct such as MapDev) is known to the compiler to be
@@ -406,6 +418,13 @@ struct ProfScope {
 #define RH_LAUNCH(kernel, grid, block, shm, stream, ...)                 \
   do {                                                                   \
     ::rh::ProfScope _ps(stream, #kernel);                                \
+    hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);   \
+  } while (0)
+
+// the same for a kernel whose template arguments hold a comma: the name is given separately, the kernel in parentheses
+#define RH_LAUNCH_NAMED(name, kernel, grid, block, shm, stream, ...)      \
+  do {                                                                   \
+    ::rh::ProfScope _ps(stream, name);                                   \
     hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);   \
   } while (0)
 

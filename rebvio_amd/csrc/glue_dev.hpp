@@ -365,6 +365,7 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
     ga.gd_copy->has_next = 1;
     *ga.st_out = st;
     ga.rec->gs = st;
+    stamp_release(&ga.rec->seq_gs, ga.seq);
     return;
   }
   // ---- wave 0: SO3 correction, covariance, the second half's inputs, the host's record (rebvio.cpp:195-203, 228) ----
@@ -432,6 +433,7 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
   for (int i = 0; i < 36; ++i) out.W_Xv[i] = w.W[i];
   out.klm_num = out.kf_matches = out.reg_num = 0;
   out.status = nan_v;
+  stamp_release(&ga.rec->seq_out, ga.seq);
 }
 
 }  // namespace rh

@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
                                                      int calls, const LmState* __restrict__ st_in,
                                                      LmState* __restrict__ st_out, const float* __restrict__ part_prev,
                                                      float* __restrict__ xrv_part, Vec3 vel_manual,
-                                                     PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero) {
+                                                     PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero, unsigned seq) {
   __shared__ LmState s;
   __shared__ float red[16];
   __shared__ float carry_in;
@@ -872,6 +872,7 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
     for (int w = 0; w < 4; ++w) acc += wsum[w][threadIdx.x];
     xrv_part[blockIdx.x * kXrvStride + threadIdx.x] = acc;
   }
+  if (slot && blockIdx.x == 0 && threadIdx.x == 0) stamp_release(&slot->seq, seq);  // (block 0's own stores: lm, map states, its record)
 }
 
 // ---- persistent minimizeVel + forwardMatch + extRotVel (core.cpp:150-245, edge_map.cpp:78-96) --------------------
@@ -1018,6 +1019,7 @@ __device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const La
   ga.st_out = gptr(L.gstate) + ((d.gpar & 1) ^ 1);
   ga.rec = gptr(L.rec[d.slot]);
   ga.gd_copy = gptr(L.glue_dev) + d.slot;
+  ga.seq = d.seq;
   // (only the scalars: a batch forms the gyroBiasCorrection matrices on the device - has_pre = 0 as a constant lets the compiler
   // drop the by-value matrices; copying them put the whole struct into scratch memory, 280 bytes per lane of every workgroup)
   ga.gp.frame_dt = gp.frame_dt;
@@ -1254,7 +1256,10 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
     }
   }
   RH_STAMP(1 + calls * 6);
-  if (!do_ext) return;
+  if (!do_ext) {
+    if (slot && blockIdx.x == 0 && tid == 0) stamp_release(&slot->seq, ga.seq);
+    return;
+  }
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
   if (blockIdx.x == 0 && tid < 3) xch_publish(xch_final + tid, tag_final, s.vel[tid]);
   if (!lm_live) {
@@ -1305,6 +1310,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
     __syncthreads();  // (rec is free: every LM collect is over)
     lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, rec, kMaxRecBlocks * kPartStride / kXrvStride, gw, s, bar_err, slow_poll, stamps);
   }
+  if (slot && blockIdx.x == 0 && tid == 0) stamp_release(&slot->seq, ga.seq);  // the last thing this launch stores into the slot
 #undef RH_STAMP
 }
 
@@ -1889,6 +1895,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
                                     ? (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride : 1, gw, s, bar_err, slow_poll, stamps);
     RH_STAMP(15);
   }
+  if (slot && blockIdx.x == 0 && tid == 0) stamp_release(&slot->seq, ga.seq);  // the last thing this launch stores into the slot
 #undef RH_STAMP
 }
 
@@ -2560,42 +2567,44 @@ __global__ __launch_bounds__(256) void k_directed_match_tail_b(KParams p, const 
 // kLPK = 1 executes the fewest instructions (batches, large maps).
 constexpr int kDmcWin = 40;        // probe steps per long-search window
 constexpr int kDmcWinPitch = 41;   // LDS pitch of one chain window (odd: the owners' rows start in different banks)
-constexpr int kDmcOpen = 16;       // open keylines a wave searches together
-constexpr int kDmcList = kDmcOpen * 2 * kDmcWin;  // candidate list capacity of a wave (phase 1 needs at most 64 * 2 * kHeadSteps = 512)
+constexpr int kDmcOpen = 16;       // open keylines a wave searches together (fewer where it owns fewer)
 constexpr int kDmcNone = 0x7fffffff;
-static_assert(kDmcList >= 64 * 2 * kHeadSteps, "phase 1 list");
-template <int kKPW>  // keylines per wave (owners)
+template <int kKPW, int kBatch>  // keylines per wave (owners), open keylines searched together
 struct DmcWave {
-  unsigned list[kDmcList];           // candidate: old keyline (16 bits) | owner (6) | slot in the reference's probe order, 2 * step + side (10)
+  static constexpr int kList = (kBatch * 2 * kDmcWin > kKPW * 2 * kHeadSteps) ? kBatch * 2 * kDmcWin : kKPW * 2 * kHeadSteps;
+  unsigned list[kList];              // candidate: old keyline (16 bits) | owner (6) | slot in the reference's probe order, 2 * step + side (10)
   float t1[kKPW * 2 * kHeadSteps];   // phase 1: t of the candidate's probe (phase 2 reads it from seq)
   float4 q_a[kKPW];                  // per owner, what the acceptance test needs of the query keyline: norm_t, sigma2_t, gradient
   float q_gn[kKPW];                  // ... and its norm
   int best[kKPW];                    // per owner: min over accepted candidates of slot << 16 | list position
   float w_f[7][kKPW];                // staged winner per owner: pos_img, (rho, sigma_rho), gradient, norm (rotated) ...
   int w_i[3][kKPW];                  // ... matches, match_id_keyframe, old keyline index
-  float4 s_a[kDmcOpen];              // probe geometry of the open keylines: t_x, t_y, pi0x, pi0y
-  float4 s_b[kDmcOpen];              // dq_min, dq_max, t_steps (int bits), -
-  float seq[kDmcOpen][2][kDmcWinPitch];  // [open keyline][0: tn, 1: tp][step - window start]
+  float4 s_a[kBatch];                // probe geometry of the open keylines: t_x, t_y, pi0x, pi0y
+  float4 s_b[kBatch];                // dq_min, dq_max, t_steps (int bits), -
+  float seq[kBatch][2][kDmcWinPitch];  // [open keyline][0: tn, 1: tp][step - window start]
 };
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
-  int incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(incl, d);
-    if (lane >= d) incl += up;
-  }
-  *total = __shfl(incl, 63);
-  return incl - v;
+// Exclusive prefix sum over the wave through the DPP data path (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast 15
+// into rows 1 and 3 and row_bcast 31 into rows 2 and 3: twelve VALU instructions, no LDS crossbar); *total is a scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_i(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
 }
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int* total) {
+  (void)lane;
+  int incl = v;
+  incl = dpp_add_i<0x111, 0xF>(incl);  // row_shr:1
+  incl = dpp_add_i<0x112, 0xF>(incl);  // row_shr:2
+  incl = dpp_add_i<0x114, 0xF>(incl);  // row_shr:4
+  incl = dpp_add_i<0x118, 0xF>(incl);  // row_shr:8
+  incl = dpp_add_i<0x142, 0xA>(incl);  // row_bcast:15 -> rows 1, 3
+  incl = dpp_add_i<0x143, 0xC>(incl);  // row_bcast:31 -> rows 2, 3
+  *total = __builtin_amdgcn_readlane(incl, 63);  // (a scalar: loops over the total are uniform)
+  return incl - v;
 }
 // Acceptance test of one candidate (edge_map.cpp:170-177) on the two query scalars it needs of the probe geometry.
 __device__ __forceinline__ bool search_accept_q(const KParams& p, float norm_t, float sigma2_t, float t, float2 cg, float cgn, float2 crs,
@@ -2658,12 +2667,20 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
   constexpr int kHP = 2 * kHeadSteps / kLPK;      // head probes per lane
   constexpr int kBatch = kKPW < kDmcOpen ? kKPW : kDmcOpen;
   static_assert(kMaxRecBlocks * 256 <= 65536, "old keyline index in 16 bits of a list entry");
-  __shared__ DmcWave<kKPW> lds[kWaves];
+  __shared__ DmcWave<kKPW, kBatch> lds[kWaves];
   const uint2 vb = xcd_band_block();
   if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[48] = __builtin_amdgcn_s_memrealtime();
+  const bool stats = p.dm_stats != nullptr;
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define RH_DMC_TICK(i)                                               \
+  if (stats) {                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    tk[i] += now_ - t_prev;                                          \
+    t_prev = now_;                                                   \
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int kl = lane / kLPK, sub = lane % kLPK;  // keyline of the wave, lane of the keyline
-  DmcWave<kKPW>& W = lds[wid];
+  DmcWave<kKPW, kBatch>& W = lds[wid];
   const int idx = (vb.x * kWaves + wid) * kKPW + kl;
   // bound-free early loads (arrays padded to the grid), issued before the parameter block is read
   const float2 pi = nm.pos_img[idx];
@@ -2724,8 +2741,10 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
   int cnt = 0;
 #pragma unroll
   for (int h = 0; h < kHP; ++h) cnt += (cand[h] >= 0) ? 1 : 0;
+  RH_DMC_TICK(0)  // set-up, head probes issued
   int T = 0;
   int pos = wave_excl_scan_i(cnt, lane, &T);
+  RH_DMC_TICK(1)  // mask loads back, scan
 #pragma unroll
   for (int h = 0; h < kHP; ++h) {
     if (cand[h] >= 0) {
@@ -2738,28 +2757,15 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
   dmc_test_list<false>(p, om, W, T, lane, A.rot, A.R0, 0);
   int found = -1, kf = 0;
   if (sub == 0 && W.best[kl] != kDmcNone) found = dmc_commit(nm, om, W, kl, idx, &kf);
+  RH_DMC_TICK(2)  // head candidates tested, commits issued
   // ---- phase 2: long searches still open (flagged on the first lane of the keyline)
   const bool open = live && sub == 0 && found < 0 && S.t_steps > kHeadSteps;
   const unsigned long long open_mask = __ballot(open);
   const int n_open = __popcll(open_mask);
   if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[49] = __builtin_amdgcn_s_memrealtime();
-  if (p.dbg) {  // REBVIO_HIP_LM_STAMPS: shape of the workload (printed by rebvio_hip_flush)
-    const int c_live = __popcll(__ballot(live && sub == 0)), c_long = __popcll(__ballot(live && sub == 0 && S.t_steps > kHeadSteps));
-    const int c_f1 = __popcll(__ballot(found >= 0));
-    if (live && sub == 0) atomicAdd(&p.dbg[80 + max(0, min(S.t_steps, 47))], 1ull);
-    if (lane == 0) {
-      if (vb.x == 0 && wid == 0) atomicAdd(&p.dbg[64], 1ull);
-      atomicAdd(&p.dbg[65], (unsigned long long)c_live);
-      atomicAdd(&p.dbg[66], (unsigned long long)c_long);
-      atomicAdd(&p.dbg[67], (unsigned long long)n_open);
-      atomicAdd(&p.dbg[68], (unsigned long long)T);
-      atomicMax(&p.dbg[70], (unsigned long long)n_open);
-      if (n_open > 16) atomicAdd(&p.dbg[71], 1ull);
-      if (n_open > 32) atomicAdd(&p.dbg[72], 1ull);
-      if (n_open > 0) atomicAdd(&p.dbg[73], 1ull);
-      atomicAdd(&p.dbg[74], (unsigned long long)c_f1);
-    }
-  }
+  const int T_head = T;
+  const int found_head = found;
+  unsigned long long T2_sum = 0ull;
   // rank of this lane's keyline among the open ones (the same for all lanes of the keyline)
   const int rank = __popcll(open_mask & ((1ull << (kl * kLPK)) - 1ull));
   const bool kl_open = ((open_mask >> (kl * kLPK)) & 1ull) != 0ull;
@@ -2775,25 +2781,32 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
       W.q_gn[jj] = gnq;
       W.best[jj] = kDmcNone;
     }
-    const int tmax = wave_max_i(mine ? S.t_steps : 0);
+    // no search is longer than the radius allows (t_steps <= search_range + pixel_uncertainty_match + 1, bounded at create):
+    // one window with the default radius of 40
+    const int tmax = cvtt_f32(max_radius + p.pixel_uncertainty_match) + 2;
     for (int step0 = kHeadSteps; step0 < tmax; step0 += kDmcWin) {
       // the chains continue through this window (tn, tp stand at step0): with two or more lanes per keyline lane 0 walks tn and
       // lane 1 tp (x - 1.0f and x + (-1.0f) are the same IEEE operation), a lone lane walks both
       const int wlen = min(kDmcWin, tmax - step0);
+      // (always a whole window of kDmcWin steps, unrolled: one add and one LDS store with an immediate offset per step; what lies
+      // beyond a keyline's t_steps is never read)
       if (kLPK >= 2) {
-        const bool writer = mine && sub < 2;
-        float x = sub == 1 ? tp : tn;
-        const float d = sub == 1 ? 1.0f : -1.0f;
-        float* dst = &W.seq[writer ? jj : 0][sub == 1 ? 1 : 0][0];
-        for (int s = 0; s < wlen; ++s) {
-          if (writer) dst[s] = x;
-          x += d;
+        if (mine && sub < 2) {
+          float x = sub == 1 ? tp : tn;
+          const float d = sub == 1 ? 1.0f : -1.0f;
+          float* dst = &W.seq[jj][sub][0];
+#pragma unroll
+          for (int s = 0; s < kDmcWin; ++s) {
+            dst[s] = x;
+            x += d;
+          }
+          if (sub == 0) tn = x;
+          else tp = x;
         }
-        if (mine && sub == 0) tn = x;
-        if (mine && sub == 1) tp = x;
       } else {
-        for (int s = 0; s < wlen; ++s) {
-          if (mine) {  // (the owners of later batches keep their chains at step kHeadSteps)
+        if (mine) {  // (the owners of later batches keep their chains at step kHeadSteps)
+#pragma unroll
+          for (int s = 0; s < kDmcWin; ++s) {
             W.seq[jj][0][s] = tn;
             W.seq[jj][1][s] = tp;
             tp += 1.0f;
@@ -2802,6 +2815,7 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
         }
       }
       wave_lds_sync();
+      RH_DMC_TICK(3)  // chains walked
       // probe slots of the batch, dealt to all 64 lanes: q -> (open keyline j, side, step); the first kDmcWin of a keyline's
       // 2 * kDmcWin slots walk tn, the others tp, so that neighbouring lanes probe neighbouring pixels of one line
       constexpr int kProbeIters = (kBatch * 2 * kDmcWin + 63) / 64;
@@ -2809,37 +2823,57 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
       unsigned pm[kProbeIters];
       constexpr int per = 2 * kDmcWin;
       const int nslots = nb * per;
+      int pj = 0, ps = lane;  // slot of this lane in round 0: (open keyline, position); +64 slots per round
+      unsigned pok = 0u;      // which of this lane's probes count
+      // Rounds in chunks of kChunk behind ONE uniform test: inside a chunk nothing branches and no loaded value is looked at (a
+      // select on it would make every round wait for its own load), so the LDS reads and mask loads of a chunk's rounds overlap.
+      constexpr int kChunk = 5;
+      static_assert(kProbeIters % kChunk == 0, "probe rounds per chunk");
 #pragma unroll
-      for (int i = 0; i < kProbeIters; ++i) {
-        const int q = i * 64 + lane;
-        int cd = -1;
-        unsigned mt = 0u;
-        if (i * 64 < nslots && q < nslots) {
-          const int j = q / per, s = q - j * per;
-          const int side = s >= kDmcWin ? 1 : 0, so = s - side * kDmcWin;
-          const int step = step0 + so;
-          const float4 sb = W.s_b[j];
-          if (so < wlen && step < __float_as_int(sb.z) && W.best[j] == kDmcNone) {
+      for (int c = 0; c < kProbeIters / kChunk; ++c) {
+        if (c * kChunk * 64 < nslots) {  // (uniform)
+#pragma unroll
+          for (int u = 0; u < kChunk; ++u) {
+            const int i = c * kChunk + u;
+            const int j = min(pj, nb - 1);
+            const int side = ps >= kDmcWin ? 1 : 0, so = ps - side * kDmcWin;
+            const int step = step0 + so;
+            const float4 sb = W.s_b[j];
+            const float4 sa = W.s_a[j];
             const float t = W.seq[j][side][so];
-            if (side ? !(t > sb.y) : !(t < sb.x)) {
-              const float4 sa = W.s_a[j];
-              const int row = cvtt_f32(roundf(sa.y * t + sa.w));
-              const int col = cvtt_f32(roundf(sa.x * t + sa.z));
-              if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) {
-                cd = om.mask[(size_t)row * p.cols + col];
-                mt = ((unsigned)j << 10) | (unsigned)(2 * step + side);
-              }
+            const int bj = W.best[j];
+            bool ok = pj < nb && so < wlen && step < __float_as_int(sb.z) && bj == kDmcNone;
+            ok = ok && (side ? !(t > sb.y) : !(t < sb.x));
+            const int row = cvtt_f32(roundf(sa.y * t + sa.w));
+            const int col = cvtt_f32(roundf(sa.x * t + sa.z));
+            ok = ok && (unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols;
+            pc[i] = om.mask[ok ? row * p.cols + col : 0];
+            pok |= ok ? (1u << i) : 0u;
+            pm[i] = ((unsigned)j << 10) | (unsigned)(2 * step + side);
+            ps += 64;  // (64 < per: at most one wrap)
+            if (ps >= per) {
+              ps -= per;
+              ++pj;
             }
           }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kChunk; ++u) {
+            pc[c * kChunk + u] = -1;
+            pm[c * kChunk + u] = 0u;
+          }
         }
-        pc[i] = cd;
-        pm[i] = mt;
       }
+      RH_DMC_TICK(4)  // long-search probes issued
       int c2 = 0;
 #pragma unroll
-      for (int i = 0; i < kProbeIters; ++i) c2 += (pc[i] >= 0) ? 1 : 0;
+      for (int i = 0; i < kProbeIters; ++i) {
+        if (!((pok >> i) & 1u)) pc[i] = -1;
+        c2 += (pc[i] >= 0) ? 1 : 0;
+      }
       int T2 = 0;
       int pos2 = wave_excl_scan_i(c2, lane, &T2);
+      RH_DMC_TICK(5)  // mask loads back, scan
 #pragma unroll
       for (int i = 0; i < kProbeIters; ++i) {
         if (pc[i] >= 0) {
@@ -2848,11 +2882,25 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
         }
       }
       wave_lds_sync();
-      if (p.dbg && lane == 0) atomicAdd(&p.dbg[69], (unsigned long long)T2);
+      T2_sum += (unsigned long long)T2;
       dmc_test_list<true>(p, om, W, T2, lane, A.rot, A.R0, step0);
     }
     if (mine && sub == 0 && W.best[jj] != kDmcNone) found = dmc_commit(nm, om, W, jj, idx, &kf);
+    RH_DMC_TICK(6)  // long-search candidates tested, commits issued
   }
+  if (stats) {  // REBVIO_HIP_DM_STATS: one record per wave (plain stores; the host aggregates them in rebvio_hip_flush)
+    const int c_live = __popcll(__ballot(live && sub == 0)), c_long = __popcll(__ballot(live && sub == 0 && S.t_steps > kHeadSteps));
+    const int c_f1 = __popcll(__ballot(found_head >= 0));
+    if (lane == 0) {
+      unsigned long long* r = p.dm_stats + 16 * (size_t)(1 + vb.x * kWaves + wid);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) r[i] = tk[i];
+      r[8] = (unsigned long long)c_live; r[9] = (unsigned long long)c_long; r[10] = (unsigned long long)c_f1;
+      r[11] = (unsigned long long)n_open; r[12] = (unsigned long long)T_head; r[13] = T2_sum;
+      if (vb.x == 0 && wid == 0) p.dm_stats[0] = (unsigned long long)(gridDim.x * kWaves);
+    }
+  }
+#undef RH_DMC_TICK
   // counters: wave -> workgroup (LDS) -> one global atomic per workgroup and counter (see k_directed_match)
   const int c_found = __popcll(__ballot(found >= 0));
   const int c_kf = __popcll(__ballot(kf != 0));
@@ -2863,19 +2911,19 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
       if (n_open) atomicAdd(&nm.st->dm_queued, n_open);
     }
   } else {
-    __shared__ int b_cnt[3];
-    if (threadIdx.x < 3) b_cnt[threadIdx.x] = 0;
-    __syncthreads();
+    __shared__ int w_cnt[kWaves][3];
     if (lane == 0) {
-      if (c_found) atomicAdd(&b_cnt[0], c_found);
-      if (c_kf) atomicAdd(&b_cnt[1], c_kf);
-      if (n_open) atomicAdd(&b_cnt[2], n_open);
+      w_cnt[wid][0] = c_found;
+      w_cnt[wid][1] = c_kf;
+      w_cnt[wid][2] = n_open;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      if (b_cnt[0]) atomicAdd(&nm.st->dm_matches, b_cnt[0]);
-      if (b_cnt[1]) atomicAdd(&nm.st->dm_kf, b_cnt[1]);
-      if (b_cnt[2]) atomicAdd(&nm.st->dm_queued, b_cnt[2]);
+    if (threadIdx.x < 3) {
+      int t = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) t += w_cnt[w][threadIdx.x];
+      int* dst = threadIdx.x == 0 ? &nm.st->dm_matches : (threadIdx.x == 1 ? &nm.st->dm_kf : &nm.st->dm_queued);
+      if (t) atomicAdd(dst, t);
     }
   }
 }
@@ -3218,9 +3266,9 @@ void launch_forward_keys(hipStream_t s, const KParams& p, const MapDev& oldm, co
 
 void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, const MapDev& newm, int do_forward,
                         int do_lm_final, int calls, LmState* st_in, LmState* st_out, const float* part_prev,
-                        float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero) {
+                        float* xrv_part, const float* vel_manual, PairSlot* slot, int* hist_to_zero, unsigned seq) {
   RH_LAUNCH(k_ext_rot_vel, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, oldm, newm, do_forward, do_lm_final,
-                     calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual), slot, hist_to_zero);
+                     calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual), slot, hist_to_zero, seq);
 }
 
 // grid of the wave-per-keyline pass: the queue holds a few thousand long searches, each a chain of dependent gathers - more
@@ -3232,17 +3280,28 @@ static int dm_tail_blocks(int kmax) { return std::max(512, std::min(1024, kmax /
 // eightfold redundant probe set-up: a win while the launch is latency-bound on a mostly idle chip (16k keylines: 11.6 vs
 // 13.8 us), a loss once the eight-fold grid fills it (64k keylines: 36 vs 24 us). head_form: 0 by map size, 1 thread per
 // keyline, 2 eight lanes per keyline (REBVIO_HIP_DM_HEAD, read when the context is created).
-// head_form 3 / 4 / 5 / 6: the compact one-launch form (k_directed_match_c): 4 lanes per keyline in 256- / 128- / 64-thread
-// workgroups (3, 4, 6), one lane per keyline in 64-thread workgroups (5)
-static bool dm_compact(int head_form) { return head_form >= 3 && head_form <= 6; }
-#define RH_DMC_DISPATCH(KERNEL, head_form, kmax, zdim, stream, ...)                                                              \
-  do {                                                                                                                           \
-    switch (head_form) {                                                                                                         \
-      case 3: RH_LAUNCH((KERNEL<256, 4>), dim3(div_up(kmax, 64), 1, zdim), dim3(256), 0, stream, __VA_ARGS__); break;            \
-      case 4: RH_LAUNCH((KERNEL<128, 4>), dim3(div_up(kmax, 32), 1, zdim), dim3(128), 0, stream, __VA_ARGS__); break;            \
-      case 6: RH_LAUNCH((KERNEL<64, 4>), dim3(div_up(kmax, 16), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;              \
-      default: RH_LAUNCH((KERNEL<64, 1>), dim3(div_up(kmax, 64), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;             \
-    }                                                                                                                            \
+// Form of the directedMatch launch (REBVIO_HIP_DM_HEAD / REBVIO_HIP_BATCH_DM_HEAD, read at create; 0 = chosen here):
+//   1 "thread", 2 "wide": the two-launch forms of rounds 1-3 (k_directed_match / k_directed_match8 + k_directed_match_tail)
+//   3..8: the one-launch compact form k_directed_match_c<threads, lanes per keyline>: 3 "compact" <256, 4>, 4 "compact128" <128, 4>,
+//   5 "compact1" <64, 1>, 6 "compact64" <64, 4>, 7 "compact8" <512, 8>, 8 "compact8s" <256, 8>
+// One stream of up to 32 768 keylines takes <512, 8>: eight keylines per wave, 1 875 short waves on an idle chip (MI355X, 640x480 /
+// 15 k keylines: 15.6 k frames/s against 15.2 k for <256, 4>, 13.7 k for the two-launch wide form; the kernel 11.5 us against 21).
+// Larger maps and batches of four lanes or more, where the chip is full, take the form with the fewest instructions, <64, 1>.
+static int dm_form(int kmax, int head_form, int lanes) {
+  if (head_form) return head_form;
+  return (kmax <= 32768 && lanes < 4) ? 7 : 5;
+}
+static bool dm_compact(int form) { return form >= 3 && form <= 8; }
+#define RH_DMC_DISPATCH(KERNEL, head_form, kmax, zdim, stream, ...)                                                                            \
+  do {                                                                                                                                         \
+    switch (head_form) {                                                                                                                       \
+      case 3: RH_LAUNCH_NAMED(#KERNEL "<256,4>", (KERNEL<256, 4>), dim3(div_up(kmax, 64), 1, zdim), dim3(256), 0, stream, __VA_ARGS__); break; \
+      case 4: RH_LAUNCH_NAMED(#KERNEL "<128,4>", (KERNEL<128, 4>), dim3(div_up(kmax, 32), 1, zdim), dim3(128), 0, stream, __VA_ARGS__); break; \
+      case 6: RH_LAUNCH_NAMED(#KERNEL "<64,4>", (KERNEL<64, 4>), dim3(div_up(kmax, 16), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;    \
+      case 7: RH_LAUNCH_NAMED(#KERNEL "<512,8>", (KERNEL<512, 8>), dim3(div_up(kmax, 64), 1, zdim), dim3(512), 0, stream, __VA_ARGS__); break; \
+      case 8: RH_LAUNCH_NAMED(#KERNEL "<256,8>", (KERNEL<256, 8>), dim3(div_up(kmax, 32), 1, zdim), dim3(256), 0, stream, __VA_ARGS__); break; \
+      default: RH_LAUNCH_NAMED(#KERNEL "<64,1>", (KERNEL<64, 1>), dim3(div_up(kmax, 64), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;   \
+    }                                                                                                                                          \
   } while (0)
 static bool dm_head_wide(int kmax, int head_form) {
   if (head_form) return head_form == 2;
@@ -3252,6 +3311,7 @@ static bool dm_head_wide(int kmax, int head_form) {
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
                            const float* R0_on_the_fly, int head_form) {
+  head_form = dm_form(p.kmax, head_form, 1);
   // *work_n is zero on entry (reset by the kernel that follows the tail, or by the caller)
   const int rot = R0_on_the_fly ? 1 : 0;
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -3275,6 +3335,7 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
 // (device glue, glue_dev.hpp)
 void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
                                int* work, int* work_n, int head_form) {
+  head_form = dm_form(p.kmax, head_form, 1);
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
   if (dm_compact(head_form)) {
     RH_DMC_DISPATCH(k_directed_match_c, head_form, p.kmax, 1, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, 1, mat3(I), gd);
@@ -3359,7 +3420,8 @@ void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStat
   // head form: eight lanes per keyline is the low-latency form while the chip is mostly idle; from a few lanes on the chip is
   // full and the thread-per-keyline form (an eighth of the waves) is the cheaper one (REBVIO_HIP_BATCH_DM_HEAD=wide|thread,
   // read when the batch is created)
-  const bool wide = head_form ? head_form == 2 : (lanes < 4 && p.kmax <= 32768);
+  head_form = dm_form(p.kmax, head_form, lanes);
+  const bool wide = head_form == 2;
   if (dm_compact(head_form)) {
     RH_DMC_DISPATCH(k_directed_match_c_b, head_form, p.kmax, z, s, p, ls, maptab, dyn, max_radius);
     RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);

@@ -29,6 +29,35 @@ def test_gpus_n_without_launcher_starts_n_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2
     assert d["max_over_ranks"] == 2.0  # rank 1 reports 2.0: the maximum crossed the process boundary
+    # every rank went through the CPU-baseline leg's build + load path (built once before the ranks exist, found up to date by
+    # the ranks; the file lock and the rename into place keep a concurrent loader from mapping a half-written library)
+    assert d["cpu_oracle_loaded_ranks"] == 2
+
+
+def test_ranks_under_a_launcher_build_the_cpu_oracle_once():
+    """The driver's form (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`): no self-launcher runs, so the
+    ranks meet the build themselves - rank 0 builds, a barrier, the others find the library up to date. Started here from a
+    clean native directory, twice in a row (the second run finds everything built)."""
+    import glob
+    import shutil
+    import socket
+    for d in glob.glob(os.path.join(ROOT, "oracle", "_build", "native-*")):
+        shutil.rmtree(d)
+    for _ in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(2):
+            env = dict(_env_without_ranks(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--control-plane-only"], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE))
+        outs = [q.communicate(timeout=600) for q in procs]
+        assert all(q.returncode == 0 for q in procs), [o[1].decode()[-800:] for o in outs]
+        d = json.loads([ln for ln in outs[0][0].decode().splitlines() if ln.strip()][-1])
+        assert d["cpu_oracle_loaded_ranks"] == 2
+    built = glob.glob(os.path.join(ROOT, "oracle", "_build", "native-*", "librebvio_oracle.so"))
+    assert len(built) == 1 and not glob.glob(os.path.join(ROOT, "oracle", "_build", "native-*", "*.tmp.*"))
 
 
 def test_world_size_mismatch_is_an_error():
@@ -67,7 +96,7 @@ def test_cpu_baseline_counts_the_frames_it_ran(orc_mod):
 def test_stage_map_covers_every_kernel_name():
     import bench
     names = ["k_front_end_u8", "k_rowscan<0>", "k_rowscan<1>", "k_rowscan<2>", "k_colscan", "k_dog_mag", "k_keyline_flag",
-             "k_keyline_emit", "k_join_edges", "k_df_tiles<32>", "k_df_bin", "k_lm_chain<512>", "k_directed_match8",
+             "k_keyline_emit", "k_join_edges", "k_df_tiles<32>", "k_df_bin", "k_lm_chain<512>", "k_directed_match_c<512,8>",
              "k_directed_match_tail", "k_regularize_ekf", "k_rotate"]
     per = {n: 1.0 for n in names}
     st = bench.stage_us(per)

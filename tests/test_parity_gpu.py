@@ -347,16 +347,17 @@ def c3_stream():
 KW_C3 = dict(keylines_ref=60000, keylines_max=64000, threshold=0.006)
 
 
-@pytest.mark.parametrize("config,head", [("c2", None), ("c2", "thread"), ("c3", None), ("c3", "wide"), ("c2", "compact"), ("c2", "compact128"),
-                                         ("c2", "compact64"), ("c2", "compact1"), ("c3", "compact"), ("c3", "compact1")],
-                         ids=["c2-default(wide)", "c2-thread-head", "c3-64k-default(thread)", "c3-64k-wide-head", "c2-compact", "c2-compact128",
-                              "c2-compact64", "c2-compact1", "c3-64k-compact", "c3-64k-compact1"])
+@pytest.mark.parametrize("config,head", [("c2", None), ("c2", "thread"), ("c2", "wide"), ("c3", None), ("c3", "thread"), ("c3", "wide"), ("c2", "compact"),
+                                         ("c2", "compact128"), ("c2", "compact64"), ("c2", "compact1"), ("c3", "compact"), ("c2", "compact8s")],
+                         ids=["c2-default(compact8)", "c2-thread-head", "c2-wide-head", "c3-64k-default(compact1)", "c3-64k-thread-head",
+                              "c3-64k-wide-head", "c2-compact", "c2-compact128", "c2-compact64", "c2-compact1", "c3-64k-compact", "c2-compact8s"])
 def test_directed_match_regularize_ekf_bit_exact(orc_mod, B, c2_stream, c3_stream, monkeypatch, config, head):
     """directedMatch / searchMatch (edge_map.cpp:101-218), regularize1Iter, depth EKF on maps synced from the oracle: every
-    keyline field bit-exact, counters equal - for BOTH forms of the directedMatch head (eight lanes per keyline,
-    k_directed_match8, the default up to 32 768 keylines; one thread per keyline, k_directed_match, beyond) at BASELINE
-    config 2 and on a 64 000-keyline map of config 3 (1280x960), each form also where it is not the default
-    (REBVIO_HIP_DM_HEAD, read when the context is created)."""
+    keyline field bit-exact, counters equal - for every form of the directedMatch launch (REBVIO_HIP_DM_HEAD, read when the
+    context is created): the one-launch compact kernel k_directed_match_c with 8 / 4 / 1 lanes per keyline and every workgroup
+    size it is instantiated for (defaults: <512, 8> up to 32 768 keylines, <64, 1> beyond) and the two-launch forms of rounds 1-3
+    (eight lanes per keyline / one thread per keyline + the wave-per-search tail), at BASELINE config 2 and on a 64 000-keyline
+    map of config 3 (1280x960)."""
     frames, cam = c2_stream if config == "c2" else c3_stream
     kw = KW_C2 if config == "c2" else KW_C3
     if head:
@@ -1071,6 +1072,68 @@ def test_pair_step_failure_paths(orc_mod, B, small_stream):
     npx = cam.width * cam.height
     st = [o.status for o, _ in run_stream(ctx2, dev, range(len(seq)), npx)]
     assert len(st) == len(seq) - 1 and st[0] == 0 and 2 in st and st[-1] == 0, st   # the bad pair is reported, the stream goes on
+
+
+def test_record_read_before_its_pair_wrote_it_is_reported(B, small_stream):
+    """Every pair carries a sequence stamp that its kernels store as the last word of each host-visible record (result slot:
+    LM state + map state records; glue record: pose record and filter state), and every reader compares it before it uses the
+    record. rebvio_hip_test_forge_record_stamp hands the NEXT pair's kernels a wrong number - what a record looks like when it
+    is read before the pair has written it, the failure seen in round 3 with kernel-bound stop events (192x144 stream, this
+    fixture) - and the reading call must fail with -12 on every path: per-pair API, split API, streaming driver (harvest
+    inside a push or the flush), batch. One deterministic run each; no timing involved."""
+    import ctypes
+    from rebvio_amd import backend
+    frames, cam = small_stream
+    kw = dict(keylines_ref=1500, keylines_max=2500, global_min_matches_threshold=100)
+    npx = cam.width * cam.height
+
+    def stale(fn):
+        with pytest.raises(backend.HipError) as e:
+            fn()
+        assert "error -12" in str(e.value), str(e.value)
+
+    # per-pair API: the slot is read right behind the stream synchronisation
+    ctx = B.Context(params_for(B, cam, **kw))
+    g0, g1, g2 = (ctx.detect_u8(frames[i], i * 50000) for i in range(3))
+    assert ctx.track_pair(g0, g1).status == 0   # (stamps in order: nothing to report)
+    backend._chk(backend.lib().rebvio_hip_test_forge_record_stamp(ctx.h))
+    stale(lambda: ctx.track_pair(g1, g2))
+    ctx.close()
+    # split API (rebvio::Rebvio's path)
+    ctx = B.Context(params_for(B, cam, **kw))
+    g0, g1 = (ctx.detect_u8(frames[i], i * 50000) for i in range(2))
+    backend._chk(backend.lib().rebvio_hip_test_forge_record_stamp(ctx.h))
+    stale(lambda: ctx.track_pair_begin(g0, g1, None, 0.05))
+    ctx.close()
+    # streaming driver: the forged pair is reported by whichever call harvests it
+    ctx = B.Context(params_for(B, cam, **kw))
+    dev = ctx.upload_frames(frames)
+
+    def stream():
+        for k in range(len(frames)):
+            if k == 8:
+                backend._chk(backend.lib().rebvio_hip_test_forge_record_stamp(ctx.h))
+            ctx.push_frame_u8_device(dev + k * npx, k * 50000)
+        ctx.flush()
+    stale(stream)
+    ctx.close()
+    # a clean stream of the same frames: every record arrives
+    ctx = B.Context(params_for(B, cam, **kw))
+    dev = ctx.upload_frames(frames)
+    assert len(run_stream(ctx, dev, range(len(frames)), npx)) == len(frames) - 1
+    ctx.close()
+    # batch: the last lane of one step
+    bat = B.Batch(params_for(B, cam, **kw), 2)
+    devs = [bat.lanes[l].upload_frames(frames) for l in range(2)]
+
+    def batch():
+        for k in range(len(frames)):
+            if k == 8:
+                backend._chk(backend.lib().rebvio_hip_batch_test_forge_record_stamp(bat.h))
+            bat.push_u8_device([d + k * npx for d in devs], k * 50000)
+        bat.flush()
+    stale(batch)
+    bat.close()
 
 
 def test_pair_step_nan_path(orc_mod, B, small_stream):
