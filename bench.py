@@ -48,7 +48,30 @@ def pmc_traffic_bytes(kernel: str):
 
 
 def pmc_profile_path():
-    return next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_hbm.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
+    return next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_hbm.json") for r in range(9, 0, -1)) if os.path.exists(q)), None)
+
+
+def rocprof_stats_path():
+    return next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_kernel_stats.csv") for r in range(9, 0, -1)) if os.path.exists(q)), None)
+
+
+def rocprof_avg_us(kernel: str):
+    """Mean duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this same command
+    (profiles/rNN_kernel_stats.csv, newest round): (us, calls), or None when the file or the kernel is missing."""
+    import csv
+    import re
+    path = rocprof_stats_path()
+    if path is None:
+        return None
+    want = kernel.replace(" ", "")
+    try:
+        for r in csv.DictReader(open(path)):
+            name = re.sub(r"\(.*", "", r["Name"]).replace("rh::", "").replace("void ", "").replace(" ", "")
+            if name == want:
+                return float(r["AverageNs"]) / 1e3, int(r["Calls"])
+    except Exception:
+        return None
+    return None
 
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
@@ -319,7 +342,7 @@ def main():
     # 8 % of a 20-frame window): runs shorter than 1000 steps are followed by an extra, separately bracketed window of 2000
     # frames whose rate is reported next to the contract's figure (config.long_window), never instead of it.
     long_steps = 2000 if steps < 1000 else 0
-    order = synth.pingpong_indices(args.base_frames, settle + warmup + steps + long_steps + 96)  # GPU leg only; the CPU leg builds its own list
+    order = synth.pingpong_indices(args.base_frames, settle + warmup + steps + long_steps + 800 + 96)  # GPU leg only; the CPU leg builds its own list
 
     def push(i):
         return ctx.push_frame_u8_device(dev + int(order[i]) * npx, i * 50000)
@@ -368,12 +391,9 @@ def main():
 
     # ---- timed region: EXACTLY `steps` frames ------------------------------------------------------------------
     ctx.profile_reset()
-    # HIP events around every n-th launch of the dominant kernel (n >= 8, at most ~200 samples: the event pool is
-    # preallocated, creating events inside the timed region would cost more than it measures), on the stream it runs on
-    n_launch = steps * launches_per_frame(dominant)
-    # (an event pair is two more packets on the track stream, ~4 us on the chain of the pair it brackets - measured on a 20-frame
-    # window: every 2nd launch 11.4 k frames/s, every 4th 11.9 k, every 8th 12.1 k, none 12.2 k - hence every 8th at most)
-    ctx.profile(True, only=dominant, stride=int(os.environ.get("REBVIO_BENCH_STRIDE", max(8, n_launch // 200))))
+    # (no event pair inside the timed region: an event pair is two more packets on the track stream, ~4 us on the chain of the
+    # pair it brackets - measured on a 20-frame window: every 2nd launch 11.4 k frames/s, every 8th 12.1 k, none 12.2 k. The
+    # dominant kernel's launch time is sampled in a window of its own behind the timed region, below.)
     statuses = []
     matches = []
     push_done = np.zeros(steps, np.float64)
@@ -392,8 +412,6 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = t1 - t0
-    dom = ctx.profile_read().get(dominant, (0.0, 0))
-    ctx.profile(False)
     long_elapsed = 0.0
     if long_steps:
         barrier()
@@ -405,6 +423,19 @@ def main():
         long_elapsed = time.perf_counter() - tl0
         if world > 1:
             dist.barrier()
+    # ---- launch time of the dominant kernel: HIP events around every 8th launch (on the stream it runs on) over 800 further
+    # frames of the same stream, ~100 samples whatever --steps is; never inside a timed window
+    sample_steps = 800
+    ctx.profile_reset()
+    ctx.profile(True, only=dominant, stride=int(os.environ.get("REBVIO_BENCH_STRIDE", 8)))
+    for _ in range(sample_steps):
+        push(k)
+        k += 1
+    torch.cuda.synchronize()
+    dom = ctx.profile_read().get(dominant, (0.0, 0))
+    ctx.profile(False)
+    if world > 1:
+        dist.barrier()
     # ---- the same loop with every frame handed over from HOST memory (the reference's contract starts at a host image,
     # rebvio.cpp:38-48): pinned ring + asynchronous copy ahead of the frame's scans. Reported as config.pcie_inclusive_fps,
     # never as `value`.
@@ -447,6 +478,7 @@ def main():
         if dominant in ("k_colscan", "k_colscan4"):
             ab = (8 * npx + 16 * npx + 16 * npx) / 3.0  # mean over its three launches per frame (1, 2, 2 filters)
         achieved = ab / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+        rp = rocprof_avg_us(dominant)
         result = {
             "metric": "frames/sec at 640x480 (~15k keylines); 1-GPU and 8-stream/8-GPU batch",
             "value": fps,
@@ -489,11 +521,18 @@ def main():
                                             "this command (separate runs, committed), 2 x FETCH_SIZE + WRITE_SIZE per launch - NOT measured in "
                                             "this run" if pmc_profile_path() else None),
                          "avg_launch_us": dom_us, "launches": dom[1], "algorithmic_bytes_per_launch": ab,
+                         "avg_launch_us_basis": "HIP events around every 8th launch on the kernel's stream, in a window of 800 frames behind "
+                                                "the timed region (an event pair brackets the dispatch as well: a few us above rocprofv3's figure)",
+                         "rocprof_avg_launch_us": (rp[0] if rp else None), "rocprof_launches": (rp[1] if rp else None),
+                         "frac_rocprof": ((ab / (rp[0] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp else None),
+                         "rocprof_source": (f"{os.path.relpath(rocprof_stats_path(), ROOT)}: rocprofv3 --kernel-trace --stats of this command, "
+                                            "committed - NOT measured in this run" if rocprof_stats_path() else None),
                          "frame_algorithmic_bytes": 112 * npx + 1740 * n_keylines,
                          "frame_achieved_GBs": (112 * npx + 1740 * n_keylines) * (fps / world) / 1e9},
             "kernel_us_per_frame": {kname: round(v, 3) for kname, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
-            # per kernel: algorithmic bytes of one launch, its mean duration in the all-kernel event pass (24 frames, every launch
-            # bracketed by a HIP event pair on its stream: ~2-4 us above rocprofv3's figure for the short kernels), fraction of HBM peak
+            # per kernel: algorithmic bytes of one launch; its mean duration in the all-kernel event pass ("hip_event_us": 24 frames,
+            # every launch bracketed by a HIP event pair on its stream, ~2-4 us above rocprofv3's figure for the short kernels) and in
+            # the committed rocprofv3 summary of this command ("rocprof_us"); fraction of the HBM peak on either basis
             "kernel_roofline": kernel_roofline_table(prof, npx, n_keylines),
         }
         if cpu_multi is not None:
@@ -545,8 +584,11 @@ def kernel_roofline_table(prof, npx, n_keylines):
         if not ab or us <= 0:
             continue
         gbs = ab / (us * 1e-6) / 1e9
-        out[kname] = {"algorithmic_bytes": ab, "avg_launch_us": round(us, 3), "launches": calls, "achieved_GBs": round(gbs, 1),
-                      "frac": round(gbs / HBM_PEAK_GBS, 5)}
+        rp = rocprof_avg_us(kname)
+        out[kname] = {"algorithmic_bytes": ab, "hip_event_us": round(us, 3), "launches": calls, "achieved_GBs": round(gbs, 1),
+                      "frac": round(gbs / HBM_PEAK_GBS, 5),
+                      "rocprof_us": (round(rp[0], 3) if rp else None),
+                      "frac_rocprof": (round(ab / (rp[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if rp else None)}
     return out
 
 

@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <string>
 #include <vector>
@@ -30,6 +31,50 @@ struct SharedStreams {
   hipStream_t s_det, s_key, s_trk;
 };
 thread_local const SharedStreams* t_adopt_streams = nullptr;
+
+// ---- device-wide registry of the persistent LM kernels' users (this process) -------------------------------------------------
+// The workgroups of a persistent LM launch wait for each other's records, so all of them have to be resident together; the
+// occupancy check of a batch (lm_chain_b_max_lanes) assumes it has the device to itself. Every context with the persistent
+// kernel and every batch registers here when it is created; a batch sizes each LM launch to ITS SHARE of the device - capacity /
+// live users on that GPU - so that two batches (or a batch beside single streams) still fit together: slower, not timed out.
+// Kernels of other processes are invisible to this registry: what remains for them is the bounded poll (-9).
+struct Residency {
+  std::mutex mu;
+  std::map<int, std::map<const void*, int>> users;  // device -> owner -> workgroups of its largest LM launch
+};
+Residency& residency() {
+  static Residency r;
+  return r;
+}
+void residency_add(int device, const void* owner, int wgs) {
+  std::lock_guard<std::mutex> lk(residency().mu);
+  residency().users[device][owner] = wgs;
+}
+void residency_remove(int device, const void* owner) {
+  std::lock_guard<std::mutex> lk(residency().mu);
+  auto it = residency().users.find(device);
+  if (it != residency().users.end()) it->second.erase(owner);
+}
+int residency_users(int device) {
+  std::lock_guard<std::mutex> lk(residency().mu);
+  auto it = residency().users.find(device);
+  return it == residency().users.end() ? 0 : (int)it->second.size();
+}
+std::string residency_describe(int device, const void* self) {
+  std::lock_guard<std::mutex> lk(residency().mu);
+  auto it = residency().users.find(device);
+  int others = 0, wgs = 0;
+  if (it != residency().users.end())
+    for (auto& u : it->second)
+      if (u.first != self) {
+        ++others;
+        wgs += u.second;
+      }
+  char msg[200];
+  std::snprintf(msg, sizeof(msg), "%d other context(s) / batch(es) of this process run persistent LM kernels on GPU %d (up to %d workgroups "
+                "together); kernels of other processes are not visible to this check", others, device, wgs);
+  return msg;
+}
 
 // REBVIO_HIP_DM_HEAD / REBVIO_HIP_BATCH_DM_HEAD -> form of the directedMatch launch (track.hip: dm_head_wide, dm_compact)
 int dm_form_by_name(const char* e) {
@@ -164,7 +209,7 @@ void prof_group_end(hipStream_t s) {
 // under `mu`, which also serialises destroy against a release from another thread (an EdgeMap::SharedPtr kept by an
 // edge-image consumer, ros_rebvio.cpp:32-51, is released whenever that consumer lets go of it).
 struct LifeBlock {
-  std::mutex mu;
+  std::shared_mutex mu;  // shared: every entry point that takes a map alone, for its whole duration; exclusive: rebvio_hip_destroy
   std::atomic<bool> dead{false};
 };
 
@@ -261,6 +306,7 @@ struct rebvio_hip_ctx {
   uint64_t lm_stamp_n = 0;
   bool lm_stamp_spec = false;
   bool lm_persistent = true;
+  bool residency_registered = false;  // this context launches persistent LM kernels of its own (Residency)
   rebvio_hip_map* df_map = nullptr;
   // pinned host staging
   LmState* h_lm = nullptr;   // [2]
@@ -306,6 +352,11 @@ struct rebvio_hip_ctx {
     rebvio_hip_pair_out out;
     int keylines;
   };
+  // Pool bookkeeping (in_use, has_done / done / done_ref, release_seq, release_counter, df_map, the pool vector) is written by
+  // whoever releases a map - the tracking thread, or any thread that lets go of an EdgeMap (an edge-image consumer,
+  // ros_rebvio.cpp:32-51) - and read by the acquisition thread: one mutex around both sides, so that a map seen as free is seen
+  // with the event its next user has to wait for.
+  std::mutex pool_mu;
   std::vector<rebvio_hip_map*> frames;  // detected maps not yet consumed as "old"
   std::deque<InFlight> inflight;
   std::deque<Done> done;
@@ -362,7 +413,12 @@ void release_map(rebvio_hip_map* m, hipEvent_t done_ref);
 
 // A map handle whose context has been destroyed: every entry point that takes a map alone answers with this.
 inline bool map_dead(const rebvio_hip_map* m) { return !m || !m->life || m->life->dead.load(std::memory_order_acquire); }
+// Holds the life block (shared) for the rest of the calling function: a rebvio_hip_destroy on another thread waits until the
+// entry has returned instead of freeing the context under it (the check alone would leave a window between test and use).
 #define MAP_ALIVE_OR(m, ret)                                                   \
+  const std::shared_ptr<LifeBlock> life_hold_ = (m) ? (m)->life : nullptr;     \
+  std::shared_lock<std::shared_mutex> life_lock_;                              \
+  if (life_hold_) life_lock_ = std::shared_lock<std::shared_mutex>(life_hold_->mu); \
   do {                                                                         \
     if (map_dead(m)) {                                                         \
       g_err = "the map's context has been destroyed (rebvio_hip_destroy)";     \
@@ -426,6 +482,13 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   HIPCHK(hipMemset(d.st, 0, sizeof(MapState)));
   HIPCHK(hipMemset(d.mask, 0xFF, Pn * sizeof(int)));
   HIPCHK(hipMemset(d.df, 0xFF, Pn * sizeof(unsigned)));
+  // hipMemset on device memory returns BEFORE the fill has run (tools/memset_probe.hip on this runtime: the call takes 2.5 us, the
+  // device finishes 10 us later for 1.2 MB), on the null stream, which the context's non-blocking streams do not wait for. A map
+  // the pool grows by while the pipeline is running is handed to the detect kernels microseconds later: without this wait a late
+  // fill wiped what they had written - the state record (n = 0), the dense mask, the distance field (every tryVel evaluation a
+  // penalty: zero velocity, NaN covariance) - on a few per cent of fresh streams' first frames. (Round 3 saw exactly these records
+  // on its 192x144 stream and put them down to kernel-bound stop events)
+  HIPCHK(hipStreamSynchronize(nullptr));
   HIPCHK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->detected, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
@@ -450,6 +513,7 @@ void free_map_device(rebvio_hip_map* m) {
 
 int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m);
 rebvio_hip_map* acquire_map(rebvio_hip_ctx* c) {
+  std::lock_guard<std::mutex> pool_lk(c->pool_mu);
   // Oldest release first: a map is released in stream order, i.e. before its last consumer (the pair's B-chain) has
   // run; reusing the most recently released one makes the new frame's keyline kernels wait for that consumer.
   rebvio_hip_map* best = nullptr;
@@ -599,14 +663,34 @@ int detect_prepare(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t t
   return 0;
 }
 
+// A detect_launch that failed half way: the frame's map has been taken, the servo ring and last_detected have advanced and some of
+// its kernels may be queued. The map goes back to the pool, a staged host frame is dropped, and the context is marked failed
+// (every later push / detect reports -8 with this error) - the detector's state is one frame out of step and cannot be trusted.
+void detect_failed(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& job) {
+  {
+    std::lock_guard<std::mutex> lk(c->det_mu);
+    if (c->det_error.empty()) c->det_error = g_err.empty() ? std::string("detect launch failed") : g_err;
+  }
+  if (job.pin_slot >= 0) c->pin_staged[job.pin_slot].store(0, std::memory_order_release);
+  job.m->enqueued.store(1, std::memory_order_release);
+  release_map(job.m, nullptr);
+}
+
 int detect_common(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts, rebvio_hip_map** out) {
+  {
+    std::lock_guard<std::mutex> lk(c->det_mu);
+    if (!c->det_error.empty()) return fail_msg(c->det_error.c_str(), -8);
+  }
   rebvio_hip_ctx::DetJob job;
   int rc = detect_prepare(c, img_dev, is_u8, ts, &job);
   if (rc) return rc;
   // a queued asynchronous detect must be launched first (stream order = frame order)
   while (c->det_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   rc = detect_launch(c, job);
-  if (rc) return rc;
+  if (rc) {
+    detect_failed(c, job);
+    return rc;
+  }
   *out = job.m;
   return 0;
 }
@@ -659,9 +743,13 @@ int detect_async(rebvio_hip_ctx* c, const void* img_dev, int is_u8, uint64_t ts,
                                std::memory_order_relaxed);
       c->t_worker_n.fetch_add(1, std::memory_order_relaxed);
     }
+    if (rc) {
+      detect_failed(c, job);
+      return rc;
+    }
     job.m->enqueued.store(1, std::memory_order_release);
     *out = job.m;
-    return rc;
+    return 0;
   }
   if (!c->det_thread.joinable()) c->det_thread = std::thread(det_worker_main, c);
   job.m->enqueued.store(0, std::memory_order_relaxed);
@@ -796,9 +884,13 @@ int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, c
     char msg[256];
     std::snprintf(msg, sizeof(msg),
                   "persistent LM kernel: record exchange timed out (workgroup %d/%d thread %d waited for tag %u, last saw tag %u; "
-                  "tags issued so far %u)",
+                  "tags issued so far %u); ",
                   e[1], e[6], e[2], (unsigned)e[3], (unsigned)e[4], c->lm_tag_base);
-    return fail_msg(msg, -9);
+    return fail_msg((std::string(msg) + residency_describe(c->device, c)).c_str(), -9);
+  }
+  if (!c->residency_registered) {  // (the lane contexts of a batch never come here: the batch registers for them)
+    residency_add(c->device, c, (c->K.kmax + c->lm_threads - 1) / c->lm_threads);
+    c->residency_registered = true;
   }
   LmState* first = c->lm_zero;
   if (vel0[0] != 0.f || vel0[1] != 0.f || vel0[2] != 0.f) {
@@ -914,6 +1006,10 @@ void rebvio_hip_default_params(rebvio_hip_params* p, int rows, int cols) {
 }
 
 void rebvio_hip_reset_state(rebvio_hip_ctx* c) {
+  // While the streaming driver has pairs in flight the filter state lives on the device: they are completed first (their records
+  // stay available through rebvio_hip_next_record), so that no harvested record writes the old state back over the reset one.
+  if (!c->inflight.empty() || !c->frames.empty()) (void)rebvio_hip_flush(c);
+  c->wbg_shadow_valid = false;  // (the next stream's first pair uploads this state and starts the shadow from it)
   c->Bg[0] = c->Bg[1] = c->Bg[2] = 0.f;
   c->RGBias = hm::identity3();
   c->RGyro = hm::identity3();
@@ -1158,7 +1254,8 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   // Map handles the caller still holds outlive the context as inert husks: every map entry point checks `dead`, and the
   // husk is deleted by its rebvio_hip_map_release. The lock serialises this against a release running on another thread.
   const std::shared_ptr<LifeBlock> life = c->life;
-  std::lock_guard<std::mutex> life_lk(life->mu);
+  std::unique_lock<std::shared_mutex> life_lk(life->mu);
+  residency_remove(c->device, c);
   (void)hipSetDevice(c->device);
   if (std::getenv("REBVIO_HIP_DEBUG") && c->t_begin_n)
     std::fprintf(stderr, "[rebvio_hip] track_pair_begin over %llu pairs (us): enqueue %.1f  wait for the first half %.1f\n",
@@ -1421,7 +1518,7 @@ int rebvio_hip_map_upload(rebvio_hip_map* m, const rebvio_hip_keyline* keylines,
 void rebvio_hip_map_release(rebvio_hip_map* m) {
   if (!m) return;
   const std::shared_ptr<LifeBlock> life = m->life;
-  std::lock_guard<std::mutex> lk(life->mu);
+  std::shared_lock<std::shared_mutex> lk(life->mu);  // (against destroy; the pool's own state is under the context's pool_mu)
   if (life->dead.load(std::memory_order_acquire)) {  // the context is gone (its memory with it): drop the husk
     if (m->in_use) delete m;
     return;
@@ -1448,6 +1545,7 @@ void release_map(rebvio_hip_map* m, hipEvent_t done_ref = nullptr) {
         hipEventRecord(c->bf_done[r], c->s_trk) == hipSuccess)
       c->bf_copy_queued[r] = true;
   }
+  std::lock_guard<std::mutex> pool_lk(c->pool_mu);
   m->done_ref = done_ref;
   if (!done_ref) (void)hipEventRecord(m->done, c->s_trk);
   m->has_done = true;
@@ -2013,7 +2111,7 @@ int stream_harvest(rebvio_hip_ctx* c, int need) {
       if (q == hipErrorNotReady) break;
       HIPCHK(q);
     }
-    if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
+    if (*c->lm_bar_err) return fail_msg(("persistent LM kernel: record exchange timed out; " + residency_describe(c->device, c)).c_str(), -9);
     if (c->slot[b.slot]->seq != b.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);  // (pair a's counters ride in pair b's slot)
     const int frc = stream_finish_record(c, a, c->slot[b.slot]->old_st);
     if (frc) return frc;
@@ -2122,7 +2220,7 @@ int stream_drain(rebvio_hip_ctx* c) {
   if (c->inflight.size() == 1) {  // the last pair has no successor to carry its counters
     const rebvio_hip_ctx::InFlight a = c->inflight[0];
     HIPCHK(hipEventSynchronize(c->slot_ev[a.ev_slot]));
-    if (*c->lm_bar_err) return fail_msg("persistent LM kernel: record exchange timed out", -9);
+    if (*c->lm_bar_err) return fail_msg(("persistent LM kernel: record exchange timed out; " + residency_describe(c->device, c)).c_str(), -9);
     HIPCHK(hipMemcpyAsync(&c->h_st[1], a.nm->d.st, sizeof(MapState), hipMemcpyDeviceToHost, c->s_trk));
     HIPCHK(hipStreamSynchronize(c->s_trk));
     if (c->slot[a.slot]->seq != a.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);
@@ -2522,6 +2620,7 @@ struct rebvio_hip_batch {
   int lead = 4;
   int group = 2;          // steps queued together (REBVIO_HIP_BATCH_GROUP 1..4, see stream_enqueue_group)
   int lm_lanes_per_launch = 1;  // lanes whose LM workgroups the device holds together (lm_chain_b_max_lanes)
+  int lm_capacity_wgs = 0;      // ... and the workgroups that is (shared with the other registered users, see Residency)
   // REBVIO_HIP_DEBUG: host time per step of the detect worker's launches, of the caller's track enqueue and of its waits for
   // result slots (printed by rebvio_hip_batch_flush)
   bool dbg = false;
@@ -2560,6 +2659,7 @@ int batch_upload_map_entry(rebvio_hip_batch* b, int lane, rebvio_hip_map* m) {
   m->tab_idx = idx;
   m->canon = m->d;
   HIPCHK(hipMemcpy(b->maptab_dev + (size_t)lane * kLaneMaps + idx, &m->canon, sizeof(MapDev), hipMemcpyHostToDevice));
+  HIPCHK(hipStreamSynchronize(nullptr));  // (null-stream work is not ordered against the batch's non-blocking streams: see alloc_map)
   return 0;
 }
 inline unsigned map_swap_bits(const rebvio_hip_map* m) { return (m->d.rs != m->canon.rs ? 1u : 0u) | (m->d.grad != m->canon.grad ? 2u : 0u); }
@@ -2570,6 +2670,7 @@ void batch_release_map(rebvio_hip_map* m, bool record_done, hipEvent_t done_ref 
   if (!m || !m->in_use) return;
   rebvio_hip_ctx* c = m->ctx;
   wait_enqueued(m);
+  std::lock_guard<std::mutex> pool_lk(c->pool_mu);
   m->done_ref = done_ref;
   if (done_ref) {
     m->has_done = true;  // (the step's slot event, already recorded behind the maps' last consumer)
@@ -2680,7 +2781,7 @@ int batch_harvest(rebvio_hip_batch* b, int need) {
       HIPCHK(q);
     }
     for (int l = 0; l < b->B; ++l) {
-      if (*b->lane[l]->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
+      if (*b->lane[l]->lm_bar_err) return fail_msg(("batch: persistent LM kernel: record exchange timed out; " + residency_describe(b->device, b)).c_str(), -9);
       if (b->lane[l]->slot[n.slot]->seq != n.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);  // (step a's counters ride in step n's slots)
       st[(size_t)l] = b->lane[l]->slot[n.slot]->old_st;
     }
@@ -2757,7 +2858,11 @@ int batch_enqueue_group(rebvio_hip_batch* b, int nsteps) {
         spec_now = std::max(spec_now, ch);
     }
     const float frame_dt = (float)((double)(float)(nf.m[0]->ts - of.m[0]->ts) / 1000000.0);  // rebvio.cpp:183
-    launch_lm_chain_b(s, b->K, b->B, b->lm_lanes_per_launch, b->ls_dev, b->maptab_dev, dyn, calls, spec_now, glue_params(b->lane[0], frame_dt));
+    // this batch's share of the device: the capacity split evenly among the live users of the persistent kernels on this GPU
+    const int users = std::max(1, residency_users(b->device));
+    const int per_lane_wgs = (b->K.kmax + 511) / 512;
+    const int lanes_now = users <= 1 ? b->lm_lanes_per_launch : std::max(1, std::min(b->lm_lanes_per_launch, b->lm_capacity_wgs / users / per_lane_wgs));
+    launch_lm_chain_b(s, b->K, b->B, lanes_now, b->ls_dev, b->maptab_dev, dyn, calls, spec_now, glue_params(b->lane[0], frame_dt));
     const int gate = (int)b->P.global_min_matches_threshold;
     launch_b_chain_b(s, b->K, b->B, b->ls_dev, b->maptab_dev, dyn, b->P.search_range, gate > 0 ? gate : 0, b->dm_head_form);
     HIPCHK(hipGetLastError());
@@ -2794,7 +2899,7 @@ int batch_drain(rebvio_hip_batch* b) {
     HIPCHK(hipEventSynchronize(b->slot_ev[a.ev_slot]));
     std::vector<MapState> st((size_t)b->B);
     for (int l = 0; l < b->B; ++l) {
-      if (*b->lane[l]->lm_bar_err) return fail_msg("batch: persistent LM kernel: record exchange timed out", -9);
+      if (*b->lane[l]->lm_bar_err) return fail_msg(("batch: persistent LM kernel: record exchange timed out; " + residency_describe(b->device, b)).c_str(), -9);
       if (b->lane[l]->slot[a.slot]->seq != a.seq) return fail_msg(kStaleRecordMsg, kStaleRecord);
       HIPCHK(hipMemcpy(&st[(size_t)l], a.nf.m[l]->d.st, sizeof(MapState), hipMemcpyDeviceToHost));
     }
@@ -2821,6 +2926,7 @@ extern "C" {
 
 void rebvio_hip_batch_destroy(rebvio_hip_batch* b) {
   if (!b) return;
+  residency_remove(b->device, b);
   (void)hipSetDevice(b->device);
   if (b->det_thread.joinable()) {
     {
@@ -2877,6 +2983,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   }
   rebvio_hip_batch* b = new rebvio_hip_batch;
   b->lm_lanes_per_launch = lm_lanes_per_launch;
+  b->lm_capacity_wgs = lm_chain_b_capacity_wgs(p->device_id, p->keylines_max, (int)p->iterations + 1);
   b->dbg = std::getenv("REBVIO_HIP_DEBUG") != nullptr;
   if (const char* e = std::getenv("REBVIO_HIP_DETECT_WORKER")) b->det_worker = e[0] != '0';
   if (const char* e = std::getenv("REBVIO_HIP_BATCH_FUSE_DOG")) b->fuse_dog = e[0] == '1';
@@ -2888,6 +2995,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
   } guard{b};
   b->B = lanes;
   b->device = p->device_id;
+  residency_add(b->device, b, std::min(lanes, lm_lanes_per_launch) * ((p->keylines_max + 511) / 512));
   b->P = *p;
   // the three stages of a step overlap across steps like the stages of one stream do; one priority class for all
   // (see the comment on rebvio_hip_batch: priorities are what made pipelines starve each other)
@@ -3009,6 +3117,7 @@ int rebvio_hip_batch_push_u8_device(rebvio_hip_batch* b, const uint8_t* const* f
       while (b->det_done_steps.load(std::memory_order_acquire) < b->step) std::this_thread::yield();
       HIPCHK(hipStreamSynchronize(b->st.s_det));
       HIPCHK(hipMemcpy(b->ls_dev, b->ls_host.data(), b->ls_host.size() * sizeof(LaneStatic), hipMemcpyHostToDevice));
+      HIPCHK(hipStreamSynchronize(nullptr));
     }
     b->lens = with == B;
   }

@@ -250,6 +250,8 @@ void launch_lm_chain(hipStream_t s, const KParams& p, const MapDev& oldm, const 
 void launch_lm_final(hipStream_t s, const MapDev& oldm, int calls, LmState* st_in, LmState* st_out, const float* part_prev);
 // lanes whose persistent LM workgroups (512 threads, ceil(kmax / 512) per lane) the device holds resident at once
 int lm_chain_b_max_lanes(int device, int kmax, int calls);
+// ... and the workgroups of 512 threads that is (occupancy of the batched LM kernels x CUs, one block per CU taken off)
+int lm_chain_b_capacity_wgs(int device, int kmax, int calls);
 // the device glue as a launch of its own, behind k_ext_rot_vel (REBVIO_HIP_LM=percall: no persistent kernel to run it in)
 void launch_pair_glue(hipStream_t s, const MapDev& newm, const GlueArgs& ga);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],

@@ -3398,9 +3398,9 @@ void launch_lm_chain_b(hipStream_t s, const KParams& p, int lanes, int lanes_per
 // their lane's records, so all of them have to be resident together whatever order they are dispatched in. One block per CU is
 // taken off the occupancy query's answer where it admits several (MI355X_MICROARCH.md: the query can read one block per CU
 // high); kernels of the other streams only delay residency, they do not depend on this one. 0: not even one lane fits.
-int lm_chain_b_max_lanes(int device, int kmax, int calls) {
+int lm_chain_b_capacity_wgs(int device, int kmax, int calls) {
   int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 0;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lm_chain_b<512>, 512, 0) != hipSuccess) nb = 1;
   if (lm_spec_usable(kmax, calls)) {
@@ -3409,8 +3409,13 @@ int lm_chain_b_max_lanes(int device, int kmax, int calls) {
     nb = std::min(nb, nbs);
   }
   nb = nb > 1 ? nb - 1 : 1;
+  return nb * cus;
+}
+int lm_chain_b_max_lanes(int device, int kmax, int calls) {
+  const int cap = lm_chain_b_capacity_wgs(device, kmax, calls);
+  if (cap <= 0) return 1;
   const int per_lane = (kmax + 511) / 512;
-  return std::min(kMaxLanes, nb * cus / per_lane);
+  return std::min(kMaxLanes, cap / per_lane);
 }
 
 // second half of a batched step (every lane's inputs come from the record its LM kernel's glue left)

@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "rebvio/rebvio.hpp"
@@ -63,6 +66,60 @@ int main(int argc, char** argv) {
   p.keylines_ref = 2500; p.keylines_max = 3500;
   rebvio_hip_ctx* ctx = nullptr;
   if (rebvio_hip_create(&p, &ctx) != 0) return 1;
+  {
+    // Maps acquired on one thread (detect) while another thread releases earlier ones - what an edge-image consumer that lets
+    // go of its EdgeMap::SharedPtr does to the acquisition thread's pool (ros_rebvio.cpp:32-51). The pool's bookkeeping is
+    // under one mutex per context; the keyline counts must be those of the same frames detected and released on one thread.
+    const int rounds = 6 * N;
+    std::vector<int> serial((size_t)rounds), threaded((size_t)rounds, -1);
+    for (int i = 0; i < rounds; ++i) {
+      rebvio_hip_map* m = nullptr;
+      if (rebvio_hip_detect_u8(ctx, buf.data() + (size_t)(i % N) * W * H, 0, (uint64_t)i * 50000ull, &m) != 0) return 1;
+      serial[(size_t)i] = rebvio_hip_map_size(m);
+      rebvio_hip_map_release(m);
+    }
+    rebvio_hip_ctx* ctx2 = nullptr;
+    if (rebvio_hip_create(&p, &ctx2) != 0) return 1;
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::deque<std::pair<int, rebvio_hip_map*>> q;
+    bool done = false;
+    std::thread consumer([&] {
+      for (;;) {
+        std::pair<int, rebvio_hip_map*> e;
+        {
+          std::unique_lock<std::mutex> lk(qmu);
+          qcv.wait(lk, [&] { return done || !q.empty(); });
+          if (q.empty()) return;
+          e = q.front();
+          q.pop_front();
+        }
+        threaded[(size_t)e.first] = rebvio_hip_map_size(e.second);
+        rebvio_hip_map_release(e.second);
+      }
+    });
+    int rc_det = 0;
+    for (int i = 0; i < rounds && rc_det == 0; ++i) {
+      rebvio_hip_map* m = nullptr;
+      rc_det = rebvio_hip_detect_u8(ctx2, buf.data() + (size_t)(i % N) * W * H, 0, (uint64_t)i * 50000ull, &m);
+      if (rc_det == 0) {
+        std::lock_guard<std::mutex> lk(qmu);
+        q.emplace_back(i, m);
+      }
+      qcv.notify_one();
+    }
+    {
+      std::lock_guard<std::mutex> lk(qmu);
+      done = true;
+    }
+    qcv.notify_one();
+    consumer.join();
+    rebvio_hip_destroy(ctx2);
+    if (rc_det != 0 || serial != threaded) {
+      std::fprintf(stderr, "maps released on another thread: detect rc %d, counts %s\n", rc_det, serial == threaded ? "equal" : "differ");
+      return 1;
+    }
+  }
   rebvio_hip_map *m0 = nullptr, *m1 = nullptr;
   if (rebvio_hip_detect_u8(ctx, buf.data(), 0, 0, &m0) != 0) return 1;
   if (rebvio_hip_detect_u8(ctx, buf.data() + (size_t)W * H, 0, 50000, &m1) != 0) return 1;

@@ -1247,6 +1247,43 @@ def _batch_records(B, cam, streams, order, lens=None, **kw):
     return got
 
 
+def test_two_batches_share_one_gpu(B, c2_stream):
+    """Two 8-lane batches in ONE process on one GPU, their steps pushed alternately so that both have kernels in flight: the
+    persistent LM kernel of a batch needs all its workgroups resident together, and a batch alone sizes its launches to the
+    whole device (8 lanes x 32 workgroups of 512 threads at 16 k keylines). The device-wide registry of persistent-kernel users
+    (api.hip, Residency) gives each batch its share - half the device each here, two launches per step instead of one - so both
+    run to the end (slower, not into the bounded poll's -9) and every lane still produces the records of a stand-alone context."""
+    from rebvio_amd import synth
+    cam = c2_stream[1]
+    n, L = 24, 8
+    npx = cam.width * cam.height
+    streams = [c2_stream[0]] + [synth.render_stream(cam.width, cam.height, 8, stream_id=s)[0] for s in range(1, L)]
+    order = synth.pingpong_indices(8, n)
+    bats = [B.Batch(params_for(B, cam, **KW_C2), L) for _ in range(2)]
+    devs = [[bat.lanes[s].upload_frames(streams[(s + 3 * b) % L]) for s in range(L)] for b, bat in enumerate(bats)]
+    got = [[[] for _ in range(L)] for _ in range(2)]
+    for k, i in enumerate(order):
+        for b, bat in enumerate(bats):
+            outs, nks = bat.push_u8_device([d + int(i) * npx for d in devs[b]], k * 50000)
+            for s in range(L):
+                if outs[s].status >= 0:
+                    got[b][s].append(pair_tuple(outs[s], nks[s]))
+    for b, bat in enumerate(bats):
+        for outs, nks in bat.flush():
+            for s in range(L):
+                got[b][s].append(pair_tuple(outs[s], nks[s]))
+    for bat in bats:
+        bat.close()
+    want = {s: _stand_alone_records(B, cam, streams[s], order) for s in (0, 3, 7)}
+    for b in range(2):
+        for s in range(L):
+            assert len(got[b][s]) == n - 1, (b, s, len(got[b][s]))
+        for lane in (0, 4, 7):
+            src = (lane + 3 * b) % L
+            if src in want:
+                assert got[b][lane] == want[src], (b, lane)
+
+
 @pytest.mark.parametrize("L,env", [(3, {}), (4, {}), (8, {}), (4, {"REBVIO_HIP_LM": "seq"}), (4, {"REBVIO_HIP_LM": "spec3"}), (2, {"REBVIO_HIP_BATCH_DM_HEAD": "thread"}),
                                    (5, {"REBVIO_HIP_BATCH_DM_HEAD": "wide", "REBVIO_HIP_BATCH_LEAD": "6", "REBVIO_HIP_BATCH_GROUP": "3"}),
                                    (3, {"REBVIO_HIP_DETECT_WORKER": "0", "REBVIO_HIP_FUSE_DOG": "0"}),
