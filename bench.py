@@ -107,9 +107,7 @@ def algorithmic_bytes(kernel: str, P: int, N: int) -> float:
         # what is actually moved, not the algorithmic figure the roofline fraction is quoted on
         "k_lm_chain": 6 * 68 * N + 130 * N,
         "k_ext_rot_vel": 130 * N,
-        "k_directed_match": 192 * N,
-        "k_directed_match8": 192 * N,     # eight lanes per keyline: same compulsory bytes
-        "k_directed_match_c": 192 * N,    # one-launch compact form (round 4): head probes and long searches, same compulsory bytes
+        "k_directed_match_c": 192 * N,    # whole searchMatch in one launch (round 4): head probes and long searches
         "k_regularize": 60 * N,
         "k_depth_ekf": 48 * N,
     }

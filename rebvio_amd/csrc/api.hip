@@ -78,8 +78,8 @@ std::string residency_describe(int device, const void* self) {
 
 // REBVIO_HIP_DM_HEAD / REBVIO_HIP_BATCH_DM_HEAD -> form of the directedMatch launch (track.hip: dm_head_wide, dm_compact)
 int dm_form_by_name(const char* e) {
-  static const char* const names[] = {"", "thread", "wide", "compact", "compact128", "compact1", "compact64", "compact8", "compact8s"};
-  for (int i = 1; i < 9; ++i)
+  static const char* const names[] = {"", "compact8", "compact4", "compact1"};
+  for (int i = 1; i < 4; ++i)
     if (std::strcmp(e, names[i]) == 0) return i;
   return 0;
 }
@@ -285,8 +285,6 @@ struct rebvio_hip_ctx {
   float* part = nullptr;    // [kMaxLmCalls+1][maxblocks][kPartStride]
   float* xrv_part = nullptr;
   int* hist = nullptr;      // [128]
-  int* dm_work = nullptr;   // [keylines_max] directedMatch long-search queue
-  int* dm_work_n = nullptr; // its length (zero between pairs)
   float* fscratch = nullptr;
   int maxblocks = 0;
   // persistent LM kernel: record exchange words, tags consumed so far, sticky time-out flag
@@ -319,7 +317,7 @@ struct rebvio_hip_ctx {
   hm::M3 W_Bg{}, RGBias{}, RGyro{};
   LmState* lm_zero = nullptr;  // constant start state of minimizeVel (Vg = 0, rebvio.cpp:167)
   int lm_threads = 512;        // workgroup size of the persistent LM kernels (REBVIO_HIP_LM_THREADS: 256 | 512 | 1024)
-  int dm_head_form = 0;        // directedMatch head: 0 by map size, 1 thread per keyline, 2 eight lanes per keyline (REBVIO_HIP_DM_HEAD)
+  int dm_head_form = 0;        // directedMatch launch form: 0 by map size, 1 compact8, 2 compact4, 3 compact1 (REBVIO_HIP_DM_HEAD; track.hip dm_form)
   // Result slots. slot[0] also serves the per-pair API. The streaming driver (rebvio_hip_push_frame_u8_device) keeps the
   // WHOLE pair step on the device - the glue between the halves runs in front of the directedMatch head (glue.hpp) - and the
   // host reads a pair's records kSlots - 1 pairs late at most.
@@ -1195,9 +1193,6 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->hist, 128 * sizeof(int)));
   HIPCHK(hipMemset(c->hist, 0, 128 * sizeof(int)));
   // long-search queue: keyline indices, then three float4 of probe geometry per entry (dm_queue_put in track.hip)
-  HIPCHK(hipMalloc(&c->dm_work, (size_t)div_up(p->keylines_max, 256) * 256 * (sizeof(int) + 3 * sizeof(float4))));
-  HIPCHK(hipMalloc(&c->dm_work_n, sizeof(int)));
-  HIPCHK(hipMemset(c->dm_work_n, 0, sizeof(int)));
   HIPCHK(hipMalloc(&c->lm_zero, sizeof(LmState)));
   HIPCHK(hipMemset(c->lm_zero, 0, sizeof(LmState)));
   for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
@@ -1328,8 +1323,6 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->h_bf) (void)hipHostFree(c->h_bf);
   if (c->lm_zero) (void)hipFree(c->lm_zero);
-  if (c->dm_work) (void)hipFree(c->dm_work);
-  if (c->dm_work_n) (void)hipFree(c->dm_work_n);
   delete c;
 }
 
@@ -1761,8 +1754,7 @@ int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, vel, Rvel, Rback, vel_r, Rvel_r);
   HIPCHK(hipMemsetAsync(&nm->d.st->dm_matches, 0, 4 * sizeof(int), c->s_trk));  // dm_matches, dm_kf, reg_count, dm_queued
-  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, c->dm_work, c->dm_work_n, nullptr, c->dm_head_form);
-  HIPCHK(hipMemsetAsync(c->dm_work_n, 0, sizeof(int), c->s_trk));
+  launch_directed_match(c->s_trk, c->K, nm->d, om->d, vel_r, Rvel_r, Rback, max_radius, nullptr, c->dm_head_form);
   HIPCHK(hipGetLastError());
   MapState st;
   int rc = fetch_map_state(nm, &st, c->s_trk);
@@ -1776,7 +1768,7 @@ int rebvio_hip_regularize(rebvio_hip_ctx* c, rebvio_hip_map* m, int* count) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(trk_wait_ready(c->s_trk, m));
   HIPCHK(hipMemsetAsync(&m->d.st->reg_count, 0, sizeof(int), c->s_trk));
-  launch_regularize(c->s_trk, c->K, m->d, 0, nullptr);
+  launch_regularize(c->s_trk, c->K, m->d, 0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(m->d.rs, m->d.rs_tmp, (size_t)c->P.keylines_max * sizeof(float2), hipMemcpyDeviceToDevice, c->s_trk));
   MapState st;
@@ -1858,9 +1850,9 @@ void enqueue_b_chain(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, 
   }
   float vel_r[3], Rvel_r[9];
   rotate_inputs(c, g.V, g.P_V, g.Rgva, vel_r, Rvel_r);
-  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, g.Rgva, c->P.search_range, c->dm_work, c->dm_work_n, g.R0a, c->dm_head_form);
+  launch_directed_match(s, c->K, nm->d, om->d, vel_r, Rvel_r, g.Rgva, c->P.search_range, g.R0a, c->dm_head_form);
   const int gate = (int)c->P.global_min_matches_threshold;
-  launch_regularize_ekf(s, c->K, nm->d, g.V, gate > 0 ? gate : 0, c->dm_work_n, RT_next, c->hist);  // rebvio.cpp:256-259
+  launch_regularize_ekf(s, c->K, nm->d, g.V, gate > 0 ? gate : 0, RT_next, c->hist);  // rebvio.cpp:256-259
   std::swap(nm->d.rs, nm->d.rs_tmp);
   if (RT_next) {
     std::swap(nm->d.grad, nm->d.grad_tmp);
@@ -2187,9 +2179,9 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     glue_params_pre(c, &ga.gp);
     int rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part, ga);  // rebvio.cpp:167-177 + the glue of rebvio.cpp:177-233
     if (rc) return rc;
-    launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_work, c->dm_work_n, c->dm_head_form);
+    launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_head_form);
     const int gate = (int)c->P.global_min_matches_threshold;
-    launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->dm_work_n, c->hist);  // rebvio.cpp:256-259
+    launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->hist);  // rebvio.cpp:256-259
     std::swap(nm->d.rs, nm->d.rs_tmp);
     std::swap(nm->d.grad, nm->d.grad_tmp);
     nm->pre_rotated = true;
@@ -2628,7 +2620,7 @@ struct rebvio_hip_batch {
   bool det_worker = true;  // REBVIO_HIP_DETECT_WORKER
   bool fuse_dog = false;   // REBVIO_HIP_BATCH_FUSE_DOG=1
   double t_trk_enq = 0, t_slot_wait = 0;
-  int dm_head_form = 0;   // REBVIO_HIP_BATCH_DM_HEAD: 0 by lane count, 1 thread per keyline, 2 eight lanes per keyline
+  int dm_head_form = 0;   // REBVIO_HIP_BATCH_DM_HEAD: 0 by lane count and map size, 1 compact8, 2 compact4, 3 compact1
   bool poisoned = false;  // a step failed half way (some lanes prepared, others not): every later call is refused
   // detect-enqueue worker: launches the detect stage of a step while the caller thread launches the track stage (the
   // reference's data-acquisition thread, rebvio.cpp:28; same split as the single-stream driver)
@@ -3037,8 +3029,6 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
     L.lm_xch = c->lm_xch;
     L.lm_bar_err = c->lm_bar_err;
     L.hist = c->hist;
-    L.dm_work = c->dm_work;
-    L.dm_work_n = c->dm_work_n;
     for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
       L.slot[i] = c->slot[i];
       L.rec[i] = c->rec[i];

@@ -44,7 +44,7 @@ struct MapState {
   int dm_matches;      // directedMatch counters
   int dm_kf;
   int reg_count;
-  int dm_queued;       // directedMatch: long searches handed to the wave-per-keyline pass (diagnostic)
+  int dm_queued;       // directedMatch: long searches, i.e. keylines still open after the first four probe steps (diagnostic)
   int pad[7];
 };
 
@@ -255,20 +255,17 @@ int lm_chain_b_capacity_wgs(int device, int kmax, int calls);
 // the device glue as a launch of its own, behind k_ext_rot_vel (REBVIO_HIP_LM=percall: no persistent kernel to run it in)
 void launch_pair_glue(hipStream_t s, const MapDev& newm, const GlueArgs& ga);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
-                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
-                           const float* R0_on_the_fly, int head_form);
-// the same two launches with the second half's inputs read from *gd (device memory) at run time
+                           const float Rvel[9], const float Rback[9], float max_radius, const float* R0_on_the_fly, int head_form);
+// the same launch with the second half's inputs read from *gd (device memory) at run time
 void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
-                               int* work, int* work_n, int head_form);
-void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* work_n_reset,
-                               int* hist);
+                               int head_form);
+void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* hist);
 // fused regularize1Iter + depth EKF: reads m.rs, writes m.rs_tmp (caller swaps the pointers); Rnext != null also
 // applies the next pair's first rotation and bins sigma_rho into hist
-void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, int* work_n_reset,
-                           const float* Rnext, int* hist);
+void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, const float* Rnext, int* hist);
 void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& searched, const rebvio_hip_keyline& query,
                              const float vel[3], const float Rvel[9], const float Rback[9], float max_radius, int* out_dev);
-void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate, int* work_n_reset);
+void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int min_matches_gate);
 void launch_depth_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int use_tmp,
                       int min_matches_gate);
 void launch_render_edge_image(hipStream_t s, const KParams& p, const MapDev& m, const uint8_t* gray_or_null, uint8_t* rgb);
@@ -303,8 +300,6 @@ struct LaneStatic {
   unsigned long long* lm_xch;
   int* lm_bar_err;
   int* hist;
-  int* dm_work;
-  int* dm_work_n;
   PairSlot* slot[kPairSlots];  // pinned: LM state + map state records of a pair, written by the LM kernel
   GlueRec* rec[kPairSlots];    // pinned: what the device glue of a pair reports
   GlueDev* glue_dev;           // [kPairSlots] second-half inputs left by the directedMatch head

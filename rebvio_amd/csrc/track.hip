@@ -2093,36 +2093,9 @@ __device__ __forceinline__ void search_commit(MapDev& nm, const MapDev& om, int 
   *kf = (k.kf >= 0) ? 1 : 0;
 }
 
-// The long-search queue carries each entry's probe geometry next to its keyline index, so that pass 2 does not evaluate
-// search_setup (five IEEE divisions, a square root, two 3x3 products) a second time: work[0 .. cap) = keyline indices,
-// then cap records of three float4 (cap = keylines_max rounded up to 256).
-__device__ __forceinline__ int dm_queue_cap(const KParams& p) { return ((p.kmax + 255) / 256) * 256; }
-__device__ __forceinline__ float4* dm_queue_geom(int* work, const KParams& p) {
-  return reinterpret_cast<float4*>(work + dm_queue_cap(p));
-}
-__device__ __forceinline__ void dm_queue_put(int* work, const KParams& p, int pos, int idx, const SearchSetup& S) {
-  work[pos] = idx;
-  float4* g = dm_queue_geom(work, p) + 3 * (size_t)pos;
-  g[0] = make_float4(S.t_x, S.t_y, S.norm_t, S.pi0x);
-  g[1] = make_float4(S.pi0y, S.sigma2_t, S.dq_min, S.dq_max);
-  g[2] = make_float4(S.dq_rho, __int_as_float(S.t_steps), 0.f, 0.f);
-}
-__device__ __forceinline__ SearchSetup dm_queue_get(const float4& a, const float4& b, const float4& c) {
-  SearchSetup S;
-  S.t_x = a.x; S.t_y = a.y; S.norm_t = a.z; S.pi0x = a.w;
-  S.pi0y = b.x; S.sigma2_t = b.y; S.dq_min = b.z; S.dq_max = b.w;
-  S.dq_rho = c.x; S.t_steps = __float_as_int(c.y);
-  return S;
-}
+constexpr int kHeadSteps = 4;  // probe steps (2 probes each) of the head of a search: what most keylines are settled in
 
-constexpr int kDmSeqMax = 264;  // probe steps of one search: t_steps <= search_range + pixel_uncertainty_match + 1, search_range <= 255
-constexpr int kHeadSteps = 4;  // probe steps (2 probes each) tested by the per-keyline pass
-
-// Pass 1: one thread per keyline of the NEW map, the first kHeadSteps steps of the reference's alternating probe
-// order (edge_map.cpp:149-181). Their mask lookups are independent loads, the candidate keylines of all hits are
-// fetched together, acceptance runs in the reference's order. Keylines whose search is longer and still open are
-// queued for pass 2 (a wave with one such lane would otherwise idle 63 lanes for up to 40 more dependent steps).
-// vel / Rvel are already rotated by Rback on the host (:193-194).
+// vel / Rvel are already rotated by Rback on the host (edge_map.cpp:193-194).
 // gd != null: vel / Rvel / Rback / R0 come from *gd (uniform scalar loads) instead of the kernel arguments.
 struct DmArgs {
   Vec3 vel;
@@ -2155,397 +2128,10 @@ __device__ __forceinline__ DmArgs dm_args(const GlueDev* __restrict__ gd, const 
   return a;
 }
 
-__device__ __forceinline__ void directed_match_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
-                                                        float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
-  const uint2 vb = xcd_band_block();  // which keylines / tiles this workgroup takes: contiguous bands per XCD (common.hpp)
-  const int idx = vb.x * 256 + threadIdx.x;
-  const float2 pi = nm.pos_img[idx];  // bound-free early loads (arrays padded to the grid)
-  const float2 rsq = nm.rs[idx];
-  const float2 gq = nm.grad[idx];
-  const float gnq = nm.gnorm[idx];
-  const int n = nm.st->n;
-  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
-  if (A.skip) return;
-  const Vec3& vel = A.vel;
-  const Mat3 &Rvel = A.Rvel, &Rback = A.Rback, &R0 = A.R0;
-  const int rot = A.rot;
-  int found = -1;
-  int kf = 0;
-  bool more = false;
-  SearchSetup S{};
-  if (idx < n) {
-    S = search_setup(p, pi, rsq, gq, gnq, vel, Rvel, Rback, max_radius);
-    float tn = S.dq_rho;
-    float tp = S.dq_rho + 1.0f;
-    float tq[2 * kHeadSteps];
-    int prow[2 * kHeadSteps], pcol[2 * kHeadSteps];
-#pragma unroll
-    for (int j = 0; j < kHeadSteps; ++j) {
-      const bool active = j < S.t_steps;
-#pragma unroll
-      for (int i_idx = 0; i_idx < 2; ++i_idx) {
-        const float t = i_idx ? tp : tn;
-        const bool ok = active && (i_idx ? !(t > S.dq_max) : !(t < S.dq_min));
-        int pr = -1, pc = 0;
-        if (ok) {
-          const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
-          const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
-          if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) {
-            pr = row;
-            pc = col;
-          }
-        }
-        tq[j * 2 + i_idx] = t;
-        prow[j * 2 + i_idx] = pr;
-        pcol[j * 2 + i_idx] = pc;
-      }
-      tp += 1.0f;
-      tn -= 1.0f;
-    }
-    int cand[2 * kHeadSteps];
-#pragma unroll
-    for (int k = 0; k < 2 * kHeadSteps; ++k) cand[k] = (prow[k] >= 0) ? om.mask[prow[k] * p.cols + pcol[k]] : -1;
-    OldKl ck[2 * kHeadSteps];
-#pragma unroll
-    for (int k = 0; k < 2 * kHeadSteps; ++k)
-      if (cand[k] >= 0) ck[k] = load_old(om, cand[k], rot, R0, p.fm);
-    OldKl hit;
-#pragma unroll
-    for (int k = 0; k < 2 * kHeadSteps; ++k) {
-      if (found >= 0 || cand[k] < 0) continue;
-      if (search_accept(p, S, tq[k], ck[k].g, ck[k].gn, ck[k].rs, gq, gnq)) {
-        found = cand[k];
-        hit = ck[k];
-      }
-    }
-    if (found >= 0) search_commit(nm, om, idx, found, hit, &kf);
-    more = (found < 0) && (S.t_steps > kHeadSteps);
-  }
-  // queue the open long searches (order in the queue is irrelevant: each entry only touches its own keyline) and count
-  // the matches: ONE global atomic per workgroup and counter (same-address device-scope atomics execute one after the
-  // other at the memory side; per-wave atomics were a measurable part of this kernel)
-  __shared__ int w_more[4], w_base[4], b_found, b_kf;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const unsigned long long mm = __ballot(more);
-  const int c1 = wave_sum_i(found >= 0 ? 1 : 0);
-  const int c2 = wave_sum_i(kf);
-  if (threadIdx.x == 0) {
-    b_found = 0;
-    b_kf = 0;
-  }
-  if (lane == 0) w_more[wid] = __popcll(mm);
-  __syncthreads();
-  if (lane == 0) {
-    if (c1) atomicAdd(&b_found, c1);
-    if (c2) atomicAdd(&b_kf, c2);
-  }
-  if (threadIdx.x == 0) {
-    const int tot = w_more[0] + w_more[1] + w_more[2] + w_more[3];
-    int base = tot ? atomicAdd(work_n, tot) : 0;
-    for (int w = 0; w < 4; ++w) {
-      w_base[w] = base;
-      base += w_more[w];
-    }
-  }
-  __syncthreads();
-  if (more) dm_queue_put(work, p, w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull)), idx, S);
-  if (threadIdx.x == 0) {
-    if (b_found) atomicAdd(&nm.st->dm_matches, b_found);
-    if (b_kf) atomicAdd(&nm.st->dm_kf, b_kf);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_directed_match(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
-                                                        float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                        int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
-  directed_match_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd);
-}
-__global__ __launch_bounds__(256) void k_directed_match_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
-                                                          LaneDynB dyn, float max_radius) {
-  const LaneStatic& L = ls[blockIdx.z];
-  const LaneDyn d = dyn.v[blockIdx.z];
-  const Vec3 z3{};
-  const Mat3 z9{};
-  directed_match_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9, max_radius,
-                      gptr(L.dm_work), gptr(L.dm_work_n), 1, z9, gptr(L.glue_dev) + d.slot);
-}
-
-// Pass 1, wide form: EIGHT lanes per keyline of the NEW map, one per probe slot of the head (2 * kHeadSteps == 8). The
-// per-thread form above executes ~2900 instructions per wave (eight unrolled candidate fetches, each with the on-the-fly
-// rotation: six IEEE divisions and a double-precision 3x3 product) on 60 workgroups: it is bound by instruction latency
-// with one wave per SIMD, while 3/4 of the chip idles. Here every lane evaluates the (bit-identical) probe geometry of its
-// keyline, then ONE probe and at most ONE candidate; the first accepted slot in the reference's order is found with a
-// ballot over the eight lanes and that lane, which holds the rotated candidate, commits it. Same arithmetic per probe,
-// hence the same bits; ~1/6 of the instructions per wave on eight times the waves.
-__device__ __forceinline__ void directed_match8_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
-                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
-  const uint2 vb = xcd_band_block();  // which keylines / tiles this workgroup takes: contiguous bands per XCD (common.hpp)
-  static_assert(kHeadSteps == 4, "eight probe slots per keyline");
-  if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[48] = __builtin_amdgcn_s_memrealtime();
-  const int gid = vb.x * 256 + threadIdx.x;
-  const int idx = gid >> 3, slot = gid & 7;  // keyline, probe slot (slot = 2 * step + side; side 0: tn, 1: tp)
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  // bound-free early loads (idx < kmax rounded up to 32: arrays are padded to 1024), issued before the parameter block is read
-  const float2 pi = nm.pos_img[idx];
-  const float2 rsq = nm.rs[idx];
-  const float2 gq = nm.grad[idx];
-  const float gnq = nm.gnorm[idx];
-  const int n = nm.st->n;
-  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
-  if (A.skip) return;
-  bool acc = false, more = false;
-  int cand = -1;
-  OldKl ck{};
-  SearchSetup S{};
-  if (idx < n) {
-    S = search_setup(p, pi, rsq, gq, gnq, A.vel, A.Rvel, A.Rback, max_radius);
-    // t of this slot: the reference reaches step j by j repeated +1.0f / -1.0f (not dq_rho +- j: the roundings differ)
-    const int step = slot >> 1, side = slot & 1;
-    float tn = S.dq_rho, tp = S.dq_rho + 1.0f;
-    for (int j = 0; j < step; ++j) {
-      tp += 1.0f;
-      tn -= 1.0f;
-    }
-    const float t = side ? tp : tn;
-    const bool ok = (step < S.t_steps) && (side ? !(t > S.dq_max) : !(t < S.dq_min));
-    if (ok) {
-      const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
-      const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
-      if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) cand = om.mask[row * p.cols + col];
-    }
-    if (cand >= 0) {
-      ck = load_old(om, cand, A.rot, A.R0, p.fm);
-      acc = search_accept(p, S, t, ck.g, ck.gn, ck.rs, gq, gnq);
-    }
-    more = (slot == 0) && (S.t_steps > kHeadSteps);  // provisional: cleared below when one of the eight slots accepted
-  }
-  // first accepted slot of each keyline, in slot order
-  const unsigned long long am = __ballot(acc);
-  const unsigned grp = (unsigned)((am >> (lane & 56)) & 0xFFull);  // the eight lanes of this keyline
-  const bool winner = acc && ((grp & ((1u << slot) - 1u)) == 0u);
-  int kf = 0;
-  if (winner) search_commit(nm, om, idx, cand, ck, &kf);
-  more = more && (grp == 0u);
-  // queue + counters: wave -> workgroup (LDS) -> one global atomic per workgroup (see k_directed_match)
-  __shared__ int w_more[4], w_base[4], b_found, b_kf;
-  const unsigned long long mm = __ballot(more);
-  const int c1 = __popcll(__ballot(winner));
-  const int c2 = __popcll(__ballot(kf != 0));
-  if (threadIdx.x == 0) {
-    b_found = 0;
-    b_kf = 0;
-  }
-  if (lane == 0) w_more[wid] = __popcll(mm);
-  __syncthreads();
-  if (lane == 0) {
-    if (c1) atomicAdd(&b_found, c1);
-    if (c2) atomicAdd(&b_kf, c2);
-  }
-  if (threadIdx.x == 0) {
-    const int tot = w_more[0] + w_more[1] + w_more[2] + w_more[3];
-    int base = tot ? atomicAdd(work_n, tot) : 0;
-    for (int w = 0; w < 4; ++w) {
-      w_base[w] = base;
-      base += w_more[w];
-    }
-  }
-  __syncthreads();
-  if (more) dm_queue_put(work, p, w_base[wid] + __popcll(mm & ((1ull << lane) - 1ull)), idx, S);
-  if (threadIdx.x == 0) {
-    if (b_found) atomicAdd(&nm.st->dm_matches, b_found);
-    if (b_kf) atomicAdd(&nm.st->dm_kf, b_kf);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_directed_match8(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
-                                                         float max_radius, int* __restrict__ work, int* __restrict__ work_n,
-                                                         int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
-  directed_match8_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd);
-}
-__global__ __launch_bounds__(256) void k_directed_match8_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
-                                                           LaneDynB dyn, float max_radius) {
-  const LaneStatic& L = ls[blockIdx.z];
-  const LaneDyn d = dyn.v[blockIdx.z];
-  const Vec3 z3{};
-  const Mat3 z9{};
-  directed_match8_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9, max_radius,
-                       gptr(L.dm_work), gptr(L.dm_work_n), 1, z9, gptr(L.glue_dev) + d.slot);
-}
-
-// Pass 2: one WAVE per queued keyline. Lane l evaluates probe slot (kHeadSteps*2 + 64*round + l) of the reference's
-// sequence; the first accepted slot in that order (lowest slot index) is the match, found with a ballot.
-// tn/tp are produced by the same repeated -1.0f / +1.0f steps as the sequential loop (not dq_rho -/+ k).
-__device__ __forceinline__ void directed_match_tail_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
-                                                             float max_radius, const int* __restrict__ work,
-                                                             const int* __restrict__ work_n, int rot_, Mat3 R0_,
-                                                             const GlueDev* __restrict__ gd) {
-  // band order (common.hpp): the waves of one XCD take a contiguous part of the queue - neighbouring keylines search along
-  // parallel lines one pixel apart and meet the same mask lines and old-map keylines
-  const uint2 vb = xcd_band_block();
-  if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[49] = __builtin_amdgcn_s_memrealtime();
-  const int wave = (vb.x * 256 + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  // queue length, this wave's first entry (speculative: the queue array has kmax entries) and the parameter block are three
-  // independent loads: one round trip instead of three dependent ones
-  const int total = *work_n;
-  const int idx_first = work[min(wave, p.kmax - 1)];
-  const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
-  if (A.skip) return;
-  const Mat3& R0 = A.R0;  // (velocity, its covariance and Rback only enter the probe geometry, which the queue carries)
-  const int rot = A.rot;
-  (void)max_radius;
-  if (vb.x == 0 && threadIdx.x == 0) nm.st->dm_queued = total;
-  __shared__ float seq[4][2][kDmSeqMax];  // per wave: the probe sequences of the entry in work (see below)
-  int nfound = 0, nkf = 0;  // per lane: the lane that holds the accepted candidate commits it
-  const int wstride = (gridDim.x * 256) >> 6;
-
-  // software pipeline over this wave's queue entries: the next entry's keyline is loaded while the current one is searched
-  const float4* geom = dm_queue_geom(const_cast<int*>(work), p);
-  int idx = (wave < total) ? idx_first : 0;
-  const int w0 = min(wave, p.kmax - 1);
-  float4 ga = geom[3 * (size_t)w0], gb = geom[3 * (size_t)w0 + 1], gc = geom[3 * (size_t)w0 + 2];
-  float2 gq = nm.grad[idx];
-  float gnq = nm.gnorm[idx];
-  for (int w = wave; w < total; w += wstride) {
-    const int idx_cur = idx;
-    const float2 gq_cur = gq;
-    const float gnq_cur = gnq;
-    const SearchSetup S = dm_queue_get(ga, gb, gc);  // probe geometry as the first pass computed it
-    if (w + wstride < total) {
-      idx = work[w + wstride];
-      ga = geom[3 * (size_t)(w + wstride)];
-      gb = geom[3 * (size_t)(w + wstride) + 1];
-      gc = geom[3 * (size_t)(w + wstride) + 2];
-      gq = nm.grad[idx];
-      gnq = nm.gnorm[idx];
-    }
-    bool done = false;
-    // two probe slots per lane and trip (slot, slot + 64): a search over the full +-42 range (what an unmatched keyline
-    // runs through) is ONE gather round trip instead of two; acceptance is still taken in slot order
-    for (int slot0 = 2 * kHeadSteps; slot0 < 2 * S.t_steps && !done; slot0 += 128) {
-      float tt[2];
-      int cand[2];
-      // t of this lane's two slots. The reference reaches step k by k repeated +1.0f / -1.0f (not dq_rho +- k: the
-      // roundings differ), so the sequence is walked ONCE, uniformly for the wave, and every lane picks its two elements
-      // (a per-lane loop to its own step count is the same arithmetic but diverges and costs ~3 us per entry).
-      const int stepA = (slot0 + lane) >> 1, stepB = stepA + 32;
-      const int odd = (slot0 + lane) & 1;  // both slots of a lane have the same parity
-      {
-        // The two chains (tn: -1.0f steps from dq_rho, even slots; tp: +1.0f steps from dq_rho + 1, odd slots; x - 1.0f
-        // and x + (-1.0f) are the same IEEE operation) are produced ONCE per wave by lanes 0 and 1 into LDS - one add and
-        // one LDS store per step - and every lane then reads its two elements, instead of all lanes walking a chain with
-        // two compares and two selects per step.
-        const int jmax = min(min(S.t_steps - 1, (slot0 + 127) >> 1), kDmSeqMax - 1);  // (rebvio_hip_create bounds t_steps)
-        float* sq = seq[threadIdx.x >> 6][odd];
-        if (lane < 2) {
-          float x = odd ? S.dq_rho + 1.0f : S.dq_rho;
-          const float d = odd ? 1.0f : -1.0f;
-          for (int j = 0; j <= jmax; ++j) {
-            sq[j] = x;
-            x += d;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        tt[0] = (stepA <= jmax) ? sq[stepA] : 0.f;
-        tt[1] = (stepB <= jmax) ? sq[stepB] : 0.f;
-        __builtin_amdgcn_wave_barrier();  // the next round / entry rewrites the sequence
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int step = h ? stepB : stepA;
-        const float t = tt[h];
-        const bool ok = (step < S.t_steps) && (odd ? !(t > S.dq_max) : !(t < S.dq_min));
-        int cd = -1;
-        if (ok) {
-          const int row = cvtt_f32(roundf(S.t_y * t + S.pi0y));
-          const int col = cvtt_f32(roundf(S.t_x * t + S.pi0x));
-          if ((unsigned)row < (unsigned)p.rows && (unsigned)col < (unsigned)p.cols) cd = om.mask[(size_t)row * p.cols + col];
-        }
-        cand[h] = cd;
-      }
-      // Candidates are sparse (~5 % of the probed pixels hold a keyline), so fetching + rotating + testing both slots of
-      // every lane runs that code twice for mostly idle lanes. Pass 1 handles each lane's EARLIEST candidate (slot A if it
-      // has one, else slot B); only if no slot-A candidate was accepted anywhere and some lane holds two candidates does
-      // pass 2 evaluate those lanes' slot B. Order of acceptance is unchanged: every A slot (slot0 + lane) precedes every
-      // B slot (slot0 + 64 + lane), within a pass the lowest lane.
-      const int h1 = (cand[0] >= 0) ? 0 : 1;
-      int c_sel = h1 ? cand[1] : cand[0];
-      float t_sel = h1 ? tt[1] : tt[0];
-      OldKl ck{};
-      bool acc = false;
-      if (c_sel >= 0) {
-        ck = load_old(om, c_sel, rot, R0, p.fm);
-        acc = search_accept(p, S, t_sel, ck.g, ck.gn, ck.rs, gq_cur, gnq_cur);
-      }
-      unsigned long long am = __ballot(acc && h1 == 0);
-      if (!am) {
-        const bool both = cand[0] >= 0 && cand[1] >= 0;
-        bool acc_b = acc && h1 == 1;
-        if (__ballot(both)) {
-          if (both) {
-            c_sel = cand[1];
-            ck = load_old(om, c_sel, rot, R0, p.fm);
-            acc_b = search_accept(p, S, tt[1], ck.g, ck.gn, ck.rs, gq_cur, gnq_cur);
-          }
-        }
-        acc = acc_b;
-        am = __ballot(acc_b);
-      }
-      if (am) {
-        done = true;
-        if (lane == __ffsll((long long)am) - 1) {  // first accepted slot in reference order: this lane owns the match
-          int kf = 0;
-          search_commit(nm, om, idx_cur, c_sel, ck, &kf);
-          nfound += 1;
-          nkf += kf;
-        }
-      }
-    }
-  }
-  // match counters: wave -> workgroup (LDS) -> one global atomic per workgroup. A global atomic per wave meant ~2.4k
-  // same-address device-scope atomics per launch, which execute one after the other at the memory side and, not the
-  // searches, set the duration of this kernel.
-  __shared__ int blk_found, blk_kf;
-  if (threadIdx.x == 0) {
-    blk_found = 0;
-    blk_kf = 0;
-  }
-  __syncthreads();
-  nfound = wave_sum_i(nfound);
-  nkf = wave_sum_i(nkf);
-  if (lane == 0) {
-    if (nfound) atomicAdd(&blk_found, nfound);
-    if (nkf) atomicAdd(&blk_kf, nkf);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (blk_found) atomicAdd(&nm.st->dm_matches, blk_found);
-    if (blk_kf) atomicAdd(&nm.st->dm_kf, blk_kf);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_directed_match_tail(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
-                                                             float max_radius, const int* __restrict__ work,
-                                                             const int* __restrict__ work_n, int rot_, Mat3 R0_,
-                                                             const GlueDev* __restrict__ gd) {
-  directed_match_tail_body(p, nm, om, vel_, Rvel_, Rback_, max_radius, work, work_n, rot_, R0_, gd);
-}
-__global__ __launch_bounds__(256) void k_directed_match_tail_b(KParams p, const LaneStatic* __restrict__ ls,
-                                                               const MapDev* __restrict__ maptab, LaneDynB dyn, float max_radius) {
-  const LaneStatic& L = ls[blockIdx.z];
-  const LaneDyn d = dyn.v[blockIdx.z];
-  const Vec3 z3{};
-  const Mat3 z9{};
-  directed_match_tail_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9,
-                           max_radius, gptr(L.dm_work), gptr(L.dm_work_n), 1, z9, gptr(L.glue_dev) + d.slot);
-}
-
-// ---- directedMatch, compact form (round 4): ONE launch, dense lanes in every expensive phase -------------------------------
-// The two-launch forms above spend most of their instructions on mostly idle lanes: a probe finds a keyline of the old map on
+// ---- directedMatch (round 4): ONE launch, dense lanes in every expensive phase -----------------------------------------------
+// The two-launch forms of rounds 1-3 (a head kernel with one thread or eight lanes per keyline for the first four probe steps,
+// a queue of the searches still open, a tail kernel with one wave per queued search; removed, DESIGN.md 6e has their numbers)
+// spent most of their instructions on mostly idle lanes: a probe finds a keyline of the old map on
 // ~5 % of the pixels it looks at (1.5 of the eight head probes of a keyline, 2 of a long search's ~35), yet the candidate
 // fetch + second rotateKeylines + acceptance test (six IEEE divisions, a double-accumulated 3x3 product: ~350 instructions)
 // runs once per probe SLOT of the wave, and the long searches take a second launch whose waves hold one keyline each behind
@@ -2972,8 +2558,7 @@ __global__ void k_search_match_one(KParams p, MapDev om, float2 pi, float2 rsq, 
 }
 
 // ---- EdgeMap::regularize1Iter (edge_map.cpp:220-259): Jacobi step, results staged in rs_tmp ----------------------
-__global__ __launch_bounds__(256) void k_regularize(KParams p, MapDev m, int gate_min_matches, int* __restrict__ work_n_reset) {
-  if (work_n_reset && blockIdx.x == 0 && threadIdx.x == 0) *work_n_reset = 0;  // directedMatch queue of this pair is consumed
+__global__ __launch_bounds__(256) void k_regularize(KParams p, MapDev m, int gate_min_matches) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float2 rs = m.rs[idx];  // bound-free early loads
   const int in = m.id_next[idx], ip = m.id_prev[idx];
@@ -3054,12 +2639,11 @@ __global__ __launch_bounds__(256) void k_depth_ekf(KParams p, MapDev m, Vec3 vel
 // (rebvio.cpp:165) and binned for its estimateQuantile, which removes that pair's k_rotate launch.
 // gd != null: vel / next rotation come from *gd; gd->nan_v (rebvio.cpp:236) leaves rho untouched like the match gate.
 __device__ __forceinline__ void regularize_ekf_body(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
-                                                        int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
+                                                        int next_rot_, Mat3 Rnext_,
                                                         int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
   const uint2 vb = xcd_band_block();  // which keylines / tiles this workgroup takes: contiguous bands per XCD (common.hpp)
   __shared__ int sh[128];
   if (p.dbg && vb.x == 0 && threadIdx.x == 0) p.dbg[50] = __builtin_amdgcn_s_memrealtime();
-  if (work_n_reset && vb.x == 0 && threadIdx.x == 0) *work_n_reset = 0;
   const int idx = vb.x * 256 + threadIdx.x;
   const float2 rs = m.rs[idx];  // bound-free early loads, issued before the parameter block is read
   const int in = m.id_next[idx], ip = m.id_prev[idx];
@@ -3169,9 +2753,9 @@ __device__ __forceinline__ void regularize_ekf_body(KParams p, MapDev m, Vec3 ve
 }
 
 __global__ __launch_bounds__(256) void k_regularize_ekf(KParams p, MapDev m, Vec3 vel_, int gate_min_matches,
-                                                        int* __restrict__ work_n_reset, int next_rot_, Mat3 Rnext_,
+                                                        int next_rot_, Mat3 Rnext_,
                                                         int* __restrict__ hist, int hist_bins, const GlueDev* __restrict__ gd) {
-  regularize_ekf_body(p, m, vel_, gate_min_matches, work_n_reset, next_rot_, Rnext_, hist, hist_bins, gd);
+  regularize_ekf_body(p, m, vel_, gate_min_matches, next_rot_, Rnext_, hist, hist_bins, gd);
 }
 __global__ __launch_bounds__(256) void k_regularize_ekf_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
                                                           LaneDynB dyn, int gate_min_matches) {
@@ -3179,7 +2763,7 @@ __global__ __launch_bounds__(256) void k_regularize_ekf_b(KParams p, const LaneS
   const LaneDyn d = dyn.v[blockIdx.z];
   const Vec3 z3{};
   const Mat3 z9{};
-  regularize_ekf_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), z3, gate_min_matches, gptr(L.dm_work_n), 0, z9, gptr(L.hist), p.quantile_num_bins,
+  regularize_ekf_body(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)), z3, gate_min_matches, 0, z9, gptr(L.hist), p.quantile_num_bins,
                       gptr(L.glue_dev) + d.slot);
 }
 
@@ -3271,84 +2855,43 @@ void launch_ext_rot_vel(hipStream_t s, const KParams& p, const MapDev& oldm, con
                      calls, (const LmState*)st_in, st_out, part_prev, xrv_part, vec3(vel_manual), slot, hist_to_zero, seq);
 }
 
-// grid of the wave-per-keyline pass: the queue holds a few thousand long searches, each a chain of dependent gathers - more
-// waves in flight shorten the pass until the dispatch of the grid itself shows (640x480 / 16k keylines: 512 workgroups beat
-// 768, 1024 and 2048 by 3 %; 1280x960 / 64k: ~10k queue entries)
-static int dm_tail_blocks(int kmax) { return std::max(512, std::min(1024, kmax / 32)); }
 
-// Pass 1 form. Eight lanes per keyline shorten the dependent instruction chain of a wave sixfold and pay for it with an
-// eightfold redundant probe set-up: a win while the launch is latency-bound on a mostly idle chip (16k keylines: 11.6 vs
-// 13.8 us), a loss once the eight-fold grid fills it (64k keylines: 36 vs 24 us). head_form: 0 by map size, 1 thread per
-// keyline, 2 eight lanes per keyline (REBVIO_HIP_DM_HEAD, read when the context is created).
-// Form of the directedMatch launch (REBVIO_HIP_DM_HEAD / REBVIO_HIP_BATCH_DM_HEAD, read at create; 0 = chosen here):
-//   1 "thread", 2 "wide": the two-launch forms of rounds 1-3 (k_directed_match / k_directed_match8 + k_directed_match_tail)
-//   3..8: the one-launch compact form k_directed_match_c<threads, lanes per keyline>: 3 "compact" <256, 4>, 4 "compact128" <128, 4>,
-//   5 "compact1" <64, 1>, 6 "compact64" <64, 4>, 7 "compact8" <512, 8>, 8 "compact8s" <256, 8>
+// Form of the directedMatch launch, k_directed_match_c<threads, lanes per keyline> (REBVIO_HIP_DM_HEAD / REBVIO_HIP_BATCH_DM_HEAD, read
+// at create; 0 = chosen here): 1 "compact8" <512, 8>, 2 "compact4" <256, 4>, 3 "compact1" <64, 1>.
 // One stream of up to 32 768 keylines takes <512, 8>: eight keylines per wave, 1 875 short waves on an idle chip (MI355X, 640x480 /
-// 15 k keylines: 15.6 k frames/s against 15.2 k for <256, 4>, 13.7 k for the two-launch wide form; the kernel 11.5 us against 21).
-// Larger maps and batches of four lanes or more, where the chip is full, take the form with the fewest instructions, <64, 1>.
+// 15 k keylines: 15.6 k frames/s against 15.2 k for <256, 4>, 12.1 k for <64, 1>, 13.7 k for the two-launch form of round 3).
+// Larger maps and batches of four lanes or more, where the chip is full, take the form with the fewest instructions, <64, 1>
+// (1280x960 / 57 k keylines: 7.07 k frames/s against 6.26 k for <256, 4> and 6.69 k for round 3's form).
 static int dm_form(int kmax, int head_form, int lanes) {
-  if (head_form) return head_form;
-  return (kmax <= 32768 && lanes < 4) ? 7 : 5;
+  if (head_form >= 1 && head_form <= 3) return head_form;
+  return (kmax <= 32768 && lanes < 4) ? 1 : 3;
 }
-static bool dm_compact(int form) { return form >= 3 && form <= 8; }
-#define RH_DMC_DISPATCH(KERNEL, head_form, kmax, zdim, stream, ...)                                                                            \
+#define RH_DMC_DISPATCH(KERNEL, form, kmax, zdim, stream, ...)                                                                                 \
   do {                                                                                                                                         \
-    switch (head_form) {                                                                                                                       \
-      case 3: RH_LAUNCH_NAMED(#KERNEL "<256,4>", (KERNEL<256, 4>), dim3(div_up(kmax, 64), 1, zdim), dim3(256), 0, stream, __VA_ARGS__); break; \
-      case 4: RH_LAUNCH_NAMED(#KERNEL "<128,4>", (KERNEL<128, 4>), dim3(div_up(kmax, 32), 1, zdim), dim3(128), 0, stream, __VA_ARGS__); break; \
-      case 6: RH_LAUNCH_NAMED(#KERNEL "<64,4>", (KERNEL<64, 4>), dim3(div_up(kmax, 16), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;    \
-      case 7: RH_LAUNCH_NAMED(#KERNEL "<512,8>", (KERNEL<512, 8>), dim3(div_up(kmax, 64), 1, zdim), dim3(512), 0, stream, __VA_ARGS__); break; \
-      case 8: RH_LAUNCH_NAMED(#KERNEL "<256,8>", (KERNEL<256, 8>), dim3(div_up(kmax, 32), 1, zdim), dim3(256), 0, stream, __VA_ARGS__); break; \
+    switch (form) {                                                                                                                            \
+      case 1: RH_LAUNCH_NAMED(#KERNEL "<512,8>", (KERNEL<512, 8>), dim3(div_up(kmax, 64), 1, zdim), dim3(512), 0, stream, __VA_ARGS__); break; \
+      case 2: RH_LAUNCH_NAMED(#KERNEL "<256,4>", (KERNEL<256, 4>), dim3(div_up(kmax, 64), 1, zdim), dim3(256), 0, stream, __VA_ARGS__); break; \
       default: RH_LAUNCH_NAMED(#KERNEL "<64,1>", (KERNEL<64, 1>), dim3(div_up(kmax, 64), 1, zdim), dim3(64), 0, stream, __VA_ARGS__); break;   \
     }                                                                                                                                          \
   } while (0)
-static bool dm_head_wide(int kmax, int head_form) {
-  if (head_form) return head_form == 2;
-  return kmax <= 32768;
-}
 
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
-                           const float Rvel[9], const float Rback[9], float max_radius, int* work, int* work_n,
-                           const float* R0_on_the_fly, int head_form) {
-  head_form = dm_form(p.kmax, head_form, 1);
-  // *work_n is zero on entry (reset by the kernel that follows the tail, or by the caller)
+                           const float Rvel[9], const float Rback[9], float max_radius, const float* R0_on_the_fly, int head_form) {
+  const int form = dm_form(p.kmax, head_form, 1);
   const int rot = R0_on_the_fly ? 1 : 0;
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
-  if (dm_compact(head_form)) {
-    RH_DMC_DISPATCH(k_directed_match_c, head_form, p.kmax, 1, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius, rot, R0,
-                    (const GlueDev*)nullptr);
-    return;
-  }
-  if (dm_head_wide(p.kmax, head_form))
-    RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback),
-              max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr);
-  else
-    RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel),
-                       mat3(Rback), max_radius, work, work_n, rot, R0, (const GlueDev*)nullptr);
-  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius,
-            (const int*)work, (const int*)work_n, rot, R0, (const GlueDev*)nullptr);
+  RH_DMC_DISPATCH(k_directed_match_c, form, p.kmax, 1, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius, rot, R0,
+                  (const GlueDev*)nullptr);
 }
 
-// the same two launches with the second half's inputs read from *gd at run time: the record the pair's LM kernel left
-// (device glue, glue_dev.hpp)
+// the same launch with the second half's inputs read from *gd at run time: the record the pair's LM kernel left (device glue,
+// glue_dev.hpp)
 void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
-                               int* work, int* work_n, int head_form) {
-  head_form = dm_form(p.kmax, head_form, 1);
+                               int head_form) {
+  const int form = dm_form(p.kmax, head_form, 1);
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-  if (dm_compact(head_form)) {
-    RH_DMC_DISPATCH(k_directed_match_c, head_form, p.kmax, 1, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, 1, mat3(I), gd);
-    return;
-  }
-  if (dm_head_wide(p.kmax, head_form))
-    RH_LAUNCH(k_directed_match8, dim3(div_up(p.kmax, 32)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
-              work, work_n, 1, mat3(I), gd);
-  else
-    RH_LAUNCH(k_directed_match, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, work,
-              work_n, 1, mat3(I), gd);
-  RH_LAUNCH(k_directed_match_tail, dim3(dm_tail_blocks(p.kmax)), dim3(256), 0, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius,
-            (const int*)work, (const int*)work_n, 1, mat3(I), gd);
+  RH_DMC_DISPATCH(k_directed_match_c, form, p.kmax, 1, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, 1, mat3(I), gd);
 }
 
 void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& searched, const rebvio_hip_keyline& q, const float vel[3],
@@ -3358,21 +2901,19 @@ void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& sear
             mat3(Rback), max_radius, out_dev);
 }
 
-void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate, int* work_n_reset) {
-  RH_LAUNCH(k_regularize, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, gate, work_n_reset);
+void launch_regularize(hipStream_t s, const KParams& p, const MapDev& m, int gate) {
+  RH_LAUNCH(k_regularize, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, gate);
 }
 
-void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, int* work_n_reset,
-                           const float* Rnext, int* hist) {
+void launch_regularize_ekf(hipStream_t s, const KParams& p, const MapDev& m, const float vel[3], int gate, const float* Rnext, int* hist) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(vel), gate, work_n_reset, Rnext ? 1 : 0,
+  RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(vel), gate, Rnext ? 1 : 0,
             mat3(Rnext ? Rnext : I), hist, p.quantile_num_bins, (const GlueDev*)nullptr);
 }
 
-void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* work_n_reset,
-                               int* hist) {
+void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* hist) {
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-  RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(z), gate, work_n_reset, 0, mat3(I), hist,
+  RH_LAUNCH(k_regularize_ekf, dim3(div_up(p.kmax, 256)), dim3(256), 0, s, p, m, vec3(z), gate, 0, mat3(I), hist,
                  p.quantile_num_bins, g_dev);
 }
 
@@ -3422,21 +2963,8 @@ int lm_chain_b_max_lanes(int device, int kmax, int calls) {
 void launch_b_chain_b(hipStream_t s, const KParams& p, int lanes, const LaneStatic* ls, const MapDev* maptab, const LaneDynB& dyn,
                       float max_radius, int gate, int head_form) {
   const unsigned z = (unsigned)lanes;
-  // head form: eight lanes per keyline is the low-latency form while the chip is mostly idle; from a few lanes on the chip is
-  // full and the thread-per-keyline form (an eighth of the waves) is the cheaper one (REBVIO_HIP_BATCH_DM_HEAD=wide|thread,
-  // read when the batch is created)
-  head_form = dm_form(p.kmax, head_form, lanes);
-  const bool wide = head_form == 2;
-  if (dm_compact(head_form)) {
-    RH_DMC_DISPATCH(k_directed_match_c_b, head_form, p.kmax, z, s, p, ls, maptab, dyn, max_radius);
-    RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
-    return;
-  }
-  if (wide)
-    RH_LAUNCH(k_directed_match8_b, dim3(div_up(p.kmax, 32), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
-  else
-    RH_LAUNCH(k_directed_match_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
-  RH_LAUNCH(k_directed_match_tail_b, dim3(dm_tail_blocks(p.kmax), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, max_radius);
+  const int form = dm_form(p.kmax, head_form, lanes);
+  RH_DMC_DISPATCH(k_directed_match_c_b, form, p.kmax, z, s, p, ls, maptab, dyn, max_radius);
   RH_LAUNCH(k_regularize_ekf_b, dim3(div_up(p.kmax, 256), 1, z), dim3(256), 0, s, p, ls, maptab, dyn, gate);
 }
 

@@ -97,7 +97,7 @@ def test_stage_map_covers_every_kernel_name():
     import bench
     names = ["k_front_end_u8", "k_rowscan<0>", "k_rowscan<1>", "k_rowscan<2>", "k_colscan", "k_dog_mag", "k_keyline_flag",
              "k_keyline_emit", "k_join_edges", "k_df_tiles<32>", "k_df_bin", "k_lm_chain<512>", "k_directed_match_c<512,8>",
-             "k_directed_match_tail", "k_regularize_ekf", "k_rotate"]
+             "k_directed_match_c_b<64,1>", "k_regularize_ekf", "k_rotate"]
     per = {n: 1.0 for n in names}
     st = bench.stage_us(per)
     assert sum(v["us_per_frame"] for v in st.values()) == pytest.approx(len(names))

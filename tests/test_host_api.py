@@ -128,7 +128,7 @@ def test_edge_maps_outlive_their_pipeline(host_lib, tmp_path):
 def test_host_class_modes_publish_the_same_records(host_lib, tmp_path):
     """rebvio::Rebvio with its edge-image callback reading a keyline of every fresh map (as ros_rebvio.cpp:44 does), under the
     backend's remaining switches: the sequential and the per-call LM kernels, the other workgroup sizes, the
-    thread-per-keyline directedMatch head, flat stream priorities. None of them may change a digit of the output."""
+    one-lane-per-keyline directedMatch kernel, flat stream priorities. None of them may change a digit of the output."""
     from rebvio_amd import synth
     n = 40
     frames, cam = synth.render_stream(320, 240, n)
@@ -151,7 +151,7 @@ def test_host_class_modes_publish_the_same_records(host_lib, tmp_path):
     assert run(REBVIO_HIP_LM="seq") == base
     assert run(REBVIO_HIP_LM="percall") == base
     assert run(REBVIO_HIP_LM_THREADS="1024") == base
-    assert run(REBVIO_HIP_DM_HEAD="thread") == base
+    assert run(REBVIO_HIP_DM_HEAD="compact1") == base
     assert run(REBVIO_HIP_PRIO="flat") == base
 
 

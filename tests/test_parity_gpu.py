@@ -347,17 +347,14 @@ def c3_stream():
 KW_C3 = dict(keylines_ref=60000, keylines_max=64000, threshold=0.006)
 
 
-@pytest.mark.parametrize("config,head", [("c2", None), ("c2", "thread"), ("c2", "wide"), ("c3", None), ("c3", "thread"), ("c3", "wide"), ("c2", "compact"),
-                                         ("c2", "compact128"), ("c2", "compact64"), ("c2", "compact1"), ("c3", "compact"), ("c2", "compact8s")],
-                         ids=["c2-default(compact8)", "c2-thread-head", "c2-wide-head", "c3-64k-default(compact1)", "c3-64k-thread-head",
-                              "c3-64k-wide-head", "c2-compact", "c2-compact128", "c2-compact64", "c2-compact1", "c3-64k-compact", "c2-compact8s"])
+@pytest.mark.parametrize("config,head", [("c2", None), ("c2", "compact4"), ("c2", "compact1"), ("c3", None), ("c3", "compact4"), ("c3", "compact8")],
+                         ids=["c2-default(compact8)", "c2-compact4", "c2-compact1", "c3-64k-default(compact1)", "c3-64k-compact4", "c3-64k-compact8"])
 def test_directed_match_regularize_ekf_bit_exact(orc_mod, B, c2_stream, c3_stream, monkeypatch, config, head):
     """directedMatch / searchMatch (edge_map.cpp:101-218), regularize1Iter, depth EKF on maps synced from the oracle: every
-    keyline field bit-exact, counters equal - for every form of the directedMatch launch (REBVIO_HIP_DM_HEAD, read when the
-    context is created): the one-launch compact kernel k_directed_match_c with 8 / 4 / 1 lanes per keyline and every workgroup
-    size it is instantiated for (defaults: <512, 8> up to 32 768 keylines, <64, 1> beyond) and the two-launch forms of rounds 1-3
-    (eight lanes per keyline / one thread per keyline + the wave-per-search tail), at BASELINE config 2 and on a 64 000-keyline
-    map of config 3 (1280x960)."""
+    keyline field bit-exact, counters equal - for every form of the one-launch directedMatch kernel k_directed_match_c (REBVIO_HIP_DM_HEAD,
+    read when the context is created): 8 / 4 / 1 lanes per keyline (<512, 8> the default up to 32 768 keylines, <64, 1> beyond and
+    for batches of four lanes or more, <256, 4> the alternative), each also where it is not the default, at BASELINE config 2 and
+    on a 64 000-keyline map of config 3 (1280x960)."""
     frames, cam = c2_stream if config == "c2" else c3_stream
     kw = KW_C2 if config == "c2" else KW_C3
     if head:
@@ -393,8 +390,8 @@ def test_directed_match_regularize_ekf_bit_exact(orc_mod, B, c2_stream, c3_strea
 
 
 def test_c3_stream_tracks_oracle_stream(orc_mod, B):
-    """BASELINE config 3 as a STREAM (1280x960, ~58k keylines; k_lm_chain<512> on 125 workgroups, the thread-per-keyline
-    directedMatch head, 1024 workgroups in its tail) through rebvio_hip_push_frame_u8_device against the oracle driven over the
+    """BASELINE config 3 as a STREAM (1280x960, ~58k keylines; k_lm_chain<512> on 125 workgroups, the directedMatch
+    kernel with one lane per keyline) through rebvio_hip_push_frame_u8_device against the oracle driven over the
     same eight frames, state carried independently on both sides, with the bars of the divergence report
     (test_stream_divergence_report): while the Levenberg-Marquardt decisions agree the GPU translation is within 1e-2 of the
     oracle run with double-accumulated sums and no farther from the fp32 oracle than that oracle is from its own
@@ -617,12 +614,12 @@ def test_device_glue_equals_host_glue(B, c2_stream, monkeypatch):
     (rebvio_hip_track_pair) runs the SAME statements on the host. Same frames -> the same records, bit for bit, pair by pair:
     velocity, covariance, extRotVel solution, corrected pose increment, rotation, counters, masks - and the same keylines in
     the last map. (sin / cos inside SO3::exp are hostmath.hpp's own double evaluation on both sides, so not even libm's last
-    bit differs.) Also with the thread-per-keyline directedMatch head in place of the eight-lanes form."""
+    bit differs.) Also with one lane per keyline in the directedMatch kernel in place of eight."""
     frames, cam = c2_stream
     n = len(frames)
     order = list(range(n)) + list(range(n - 2, -1, -1)) + list(range(1, n))
     npx = cam.width * cam.height
-    for head in ("", "thread"):
+    for head in ("", "compact1"):
         if head:
             monkeypatch.setenv("REBVIO_HIP_DM_HEAD", head)
         else:
@@ -1284,20 +1281,20 @@ def test_two_batches_share_one_gpu(B, c2_stream):
                 assert got[b][lane] == want[src], (b, lane)
 
 
-@pytest.mark.parametrize("L,env", [(3, {}), (4, {}), (8, {}), (4, {"REBVIO_HIP_LM": "seq"}), (4, {"REBVIO_HIP_LM": "spec3"}), (2, {"REBVIO_HIP_BATCH_DM_HEAD": "thread"}),
-                                   (5, {"REBVIO_HIP_BATCH_DM_HEAD": "wide", "REBVIO_HIP_BATCH_LEAD": "6", "REBVIO_HIP_BATCH_GROUP": "3"}),
+@pytest.mark.parametrize("L,env", [(3, {}), (4, {}), (8, {}), (4, {"REBVIO_HIP_LM": "seq"}), (4, {"REBVIO_HIP_LM": "spec3"}), (2, {"REBVIO_HIP_BATCH_DM_HEAD": "compact1"}),
+                                   (5, {"REBVIO_HIP_BATCH_DM_HEAD": "compact8", "REBVIO_HIP_BATCH_LEAD": "6", "REBVIO_HIP_BATCH_GROUP": "3"}),
                                    (3, {"REBVIO_HIP_DETECT_WORKER": "0", "REBVIO_HIP_FUSE_DOG": "0"}),
                                    (3, {"REBVIO_HIP_BATCH_FUSE_DOG": "1"})],
-                         ids=["3-lanes", "4-lanes", "8-lanes", "4-lanes-seq-lm", "4-lanes-spec3-lm", "2-lanes-thread-head", "5-lanes-wide-head-lead6-group3",
+                         ids=["3-lanes", "4-lanes", "8-lanes", "4-lanes-seq-lm", "4-lanes-spec3-lm", "2-lanes-compact1", "5-lanes-compact8-lead6-group3",
                               "3-lanes-caller-launches-unfused-dog",
                               "3-lanes-fused-candidate-kernel"])
 def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, env):
     """rebvio_hip_batch_*: L camera streams advanced in lock-step by batched launches (lane = blockIdx.z) produce, lane by lane,
     the records of L stand-alone contexts fed the same frames - bit for bit (same kernel bodies, same per-lane reduction
     order, the same glue statements), only delivered on a different schedule. The lane counts cover what the bench's
-    streams_per_gpu figures run: from 4 lanes on the directedMatch head is the thread-per-keyline kernel
-    (k_directed_match_b) and the LM kernel polls slowly; 8 lanes fill the chip with the persistent LM workgroups; the
-    sequential LM kernel (k_lm_chain_b) and both head forms at lane counts where they are not the default."""
+    streams_per_gpu figures run: from 4 lanes on the directedMatch kernel runs one lane per keyline (k_directed_match_c_b<64, 1>)
+    and the LM kernel polls slowly; 8 lanes fill the chip with the persistent LM workgroups; the sequential LM kernel
+    (k_lm_chain_b) and both directedMatch forms at lane counts where they are not the default."""
     from rebvio_amd import synth
     cam = c2_stream[1]
     n = 36
