@@ -325,7 +325,8 @@ struct rebvio_hip_ctx {
   PairSlot* slot[kSlots]{};    // pinned: LM state + map state records, written by the pair's first kernel
   hipEvent_t slot_ev[kSlots]{};  // recorded behind the pair's last kernel
   GlueRec* rec[kSlots]{};      // pinned: what the device glue of the pair reports
-  GlueDev* glue_dev = nullptr;    // [kSlots] second-half inputs left by the directedMatch head for the kernels behind it
+  GlueDev* glue_dev = nullptr;    // [kSlots] second-half inputs left by the device glue for the kernels behind it
+  GlueStage* glue_stage = nullptr;  // [kSlots] host records on their way out: written by the glue, forwarded by the directedMatch launch
   GlueState* gstate = nullptr;    // [2] device: gyro-bias filter state + prior rotation, by pair parity
   GlueState* h_gstate = nullptr;  // [2] pinned staging for the upload in front of a stream's first pair
   hm::M3 gs_R{};                  // host mirror of the device state's prior rotation (with Bg / W_Bg above)
@@ -1206,6 +1207,8 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   HIPCHK(hipMalloc(&c->fscratch, 64 * sizeof(float)));
   HIPCHK(hipMalloc(&c->glue_dev, rebvio_hip_ctx::kSlots * sizeof(GlueDev)));
   HIPCHK(hipMemset(c->glue_dev, 0, rebvio_hip_ctx::kSlots * sizeof(GlueDev)));
+  HIPCHK(hipMalloc(&c->glue_stage, rebvio_hip_ctx::kSlots * sizeof(GlueStage)));
+  HIPCHK(hipMemset(c->glue_stage, 0, rebvio_hip_ctx::kSlots * sizeof(GlueStage)));
   HIPCHK(hipMalloc(&c->gstate, 2 * sizeof(GlueState)));
   HIPCHK(hipMemset(c->gstate, 0, 2 * sizeof(GlueState)));
   HIPCHK(hipHostMalloc(&c->h_gstate, 2 * sizeof(GlueState), hipHostMallocDefault));
@@ -1316,6 +1319,7 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
     if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
   }
   if (c->glue_dev) (void)hipFree(c->glue_dev);
+  if (c->glue_stage) (void)hipFree(c->glue_stage);
   if (c->lm_bar_err) (void)hipHostFree(c->lm_bar_err);
   if (c->lm_stamps) (void)hipHostFree(c->lm_stamps);
   if (c->dm_stats) (void)hipFree(c->dm_stats);
@@ -2175,11 +2179,12 @@ int stream_enqueue_group(rebvio_hip_ctx* c, int npairs) {
     ga.st_out = c->gstate + (gpar ^ 1);
     ga.rec = c->rec[slot];
     ga.gd_copy = c->glue_dev + slot;
+    ga.stage = c->glue_stage + slot;
     ga.gp = glue_params(c, frame_dt);
     glue_params_pre(c, &ga.gp);
     int rc = enqueue_pair_lm(c, om, nm, v0, c->slot[slot], c->xrv_part, ga);  // rebvio.cpp:167-177 + the glue of rebvio.cpp:177-233
     if (rc) return rc;
-    launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->P.search_range, c->dm_head_form);
+    launch_directed_match_dev(s, c->K, nm->d, om->d, c->glue_dev + slot, c->glue_stage + slot, c->P.search_range, c->dm_head_form);
     const int gate = (int)c->P.global_min_matches_threshold;
     launch_regularize_ekf_dev(s, c->K, nm->d, c->glue_dev + slot, gate > 0 ? gate : 0, c->hist);  // rebvio.cpp:256-259
     std::swap(nm->d.rs, nm->d.rs_tmp);
@@ -2474,6 +2479,7 @@ int rebvio_hip_test_glue(rebvio_hip_ctx* c, const float vel[3], const float JtJ6
   ga.st_out = d_st + 1;
   ga.rec = d_rec;
   ga.gd_copy = d_gl;
+  ga.stage = nullptr;
   ga.seq = 1u;
   ga.gp = glue_params(c, frame_dt);
   launch_pair_glue(c->s_trk, fake, ga);
@@ -3032,6 +3038,7 @@ int rebvio_hip_batch_create(const rebvio_hip_params* p, int lanes, rebvio_hip_ba
     for (int i = 0; i < rebvio_hip_ctx::kSlots; ++i) {
       L.slot[i] = c->slot[i];
       L.rec[i] = c->rec[i];
+      L.glue_stage = c->glue_stage;
     }
     L.glue_dev = c->glue_dev;
     L.gstate = c->gstate;

@@ -211,6 +211,19 @@ struct GlueRec {
   unsigned seq_gs, seq_out; // sequence stamps behind `gs` and behind `out` (two waves of the glue write them; see PairSlot::seq)
 };
 
+// Where the device glue leaves a pair's host record when a directedMatch launch follows it (streaming and batch drivers): device
+// memory, one per result slot. Stores into pinned host memory at the tail of the LM kernel sat on the pair's critical path (a PCIe
+// write latency before the kernel could end, and a release in front of the sequence stamp on top: 3 us per pair measured); the
+// last wave of the directedMatch launch - which owns no keyline - copies the record to the host and stamps it while the rest of
+// that launch works (directed_match_c_body).
+struct GlueStage {
+  GlueRec rec;          // as the glue wrote it (stamps unset)
+  GlueRec* host_rec;    // pinned destination
+  PairSlot* host_slot;  // the pair's result slot, stamped with the record (its contents were stored by the LM kernel itself)
+  unsigned seq;
+  unsigned pad;
+};
+
 struct GlueParams {
   float frame_dt;
   float gyro_std_dev, gyro_bias_std_dev;
@@ -233,6 +246,7 @@ struct GlueArgs {
   GlueState* st_out;       // ... and after it (the other parity slot: late workgroups still read st_in)
   GlueRec* rec;            // pinned host record of this pair
   GlueDev* gd_copy;        // device copy of the second half's inputs for the kernels queued behind the head
+  GlueStage* stage;        // != null: the host record goes here and the directedMatch launch forwards it (GlueStage); null: straight to *rec
   unsigned seq;            // the pair's sequence stamp (PairSlot::seq, GlueRec::seq_gs / seq_out); also used when lm == null
   GlueParams gp;
 };
@@ -257,8 +271,8 @@ void launch_pair_glue(hipStream_t s, const MapDev& newm, const GlueArgs& ga);
 void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const float vel[3],
                            const float Rvel[9], const float Rback[9], float max_radius, const float* R0_on_the_fly, int head_form);
 // the same launch with the second half's inputs read from *gd (device memory) at run time
-void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
-                               int head_form);
+void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd,
+                               const GlueStage* stage, float max_radius, int head_form);
 void launch_regularize_ekf_dev(hipStream_t s, const KParams& p, const MapDev& m, const GlueDev* g_dev, int gate, int* hist);
 // fused regularize1Iter + depth EKF: reads m.rs, writes m.rs_tmp (caller swaps the pointers); Rnext != null also
 // applies the next pair's first rotation and bins sigma_rho into hist
@@ -302,7 +316,8 @@ struct LaneStatic {
   int* hist;
   PairSlot* slot[kPairSlots];  // pinned: LM state + map state records of a pair, written by the LM kernel
   GlueRec* rec[kPairSlots];    // pinned: what the device glue of a pair reports
-  GlueDev* glue_dev;           // [kPairSlots] second-half inputs left by the directedMatch head
+  GlueDev* glue_dev;           // [kPairSlots] second-half inputs left by the device glue
+  GlueStage* glue_stage;       // [kPairSlots] host records on their way out (GlueStage)
   GlueState* gstate;           // [2] gyro-bias filter state + prior rotation, by pair parity
   float* xrv_part;             // extRotVel block records of the pair in flight
   const int2* undist_map;      // the lane's lens model (fixed-point source coordinates), null without one
@@ -336,8 +351,16 @@ __host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int l
 }
 #if defined(__HIPCC__)
 // Sequence stamp of a host-visible record: stored behind everything else the writer stored (system-scope release).
-__device__ __forceinline__ void stamp_release(unsigned* w, unsigned seq) {
-  __hip_atomic_store(w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// The writer waits until everything it has stored itself is acknowledged (s_waitcnt vmcnt(0): stores to host-visible memory are
+// written through) and stores the stamp relaxed: a system-scope RELEASE here writes the XCD's L2 back first - +3 us per pair when
+// it sat at the tail of the LM kernel (in-kernel stamps, round 4).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "common.hpp: stamp_drain() encodes s_waitcnt for gfx942 / gfx950 only"
+#endif
+__device__ __forceinline__ void stamp_drain(unsigned* w, unsigned seq) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (compiler ordering; no cache operation outside tgsplit mode)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0); expcnt / lgkmcnt untouched
+  __hip_atomic_store(w, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif
 #if defined(__HIPCC__)

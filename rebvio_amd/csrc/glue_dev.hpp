@@ -364,8 +364,12 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
     hm::store3(hm::transpose(Rn), ga.gd_copy->RT_next);
     ga.gd_copy->has_next = 1;
     *ga.st_out = st;
-    ga.rec->gs = st;
-    stamp_release(&ga.rec->seq_gs, ga.seq);
+    if (ga.stage) {
+      ga.stage->rec.gs = st;
+    } else {
+      ga.rec->gs = st;
+      stamp_drain(&ga.rec->seq_gs, ga.seq);
+    }
     return;
   }
   // ---- wave 0: SO3 correction, covariance, the second half's inputs, the host's record (rebvio.cpp:195-203, 228) ----
@@ -404,7 +408,9 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
     gl->R0a[i] = R0a[i];
   }
   gl->nan_v = nan_v;
-  rebvio_hip_pair_out& out = ga.rec->out;  // pinned host memory: plain stores, complete when the kernel ends
+  // the host's record: staged in device memory when a directedMatch launch follows (it forwards the record, GlueStage), else
+  // straight into the pinned record
+  rebvio_hip_pair_out& out = ga.stage ? ga.stage->rec.out : ga.rec->out;
   out.F = lm.F;
   out.lm_accept_mask = lm.accept_mask;
   out.sigma_rho_min = lm.sigma_rho_min;
@@ -433,7 +439,12 @@ __device__ __forceinline__ void glue_workgroup(GlueLds& w, const LmState& lm /*L
   for (int i = 0; i < 36; ++i) out.W_Xv[i] = w.W[i];
   out.klm_num = out.kf_matches = out.reg_num = 0;
   out.status = nan_v;
-  stamp_release(&ga.rec->seq_out, ga.seq);
+  if (ga.stage) {
+    ga.stage->host_rec = ga.rec;
+    ga.stage->seq = ga.seq;
+  } else {
+    stamp_drain(&ga.rec->seq_out, ga.seq);
+  }
 }
 
 }  // namespace rh

@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
     for (int w = 0; w < 4; ++w) acc += wsum[w][threadIdx.x];
     xrv_part[blockIdx.x * kXrvStride + threadIdx.x] = acc;
   }
-  if (slot && blockIdx.x == 0 && threadIdx.x == 0) stamp_release(&slot->seq, seq);  // (block 0's own stores: lm, map states, its record)
+  if (slot && blockIdx.x == 0 && threadIdx.x == 0) stamp_drain(&slot->seq, seq);  // (block 0's own stores: lm, map states, its record)
 }
 
 // ---- persistent minimizeVel + forwardMatch + extRotVel (core.cpp:150-245, edge_map.cpp:78-96) --------------------
@@ -1019,6 +1019,7 @@ __device__ __forceinline__ GlueArgs lane_glue_args(const LaneStatic& L, const La
   ga.st_out = gptr(L.gstate) + ((d.gpar & 1) ^ 1);
   ga.rec = gptr(L.rec[d.slot]);
   ga.gd_copy = gptr(L.glue_dev) + d.slot;
+  ga.stage = gptr(L.glue_stage) + d.slot;
   ga.seq = d.seq;
   // (only the scalars: a batch forms the gyroBiasCorrection matrices on the device - has_pre = 0 as a constant lets the compiler
   // drop the by-value matrices; copying them put the whole struct into scratch memory, 280 bytes per lane of every workgroup)
@@ -1257,7 +1258,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   }
   RH_STAMP(1 + calls * 6);
   if (!do_ext) {
-    if (slot && blockIdx.x == 0 && tid == 0) stamp_release(&slot->seq, ga.seq);
+    if (slot && blockIdx.x == 0 && tid == 0) stamp_drain(&slot->seq, ga.seq);
     return;
   }
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
@@ -1310,7 +1311,12 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
     __syncthreads();  // (rec is free: every LM collect is over)
     lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, rec, kMaxRecBlocks * kPartStride / kXrvStride, gw, s, bar_err, slow_poll, stamps);
   }
-  if (slot && blockIdx.x == 0 && tid == 0) stamp_release(&slot->seq, ga.seq);  // the last thing this launch stores into the slot
+  if (slot && blockIdx.x == 0 && tid == 0) {  // the slot's stamp: by the directedMatch launch with the glue's record, or here
+    if (ga.lm && ga.stage)
+      ga.stage->host_slot = slot;
+    else
+      stamp_drain(&slot->seq, ga.seq);
+  }
 #undef RH_STAMP
 }
 
@@ -1895,7 +1901,12 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
                                     ? (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride : 1, gw, s, bar_err, slow_poll, stamps);
     RH_STAMP(15);
   }
-  if (slot && blockIdx.x == 0 && tid == 0) stamp_release(&slot->seq, ga.seq);  // the last thing this launch stores into the slot
+  if (slot && blockIdx.x == 0 && tid == 0) {  // the slot's stamp: by the directedMatch launch with the glue's record, or here
+    if (ga.lm && ga.stage)
+      ga.stage->host_slot = slot;
+    else
+      stamp_drain(&slot->seq, ga.seq);
+  }
 #undef RH_STAMP
 }
 
@@ -2246,7 +2257,7 @@ __device__ __forceinline__ int dmc_commit(MapDev& nm, const MapDev& om, DmcWaveT
 
 template <int kThreads, int kLPK>
 __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_, float max_radius,
-                                                      int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
+                                                      int rot_, Mat3 R0_, const GlueDev* __restrict__ gd, const GlueStage* __restrict__ stage) {
   static_assert(kLPK == 1 || kLPK == 2 || kLPK == 4 || kLPK == 8, "lanes per keyline");
   constexpr int kWaves = kThreads / 64;
   constexpr int kKPW = 64 / kLPK;                 // keylines per wave
@@ -2274,6 +2285,26 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
   const float2 gq = nm.grad[idx];
   const float gnq = nm.gnorm[idx];
   const int n = nm.st->n;
+  if (stage && vb.x == gridDim.x - 1 && wid == kWaves - 1) {
+    // The pair's host record, left in device memory by the glue at the tail of the LM kernel (GlueStage): this wave - the last
+    // of the grid, which owns no keyline unless the map is full - copies it into the pinned record while the launch works, waits
+    // for its stores to be acknowledged and stamps the record and the pair's result slot (what the host compares, -12).
+    const unsigned* src = reinterpret_cast<const unsigned*>(&stage->rec);
+    GlueRec* hr = stage->host_rec;
+    unsigned* dst = reinterpret_cast<unsigned*>(hr);
+    constexpr int kWords = (int)(offsetof(GlueRec, seq_gs) / sizeof(unsigned));
+    for (int i = lane; i < kWords; i += 64) dst[i] = src[i];
+    const unsigned seq = stage->seq;
+    PairSlot* hs = stage->host_slot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every lane's stores acknowledged (see stamp_drain)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      __hip_atomic_store(&hr->seq_gs, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&hr->seq_out, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (hs) __hip_atomic_store(&hs->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   const DmArgs A = dm_args(gd, vel_, Rvel_, Rback_, rot_, R0_);
   if (A.skip) return;
   const bool live = idx < n;
@@ -2516,8 +2547,9 @@ __device__ __forceinline__ void directed_match_c_body(KParams p, MapDev nm, MapD
 
 template <int kThreads, int kLPK>
 __global__ __launch_bounds__(kThreads) void k_directed_match_c(KParams p, MapDev nm, MapDev om, Vec3 vel_, Mat3 Rvel_, Mat3 Rback_,
-                                                               float max_radius, int rot_, Mat3 R0_, const GlueDev* __restrict__ gd) {
-  directed_match_c_body<kThreads, kLPK>(p, nm, om, vel_, Rvel_, Rback_, max_radius, rot_, R0_, gd);
+                                                               float max_radius, int rot_, Mat3 R0_, const GlueDev* __restrict__ gd,
+                                                               const GlueStage* __restrict__ stage) {
+  directed_match_c_body<kThreads, kLPK>(p, nm, om, vel_, Rvel_, Rback_, max_radius, rot_, R0_, gd, stage);
 }
 template <int kThreads, int kLPK>
 __global__ __launch_bounds__(kThreads) void k_directed_match_c_b(KParams p, const LaneStatic* __restrict__ ls, const MapDev* __restrict__ maptab,
@@ -2528,7 +2560,7 @@ __global__ __launch_bounds__(kThreads) void k_directed_match_c_b(KParams p, cons
   const Mat3 z9{};
   directed_match_c_body<kThreads, kLPK>(p, global_map(lane_map(maptab, blockIdx.z, d.nm, d.nm_swap)),
                                         global_map(lane_map(maptab, blockIdx.z, d.om, d.om_swap)), z3, z9, z9, max_radius, 1, z9,
-                                        gptr(L.glue_dev) + d.slot);
+                                        gptr(L.glue_dev) + d.slot, gptr(L.glue_stage) + d.slot);
 }
 
 // ---- EdgeMap::searchMatch as a public single-keyline call (edge_map.hpp:93-94, edge_map.cpp:101-184) ----------------
@@ -2882,16 +2914,16 @@ void launch_directed_match(hipStream_t s, const KParams& p, const MapDev& newm, 
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const Mat3 R0 = mat3(R0_on_the_fly ? R0_on_the_fly : I);
   RH_DMC_DISPATCH(k_directed_match_c, form, p.kmax, 1, s, p, newm, oldm, vec3(vel), mat3(Rvel), mat3(Rback), max_radius, rot, R0,
-                  (const GlueDev*)nullptr);
+                  (const GlueDev*)nullptr, (const GlueStage*)nullptr);
 }
 
 // the same launch with the second half's inputs read from *gd at run time: the record the pair's LM kernel left (device glue,
 // glue_dev.hpp)
-void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd, float max_radius,
-                               int head_form) {
+void launch_directed_match_dev(hipStream_t s, const KParams& p, const MapDev& newm, const MapDev& oldm, const GlueDev* gd,
+                               const GlueStage* stage, float max_radius, int head_form) {
   const int form = dm_form(p.kmax, head_form, 1);
   const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-  RH_DMC_DISPATCH(k_directed_match_c, form, p.kmax, 1, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, 1, mat3(I), gd);
+  RH_DMC_DISPATCH(k_directed_match_c, form, p.kmax, 1, s, p, newm, oldm, vec3(z), mat3(I), mat3(I), max_radius, 1, mat3(I), gd, stage);
 }
 
 void launch_search_match_one(hipStream_t s, const KParams& p, const MapDev& searched, const rebvio_hip_keyline& q, const float vel[3],
