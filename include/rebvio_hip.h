@@ -1,7 +1,7 @@
 /*
  * rebvio_hip.h — C-ABI of the MI355X (gfx950) backend for rebvio's per-frame edge-detection +
  * edge-tracking hot path. Plain C types, caller-allocated outputs, int status (0 = ok, <0 = error,
- * see rebvio_hip_last_error). No exceptions cross this boundary. One context per camera stream and
+ * see rebvio_hip_last_error; the codes are listed in INTEGRATION.md "Status codes"). No exceptions cross this boundary. One context per camera stream and
  * GPU; a context is not thread-safe, but its detect-side entries (detect*) and track-side entries
  * run on two private HIP streams and overlap on the device, mirroring the reference's two workers
  * (rebvio/src/rebvio.cpp:28-29).
@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define REBVIO_HIP_ABI_VERSION 2
+/* 3: status -12 (a pair's record read before the device wrote it: sequence stamps), rebvio_hip_test_forge_record_stamp,
+ *    REBVIO_HIP_DM_HEAD values compact8 / compact4 / compact1 (2: map handles outlive their context, -10) */
+#define REBVIO_HIP_ABI_VERSION 3
 
 /* Host mirror of one keyline: field-for-field rebvio::types::KeyLine
  * (rebvio/include/rebvio/types/keyline.hpp:24-40), 84 bytes. Device storage is SoA. */

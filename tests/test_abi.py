@@ -34,7 +34,7 @@ def test_header_symbols_all_exported(backend):
 def test_binding_covers_header(backend):
     assert sorted(backend.SIGNATURES) == _declared_symbols()
     L = backend.lib()
-    assert L.rebvio_hip_abi_version() == 2
+    assert L.rebvio_hip_abi_version() == 3
 
 
 def test_keyline_layout_is_the_reference_84_bytes(backend):
