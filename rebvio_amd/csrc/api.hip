@@ -861,6 +861,61 @@ uint32_t next_stamp(uint32_t* counter) {
 constexpr int kStaleRecord = -12;
 const char* const kStaleRecordMsg = "a pair's record was read before the device had written it (sequence stamp mismatch)";
 
+// Waits for a pair's host records (per-pair API: the result slot and the extRotVel block records behind it) by polling their
+// sequence stamps. The stream is queried now and then so that a device-side failure ends the wait with its error; after two
+// seconds without the stamps the stream is synchronised and the stamps decide (-12).
+int poll_pair_records(rebvio_hip_ctx* c, const PairSlot* slot, uint32_t seq) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  bool synced = false;
+  // one step of waiting: 0 keep polling, < 0 error. The stream is queried now and then so that a device-side failure ends the wait
+  // with its error; after two seconds the stream is synchronised and the records get one last look.
+  auto wait_step = [&]() -> int {
+    if (synced) return fail_msg(kStaleRecordMsg, kStaleRecord);
+    __builtin_ia32_pause();
+    if ((++spins & 0x3FFFu) != 0u) return 0;
+    const hipError_t q = hipStreamQuery(c->s_trk);
+    if (q != hipSuccess && q != hipErrorNotReady) return fail("track stream", q);
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      const hipError_t e = hipStreamSynchronize(c->s_trk);
+      if (e != hipSuccess) return fail("track stream", e);
+      synced = true;
+    }
+    return 0;
+  };
+  // A record counts once its stamp AND its checksum fit: the words are re-read on every try (writes to host memory may arrive out
+  // of order; a torn read fails the sum and is simply repeated).
+  auto slot_ok = [&]() -> bool {
+    const volatile unsigned* w = reinterpret_cast<const volatile unsigned*>(slot);
+    if (*reinterpret_cast<const volatile unsigned*>(&slot->seq) != seq) return false;
+    unsigned x = 0u;
+    for (size_t i = 0; i < offsetof(PairSlot, seq) / sizeof(unsigned); ++i) x ^= w[i];
+    return (x ^ seq) == *reinterpret_cast<const volatile unsigned*>(&slot->sum);
+  };
+  static_assert(offsetof(PairSlot, seq) == sizeof(LmState) + 2 * sizeof(MapState), "PairSlot::sum covers lm, new_st, old_st");
+  while (!slot_ok()) {
+    const int e = wait_step();
+    if (e) return e;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const int nb = std::min(div_up(std::max(slot->new_st.n, 0), 256), c->maxblocks);
+  for (int b = 0; b < nb; ++b) {
+    const volatile unsigned* w = reinterpret_cast<const volatile unsigned*>(slot->xrv + (size_t)b * kXrvStride);
+    auto rec_ok = [&]() -> bool {
+      if (w[kXrvStride - 1] != seq) return false;
+      unsigned x = 0u;
+      for (int k = 0; k < 28; ++k) x ^= w[k];
+      return (x ^ seq) == w[kXrvStride - 2];
+    };
+    while (!rec_ok()) {
+      const int e = wait_step();
+      if (e) return e;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
 int enqueue_pair_lm(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hip_map* nm, const float vel0[3], PairSlot* slot, float* xrv_dst,
                     const GlueArgs& ga_in) {
   const int calls = (int)c->P.iterations + 1;
@@ -1952,9 +2007,15 @@ int rebvio_hip_track_pair_begin(rebvio_hip_ctx* c, rebvio_hip_map* om, rebvio_hi
   rc = enqueue_pair_lm(c, om, nm, v0, slot, slot->xrv, GlueArgs{});
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->slot_ev[0], s));
   const auto tb1 = std::chrono::steady_clock::now();
-  HIPCHK(hipEventSynchronize(c->slot_ev[0]));
+  // No event behind the first half: a completion event is a packet of its own on the track stream (~5 us until its signal fires
+  // on this runtime, plus the wake-up) between the LM kernel's end and this thread - the path the inertial fusion and the second
+  // half's launch wait on. The records carry sequence stamps (slot: the LM kernel's last store; every extRotVel block record:
+  // stored behind the record's own words), so the thread polls them in pinned memory instead.
+  {
+    const int prc = poll_pair_records(c, slot, c->last_stamp);
+    if (prc) return prc;
+  }
   const auto tb2 = std::chrono::steady_clock::now();
   c->t_begin_enq += std::chrono::duration<double, std::micro>(tb1 - tb0).count();
   c->t_begin_wait += std::chrono::duration<double, std::micro>(tb2 - tb1).count();

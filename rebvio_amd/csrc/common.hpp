@@ -179,8 +179,10 @@ struct PairSlot {
   LmState lm;          // final minimizeVel state
   MapState new_st;     // snapshot of the new map's scalars
   MapState old_st;     // snapshot of the old map's scalars (directedMatch / regularize counters of the previous pair)
-  unsigned seq;        // sequence stamp of the pair that wrote this slot: the LAST word its kernel stores (system-scope release), so a
-  unsigned pad_[3];    // host that reads the slot before the pair has run sees the previous user's stamp and reports -12
+  unsigned seq;        // sequence stamp of the pair that wrote this slot: the LAST word its kernel stores, so a host that reads the
+                       // slot before the pair has run sees the previous user's stamp and reports -12
+  unsigned sum;        // XOR of every word of lm / new_st / old_st, ^ seq: a host that POLLS the slot (rebvio_hip_track_pair_begin) instead
+  unsigned pad_[2];    // of waiting for an event accepts it only when the words it read add up (writes to host memory may arrive out of order)
   float xrv[1];        // [nblocks][kXrvStride] block records follow
 };
 // Result of the host glue of one pair (rebvio.cpp:186-233) as the second half of the pair step reads it from memory
@@ -357,6 +359,25 @@ __host__ __device__ inline MapDev lane_map(const MapDev* __restrict__ tab, int l
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
 #error "common.hpp: stamp_drain() encodes s_waitcnt for gfx942 / gfx950 only"
 #endif
+// Fills a result slot and returns the XOR of the words stored (PairSlot::sum ^ seq, stored with the stamp at the kernel's end).
+__device__ __forceinline__ unsigned slot_fill(PairSlot* slot, const LmState& lm, const MapState* new_st, const MapState* old_st) {
+  const LmState l = lm;
+  const MapState a = *new_st, b = *old_st;
+  slot->lm = l;
+  slot->new_st = a;
+  slot->old_st = b;
+  unsigned x = 0u;
+  const unsigned* p = reinterpret_cast<const unsigned*>(&l);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(LmState) / 4); ++i) x ^= p[i];
+  p = reinterpret_cast<const unsigned*>(&a);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(MapState) / 4); ++i) x ^= p[i];
+  p = reinterpret_cast<const unsigned*>(&b);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(MapState) / 4); ++i) x ^= p[i];
+  return x;
+}
 __device__ __forceinline__ void stamp_drain(unsigned* w, unsigned seq) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (compiler ordering; no cache operation outside tgsplit mode)
   __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0); expcnt / lgkmcnt untouched

@@ -792,6 +792,21 @@ __device__ __forceinline__ void xrv_eval(const KParams& p, const MapDev& om, Map
   }
 }
 
+// Sequence stamp of one extRotVel block record (kXrvStride floats: 27 sums, the match count, two spare words, a checksum, the stamp),
+// called by the 32 lanes that own the record's words right after they stored them (`bits` = what lane k stored, 0 for k >= 28): the
+// wave waits for its stores (vmcnt(0)), lane 30 stores the XOR of the record's words ^ seq, lane 31 the stamp. A host that polls
+// the record accepts it when stamp AND checksum fit: the record is 128 bytes = two 64-byte writes on the way to host memory, and
+// writes to host memory may arrive out of order.
+__device__ __forceinline__ void xrv_record_stamp(float* rec, int k, unsigned seq, unsigned bits) {
+  unsigned x = bits;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) x ^= (unsigned)__shfl_xor((int)x, o);  // (stays inside the 32-lane half that owns the record)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (see stamp_drain)
+  if (k == kXrvStride - 2) __hip_atomic_store(reinterpret_cast<unsigned*>(rec + k), x ^ seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (k == kXrvStride - 1) __hip_atomic_store(reinterpret_cast<unsigned*>(rec + k), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- EdgeMap::forwardMatch gather (edge_map.cpp:78-96) + Core::extRotVel sums (core.cpp:198-245) -------------
 // Sequential rule "overwrite unless the target already holds a larger rho" == the writer with the largest
 // rho wins, ties -> largest index: exactly the atomicMax key. One thread per keyline of the NEW map.
@@ -801,6 +816,7 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
                                                      LmState* __restrict__ st_out, const float* __restrict__ part_prev,
                                                      float* __restrict__ xrv_part, Vec3 vel_manual,
                                                      PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero, unsigned seq) {
+  unsigned slot_sum = 0u;  // XOR of the words this thread stored into the result slot (PairSlot::sum)
   __shared__ LmState s;
   __shared__ float red[16];
   __shared__ float carry_in;
@@ -827,11 +843,7 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
       lm_step(s, red, calls, true);
       if (blockIdx.x == 0) {
         *st_out = s;
-        if (slot) {  // zero-copy: the host reads these after the pair's event
-          slot->lm = s;
-          slot->new_st = *nm.st;
-          slot->old_st = *om.st;
-        }
+        if (slot) slot_sum = slot_fill(slot, s, nm.st, om.st);  // zero-copy: the host reads these once the stamps say so
       }
     }
     __syncthreads();
@@ -867,12 +879,18 @@ __global__ __launch_bounds__(256) void k_ext_rot_vel(KParams p, MapDev om, MapDe
     for (int k = 0; k < 28; ++k) wsum[wid][k] = v[k];
   }
   __syncthreads();
+  unsigned stored = 0u;
   if (threadIdx.x < 28) {
     float acc = 0.f;
     for (int w = 0; w < 4; ++w) acc += wsum[w][threadIdx.x];
     xrv_part[blockIdx.x * kXrvStride + threadIdx.x] = acc;
+    stored = __float_as_uint(acc);
   }
-  if (slot && blockIdx.x == 0 && threadIdx.x == 0) stamp_drain(&slot->seq, seq);  // (block 0's own stores: lm, map states, its record)
+  if (threadIdx.x < 32) xrv_record_stamp(xrv_part + (size_t)blockIdx.x * kXrvStride, (int)threadIdx.x, seq, stored);
+  if (slot && blockIdx.x == 0 && threadIdx.x == 0) {  // (block 0's own stores: lm, map states, its record)
+    slot->sum = slot_sum ^ seq;
+    stamp_drain(&slot->seq, seq);
+  }
 }
 
 // ---- persistent minimizeVel + forwardMatch + extRotVel (core.cpp:150-245, edge_map.cpp:78-96) --------------------
@@ -1092,6 +1110,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
                                                             unsigned frame_count, float* __restrict__ xrv_part,
                                                             PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
                                                             unsigned long long* __restrict__ stamps, int slow_poll, const GlueArgs ga) {
+  unsigned slot_sum = 0u;  // XOR of the words thread 0 of workgroup 0 stored into the result slot (PairSlot::sum)
   constexpr int kChainGroups = kChainThreads / 256;
   __shared__ GlueLds gw;
   __shared__ float lm_inv[9];
@@ -1250,15 +1269,14 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   }
   if (blockIdx.x == 0 && tid == 0) {
     *st_out = s;
-    if (slot) {  // zero-copy: the host reads these after the pair's event
-      slot->lm = s;
-      slot->new_st = *nm.st;
-      slot->old_st = *om.st;
-    }
+    if (slot) slot_sum = slot_fill(slot, s, nm.st, om.st);  // zero-copy: the host reads these once the stamps say so
   }
   RH_STAMP(1 + calls * 6);
   if (!do_ext) {
-    if (slot && blockIdx.x == 0 && tid == 0) stamp_drain(&slot->seq, ga.seq);
+    if (slot && blockIdx.x == 0 && tid == 0) {
+      slot->sum = slot_sum ^ ga.seq;
+      stamp_drain(&slot->seq, ga.seq);
+    }
     return;
   }
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
@@ -1297,6 +1315,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
   unsigned long long* xch_xrv = xch + lm_xch_xrv_offset((size_t)nrec_launched, (size_t)gridDim.x);
   if (tid < kChainGroups * 32) {
     const int g = tid >> 5, k = tid & 31;
+    unsigned stored = 0u;
     if (k < 28) {
       float acc = 0.f;
       for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
@@ -1304,7 +1323,11 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
         xch_publish(xch_xrv + ((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k, tag_final, acc);
       else
         xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
+      stored = __float_as_uint(acc);
     }
+    // records that go straight to the host (per-pair API): each carries the pair's sequence stamp in its last word, stored once
+    // this wave's 28 sums are acknowledged - a host that polls the records instead of waiting for an event reads complete ones
+    if (!ga.lm) xrv_record_stamp(xrv_part + ((size_t)blockIdx.x * kChainGroups + g) * kXrvStride, k, ga.seq, stored);
   }
   RH_STAMP(2 + calls * 6);
   if (ga.lm) {
@@ -1312,6 +1335,7 @@ __device__ __forceinline__ void lm_chain_body(KParams p, MapDev om, MapDev nm, i
     lm_tail_glue<kChainThreads>(ga, xch_xrv, tag_final, n_new, rec, kMaxRecBlocks * kPartStride / kXrvStride, gw, s, bar_err, slow_poll, stamps);
   }
   if (slot && blockIdx.x == 0 && tid == 0) {  // the slot's stamp: by the directedMatch launch with the glue's record, or here
+    slot->sum = slot_sum ^ ga.seq;
     if (ga.lm && ga.stage)
       ga.stage->host_slot = slot;
     else
@@ -1346,6 +1370,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
                                                    int* __restrict__ bar_err, const int* __restrict__ hist, unsigned frame_count,
                                                    float* __restrict__ xrv_part, PairSlot* __restrict__ slot, int* __restrict__ hist_to_zero,
                                                    unsigned long long* __restrict__ stamps, int slow_poll, const GlueArgs ga, int kf) {
+  unsigned slot_sum = 0u;  // XOR of the words thread 0 of workgroup 0 stored into the result slot (PairSlot::sum)
   // kf = index of the first speculative evaluation: evaluations 0 .. kf - 1 run one per exchange round, kf .. calls - 1 in one
   // pass under the hypothesis "all rejected". kf = 2: the steady state of a young stream (accept mask 00001); kf = 3: what the
   // same stream settles into once its depths have converged (00011 on every pair from frame ~6000 on) - four
@@ -1838,11 +1863,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   }
   if (blockIdx.x == 0 && tid == 0) {
     *st_out = s;
-    if (slot) {  // zero-copy: the host reads these after the pair's event
-      slot->lm = s;
-      slot->new_st = *nm.st;
-      slot->old_st = *om.st;
-    }
+    if (slot) slot_sum = slot_fill(slot, s, nm.st, om.st);  // zero-copy: the host reads these once the stamps say so
   }
   RH_STAMP(13);
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
@@ -1880,6 +1901,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   unsigned long long* xch_xrv = xch + lm_xch_xrv_offset((size_t)nrec_launched, (size_t)nwg);
   if (tid < kChainGroups * 32) {
     const int g = tid >> 5, k = tid & 31;
+    unsigned stored = 0u;
     if (k < 28) {
       float acc = 0.f;
       for (int w = 0; w < 4; ++w) acc += wsum[g * 4 + w][k];
@@ -1887,7 +1909,11 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         xch_publish(xch_xrv + ((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k, tag_final, acc);
       else
         xrv_part[((size_t)blockIdx.x * kChainGroups + g) * kXrvStride + k] = acc;
+      stored = __float_as_uint(acc);
     }
+    // records that go straight to the host (per-pair API): each carries the pair's sequence stamp in its last word, stored once
+    // this wave's 28 sums are acknowledged - a host that polls the records instead of waiting for an event reads complete ones
+    if (!ga.lm) xrv_record_stamp(xrv_part + ((size_t)blockIdx.x * kChainGroups + g) * kXrvStride, k, ga.seq, stored);
   }
   RH_STAMP(14);
   if (stamps && blockIdx.x == 0 && tid == 0) {
@@ -1902,6 +1928,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     RH_STAMP(15);
   }
   if (slot && blockIdx.x == 0 && tid == 0) {  // the slot's stamp: by the directedMatch launch with the glue's record, or here
+    slot->sum = slot_sum ^ ga.seq;
     if (ga.lm && ga.stage)
       ga.stage->host_slot = slot;
     else
