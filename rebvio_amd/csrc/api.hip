@@ -255,8 +255,12 @@ struct rebvio_hip_ctx {
   float* dog2[kDetPar]{};  // (the single-stream driver alternates between [0] and [1], a batch uses all: common.hpp kDetPar)
   float* mag2[kDetPar]{};
   int* rowcount2[kDetPar]{};
-  hipEvent_t ev_scan[2]{}, ev_flag[2]{};
-  bool ev_flag_used[2] = {false, false};
+  hipEvent_t ev_scan[2]{};
+  // `ready` event of the map detected two frames ago (same parity): what the scans of this frame wait for before they rewrite
+  // that frame's buffers. It is recorded a few microseconds behind the point the buffers are free (after the distance field
+  // instead of after joinEdges), two frame times before anyone waits for it - and it is an event the frame records anyway: one
+  // hipEventRecord less per frame on the launching thread (3.5 us of its 62, round 4).
+  hipEvent_t prev_ready[2]{};
   uint64_t launch_index = 0;
   uint64_t release_counter = 0;
   ScaleBufs sb{};
@@ -613,7 +617,7 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
     c->pin_staged[j.pin_slot].store(0, std::memory_order_release);
   }
   // scans of this frame (s_det); its DoG / gradient buffers were last read by the candidate kernel two frames ago
-  if (c->ev_flag_used[b]) HIPCHK(hipStreamWaitEvent(c->s_det, c->ev_flag[b], 0));
+  if (c->prev_ready[b]) HIPCHK(hipStreamWaitEvent(c->s_det, c->prev_ready[b], 0));
   const void* img = j.img;
   int is_u8 = j.is_u8;
   if (is_u8 && c->undist_map) {  // x3 + undistort (rebvio.cpp:43-47); its output was last read by the scans two frames ago
@@ -624,7 +628,7 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   // The scan stream is the busiest of the three: it hands the frame over after the last ROW pass, the last column pass and
   // the DoG / gradient kernel run at the head of the keyline stream.
   // Their inputs sb.a[] are then read while the scan stream already works on the next frame, hence the pair per parity;
-  // the frame after next waits for ev_flag[b] (recorded behind them) above.
+  // the frame after next waits for this frame's `ready` event (prev_ready[b]) above.
   launch_scale_space(c->s_det, c->K, img, is_u8, sb, c->widths, db.rowcount, 1);
   HIPCHK(hipEventRecord(c->ev_scan[b], c->s_det));
   // keyline extraction + chaining (s_key), overlapping the next frame's scans
@@ -634,12 +638,11 @@ int detect_launch(rebvio_hip_ctx* c, const rebvio_hip_ctx::DetJob& j) {
   const int fw[2] = {c->widths[0][2], c->widths[1][2]};
   launch_keylines(c->s_key, c->K, sb, db, m->d, j.det_in, j.det_out, j.prev_st, c->fuse_dog ? fw : nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->ev_flag[b], c->s_key));  // (after join: coarser than needed, same stream order)
-  c->ev_flag_used[b] = true;
   // distance field of this map, behind its keylines on the same stream (stream order is the dependency)
   launch_df_build(c->s_key, c->K, m->d, j.det_out, true);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(m->ready, c->s_key));
+  c->prev_ready[b] = m->ready;  // (pooled maps and their events live as long as the context)
   m->enqueued.store(1, std::memory_order_release);
   return 0;
 }
@@ -1189,7 +1192,6 @@ int rebvio_hip_create(const rebvio_hip_params* p, rebvio_hip_ctx** out) {
   c->rowcount2[0] = c->db.rowcount;
   for (int i = 0; i < 2; ++i) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_flag[i], hipEventDisableTiming));
   }
   for (int f = 0; f < 2; ++f) {
     c->sa2[0][f] = c->sb.a[f];
@@ -1351,7 +1353,6 @@ void rebvio_hip_destroy(rebvio_hip_ctx* c) {
   }
   for (int i = 0; i < 2; ++i) {
     if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
-    if (c->ev_flag[i]) (void)hipEventDestroy(c->ev_flag[i]);
   }
   for (int i = 1; i < kDetPar; ++i) {
     if (c->dog2[i]) (void)hipFree(c->dog2[i]);
