@@ -1809,6 +1809,9 @@ int rebvio_hip_ext_rot_vel(rebvio_hip_ctx* c, const float vel[3], float Wx[36], 
 int rebvio_hip_directed_match(rebvio_hip_ctx* c, rebvio_hip_map* nm, rebvio_hip_map* om, const float vel[3],
                               const float Rvel[9], const float Rback[9], float max_radius, int* matches, int* kf_matches) {
   HIPCHK(hipSetDevice(c->device));
+  // (a probe's slot index 2 * step + side takes 10 bits of a candidate-list entry of k_directed_match_c; rebvio_hip_create bounds
+  // search_range the same way)
+  if (!(max_radius >= 0.f) || max_radius > 255.f) return fail_msg("directed_match: max_radius outside 0..255", -3);
   HIPCHK(trk_wait_ready(c->s_trk, om));
   HIPCHK(trk_wait_ready(c->s_trk, nm));
   float vel_r[3], Rvel_r[9];

@@ -389,6 +389,36 @@ def test_directed_match_regularize_ekf_bit_exact(orc_mod, B, c2_stream, c3_strea
     assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="depth EKF")
 
 
+@pytest.mark.parametrize("head", [None, "compact4", "compact1"], ids=["compact8", "compact4", "compact1"])
+def test_directed_match_beyond_one_probe_window(orc_mod, B, c2_stream, monkeypatch, head):
+    """searchMatch with max_radius = 100 (the reference's callers pass 40, rebvio.cpp:245): t_steps reaches 103, so the long searches
+    of k_directed_match_c run through three windows of 40 probe steps - the +-1.0f chains continue from window to window in the
+    owners' registers, a keyline found in one window is not probed in the next - in every instantiation. Bit-exact against the
+    oracle, like the one-window case of test_directed_match_regularize_ekf_bit_exact."""
+    frames, cam = c2_stream
+    if head:
+        monkeypatch.setenv("REBVIO_HIP_DM_HEAD", head)
+    else:
+        monkeypatch.delenv("REBVIO_HIP_DM_HEAD", raising=False)
+    P = warm(orc_mod, B, frames, cam, 3, **KW_C2)
+    om_old, om_new = P.om
+    gm_old, gm_new = P.gm
+    P.orc.build_distance_field(om_new)
+    P.ctx.build_distance_field(gm_new)
+    ro = P.orc.minimize_vel(om_old)
+    P.orc.forward_match(om_old, om_new)
+    gm_old.upload(om_old.keylines())
+    gm_new.upload(om_new.keylines())
+    a = 0.0007
+    Rb = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    no, kfo = P.orc.directed_match(om_new, om_old, ro["vel"], ro["Rvel"], Rb, max_radius=100.0)
+    ng, kfg = P.ctx.directed_match(gm_new, gm_old, ro["vel"], ro["Rvel"], Rb, max_radius=100.0)
+    assert (no, kfo) == (ng, kfg) and no > 5000
+    assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="directedMatch, radius 100")
+    with pytest.raises(B.HipError):
+        P.ctx.directed_match(gm_new, gm_old, ro["vel"], ro["Rvel"], Rb, max_radius=300.0)
+
+
 def test_c3_stream_tracks_oracle_stream(orc_mod, B):
     """BASELINE config 3 as a STREAM (1280x960, ~58k keylines; k_lm_chain<512> on 125 workgroups, the directedMatch
     kernel with one lane per keyline) through rebvio_hip_push_frame_u8_device against the oracle driven over the
