@@ -489,8 +489,8 @@ int alloc_map(rebvio_hip_ctx* c, rebvio_hip_map* m) {
   // device finishes 10 us later for 1.2 MB), on the null stream, which the context's non-blocking streams do not wait for. A map
   // the pool grows by while the pipeline is running is handed to the detect kernels microseconds later: without this wait a late
   // fill wiped what they had written - the state record (n = 0), the dense mask, the distance field (every tryVel evaluation a
-  // penalty: zero velocity, NaN covariance) - on a few per cent of fresh streams' first frames. (Round 3 saw exactly these records
-  // on its 192x144 stream and put them down to kernel-bound stop events)
+  // penalty: zero velocity, NaN covariance) - on a few per cent of fresh streams' first frames. (Round 3 saw records of this kind
+  // on its 192x144 stream with kernel-bound stop events; the race explains them, that configuration was not re-run.)
   HIPCHK(hipStreamSynchronize(nullptr));
   HIPCHK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&m->detected, hipEventDisableTiming));
