@@ -381,6 +381,49 @@ __device__ __forceinline__ void lm_step_wave(LmState& s_lds, const float* red_ld
   if (lane == 0) s_lds = t;
 }
 
+// lm_step_wave for the step in front of a run of speculative evaluations (k_lm_chain_spec): besides the real state (q = 0) the
+// wave forms, side by side in its four 16-lane rows, the states q = 1 .. 3 the NEXT steps start from if every one of them
+// rejects - q rejections' (u, v) updates on the state the bookkeeping left (core.cpp:180-183: a rejection changes nothing
+// else), then the trial point from that state's own inverse. One inverse's latency instead of two in a row; same operations
+// per state as lm_step_book on a NaN score + lm_step_matrix + the inverse + lm_step_apply, same bits. stc[q] for q < nstates.
+__device__ __forceinline__ void lm_step_wave_states(LmState& s_lds, const float* red_lds, int call, float (*inv_lds)[9], int lane,
+                                                    LmState* stc, int nstates) {
+  LmState t = s_lds;
+  float r[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r[i] = red_lds[i];
+  lm_step_book(t, r, call);
+  const int q = lane >> 4, e = lane & 15;
+  for (int j = 0; j < q; ++j) {
+    t.u *= t.v;
+    t.v = (float)((double)t.v * 2.0);
+  }
+  float M[9];
+  lm_step_matrix(t, M);
+  const float d = glue_det3(M);
+  float o;
+  switch (e) {
+    case 0: o = M[4] * M[8] - M[5] * M[7]; break;
+    case 1: o = M[2] * M[7] - M[1] * M[8]; break;
+    case 2: o = M[1] * M[5] - M[2] * M[4]; break;
+    case 3: o = M[5] * M[6] - M[3] * M[8]; break;
+    case 4: o = M[0] * M[8] - M[2] * M[6]; break;
+    case 5: o = M[2] * M[3] - M[0] * M[5]; break;
+    case 6: o = M[3] * M[7] - M[4] * M[6]; break;
+    case 7: o = M[1] * M[6] - M[0] * M[7]; break;
+    default: o = M[0] * M[4] - M[1] * M[3]; break;
+  }
+  glue_wave_sync();  // (the previous step's inverse has been read by every lane)
+  if (e < 9) inv_lds[q][e] = o / d;
+  glue_wave_sync();
+  float inv[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) inv[i] = inv_lds[q][i];
+  lm_step_apply(t, inv);
+  if (e == 0 && q < nstates) stc[q] = t;
+  if (lane == 0) s_lds = t;
+}
+
 // Shared prologue: fixed-order reduction of the previous tryVel call's block records + carry-in of the
 // "last written fi" (oracle header, H3) for this workgroup. The records are staged in LDS by one coalesced
 // pass of the whole workgroup (one memory round trip), then summed in block order from LDS.
@@ -746,23 +789,46 @@ struct XrvIn {
   float gn;
   float2 q;
 };
-__device__ __forceinline__ void xrv_eval(const KParams& p, const MapDev& om, MapDev& nm, int idx, int do_forward, XrvIn k, float vx,
-                                         float vy, float vz, float row[6], float* Y_out, int* cnt_out) {
+// The forwardMatch gather of one keyline of the new map as loads only (what the old keyline named by `key` hands over):
+// a caller that knows the keys early (k_lm_chain_spec) has these in flight while it still decides where the velocity ends up.
+struct XrvFwd {
+  float2 rs, mpi, mgrad;
+  float mgnorm;
+  unsigned matches;
+  int kf, o;  // o < 0: nobody matched into this keyline
+};
+__device__ __forceinline__ XrvFwd xrv_gather(const MapDev& om, unsigned long long key) {
+  XrvFwd f{};
+  f.o = -1;
+  if (key != 0ull) {
+    const int o = (int)(unsigned)(key & 0xFFFFFFFFull);
+    f.o = o;
+    f.rs = om.rs[o];
+    f.mpi = om.pos_img[o];
+    f.matches = om.matches[o];
+    f.mgrad = om.grad[o];
+    f.mgnorm = om.gnorm[o];
+    f.kf = om.match_kf[o];
+  }
+  return f;
+}
+__device__ __forceinline__ void xrv_apply(const KParams& p, MapDev& nm, int idx, int do_forward, const XrvFwd& f, XrvIn k, float vx,
+                                          float vy, float vz, float row[6], float* Y_out, int* cnt_out) {
   float2 rs = k.rs, mpi = k.mpi;
   int mid = k.mid;
   if (do_forward) {
-    if (k.key != 0ull) {
-      const int o = (int)(unsigned)(k.key & 0xFFFFFFFFull);
-      rs = om.rs[o];
-      mpi = om.pos_img[o];
+    if (f.o >= 0) {
+      const int o = f.o;
+      rs = f.rs;
+      mpi = f.mpi;
       mid = o;
       nm.rs[idx] = rs;
-      nm.matches[idx] = om.matches[o] + 1u;
+      nm.matches[idx] = f.matches + 1u;
       nm.match_id[idx] = o;
       nm.mpos_img[idx] = mpi;
-      nm.mgrad[idx] = om.grad[o];
-      nm.mgnorm[idx] = om.gnorm[o];
-      nm.match_kf[idx] = om.match_kf[o];
+      nm.mgrad[idx] = f.mgrad;
+      nm.mgnorm[idx] = f.mgnorm;
+      nm.match_kf[idx] = f.kf;
     }
   }
   if (mid >= 0) {
@@ -790,6 +856,11 @@ __device__ __forceinline__ void xrv_eval(const KParams& p, const MapDev& om, Map
     *Y_out = Y;
     *cnt_out = 1;
   }
+}
+__device__ __forceinline__ void xrv_eval(const KParams& p, const MapDev& om, MapDev& nm, int idx, int do_forward, XrvIn k, float vx,
+                                         float vy, float vz, float row[6], float* Y_out, int* cnt_out) {
+  const XrvFwd f = xrv_gather(om, do_forward ? k.key : 0ull);
+  xrv_apply(p, nm, idx, do_forward, f, k, vx, vy, vz, row, Y_out, cnt_out);
 }
 
 // Sequence stamp of one extRotVel block record (kXrvStride floats: 27 sums, the match count, two spare words, a checksum, the stamp),
@@ -1409,6 +1480,9 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   const TvIn in = make_tvin(p, om.gnorm[idx], om.rs[idx], om.pos_img[idx], om.grad[idx], om.matches[idx]);
   float res = om.residual[idx];
   XrvIn xk{};
+  XrvFwd xf{};
+  xf.o = -1;
+  bool xf_valid = false;  // the forwardMatch gathers of this thread's keyline are in `xf` (issued behind the speculative collect)
   xk.mid = nm.match_id[idx];
   xk.rs = nm.rs[idx];
   xk.mpi = nm.mpos_img[idx];
@@ -1424,6 +1498,20 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   if (tid == 0) s = *st_in;
   if (tid < kChainGroups) carry_in[tid] = 0.f;
   __syncthreads();
+  const unsigned min_matches = min(p.min_match_threshold, frame_count);
+  const bool lm_live = blockIdx.x == 0 || (int)blockIdx.x * kChainGroups < nblocks;
+  // Evaluation 0 is taken at the incoming velocity, so its projection and its two dependent gathers (field cell, then the
+  // cell's keyline) start before the sigma quantile is known; the quantile's only part in it - the uncertainty gate of
+  // tv_project - is applied to the finished projection below (a gated keyline's gathers are never looked at).
+  TvProj pj0{};
+  pj0.cell = -1;
+  pj0.skip = true;
+  TvGeo ge0{};
+  ge0.id = -1;
+  if (lm_live && idx < n) {
+    pj0 = tv_project(p, in, s.vel[0], s.vel[1], s.vel[2], __builtin_inff(), thr, min_matches);
+    ge0 = tv_geometry(p, nm, tv_cell(nm, pj0));
+  }
   if (tid < 64) {
     const float q = quantile_from_hist_wave(shist, p.quantile_num_bins, p.quantile_cutoff, n, tid);
     if (tid == 0) {
@@ -1432,9 +1520,11 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     }
   }
   __syncthreads();
-  const unsigned min_matches = min(p.min_match_threshold, frame_count);
   const float srm = s.sigma_rho_min;
-  const bool lm_live = blockIdx.x == 0 || (int)blockIdx.x * kChainGroups < nblocks;
+  if (in.rs.y > srm) {
+    pj0.skip = true;
+    pj0.cell = -1;
+  }
   const int live_wgs = max(1, (nblocks + kChainGroups - 1) / kChainGroups);
   unsigned long long* xch_final = xch + (size_t)kMaxLmCalls * nrec_launched * kPartStride;
   unsigned long long* xch_carry = xch_final + kPartStride;                  // [kMaxLmCalls][nwg][2]
@@ -1575,20 +1665,18 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   }
   RH_STAMP(1);
   if (lm_live) {
-    normal_pass(0, 0);
+    do_eval(0, tag_of(0, 0), pj0, ge0, false);  // (calls >= kf + 2: evaluation 0 is never the last one)
     RH_STAMP(2);
     for (int call = 1; call < kf; ++call) normal_pass(call, 0);
     RH_STAMP(3);
     collect(kf - 1, tag_of(kf - 1, 0));
-    if (tid < 64) {
-      lm_step_wave(s, red, kf, false, lm_inv[0], tid);
-      if (tid == 0) stc[0] = s;
-    }
+    // the real step and the first three states under the hypothesis in one go (lm_step_wave_states)
+    if (tid < 64) lm_step_wave_states(s, red, kf, lm_inv, tid, stc, min(nspec, 4));
     __syncthreads();
-    // states under the hypothesis: state g + 1 applies g rejections' (u, v) updates and then one lm_step whose score is NaN (the
-    // gain test fails for any denominator): exactly the reject branch of core.cpp:180-183 plus the next trial point. Sixteen
-    // lanes per state, nine of them with one cofactor of its 3x3 inverse each (see lm_step_wave).
-    for (int g0 = 0; g0 < nspec - 1; g0 += 4) {
+    // further states under the hypothesis (iterations > 5): state g + 1 applies g rejections' (u, v) updates and then one
+    // lm_step whose score is NaN (the gain test fails for any denominator): exactly the reject branch of core.cpp:180-183
+    // plus the next trial point. Sixteen lanes per state, nine of them with one cofactor of its 3x3 inverse each.
+    for (int g0 = 3; g0 < nspec - 1; g0 += 4) {
       if (tid < 64) {
         const int g = g0 + (tid >> 4), e = tid & 15;
         const bool act = g < nspec - 1;
@@ -1677,10 +1765,8 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         }
       }
     }
-    // Every wave's forwardMatch atomics (performed at the memory side, device scope) are ACKNOWLEDGED before the workgroup goes
-    // on to publish its records: vmcnt(0) here, on the waves that issued them. (A system-scope release fence on the
-    // publishing threads, as before, orders only THEIR OWN operations and writes the XCD's whole L2 back for it.)
-    vm_drain();
+    // (the forwardMatch atomics issued above stay in flight through the neighbour round and the weighted sums; they are
+    // waited for in front of the barrier the record sets are published behind)
     RH_STAMP(7);
     __syncthreads();
     // thread kChainThreads - 1 - k: hand-off behind evaluation kf + k (carry-in of evaluation kf + 1 + k), as in do_eval
@@ -1754,6 +1840,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
         }
       }
     }
+    // Every wave's forwardMatch atomics (performed at the memory side, device scope) are ACKNOWLEDGED before the workgroup goes
+    // on to publish its records: vmcnt(0) here, on the waves that issued them, in front of the barrier. (A system-scope release
+    // fence on the publishing threads orders only THEIR OWN operations and writes the XCD's whole L2 back for it.)
+    vm_drain();
     RH_STAMP(9);
     __syncthreads();
     if (tid < kChainGroups * 16) {
@@ -1802,6 +1892,11 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
           if (ok8[j]) recm[i0 + j * kChainThreads + tid] = o8[j];
       }
       __syncthreads();
+      // Every workgroup's record sets are in, hence every forwardMatch key of the last evaluation (vm_drain above): this
+      // keyline's key is fetched HERE, under the hypothesis, and returns while the sums are reduced and checked; the gathers
+      // through it follow the check (below) and return while the state is finished.
+      xch_acquire();
+      if (idx < n_new) xk.key = __hip_atomic_load(&nm.fwd_key[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int set0 = 0; set0 < nspec; set0 += kChainThreads / 160) {
         const int sl = tid / 160, set = set0 + sl;
         if (sl < kChainThreads / 160 && set < nspec) reduce_staged_sums(recm + (size_t)set * cap, nblocks, redm[set], sl * 160);
@@ -1828,6 +1923,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     }
     fa = first_accept;
     RH_STAMP(12);
+    if (fa < 0 || fa == nspec - 1) {  // the keys of the speculative last evaluation stand
+      if (idx < n_new) xf = xrv_gather(om, xk.key);
+      xf_valid = true;
+    }
     if (fa < 0) {
       if (tid == 0) {  // every evaluation rejected: the last rejection is the final step of core.cpp:166-185 (no new trial point)
         LmState t = stc[nspec - 1];
@@ -1861,10 +1960,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
       __syncthreads();
     }
   }
-  if (blockIdx.x == 0 && tid == 0) {
-    *st_out = s;
-    if (slot) slot_sum = slot_fill(slot, s, nm.st, om.st);  // zero-copy: the host reads these once the stamps say so
-  }
+  // The final state and the pair's result slot (zero-copy: the host reads them once the stamps say so) are written by the LAST
+  // live workgroup, behind its extRotVel records: every live workgroup holds the same state, and workgroup 0, which goes on
+  // to the device glue and is waited for by it, no longer spends a microsecond of a lone thread's stores in front of its rows.
+  const int fill_wg = live_wgs - 1;
   RH_STAMP(13);
   if (hist_to_zero && blockIdx.x == 0 && tid < 128) hist_to_zero[tid] = 0;  // every evaluation has consumed the histogram
   if (blockIdx.x == 0 && tid < 3) xch_publish(xch_final + tid, tag_final, s.vel[tid]);
@@ -1876,11 +1975,14 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
   float row[6] = {0, 0, 0, 0, 0, 0};
   float Y = 0.f;
   int cnt = 0;
-  xch_acquire();  // behind the polls of the last evaluation's records: the forwardMatch keys of every workgroup (vm_drain)
-  if (idx < n_new) {
-    xk.key = __hip_atomic_load(&nm.fwd_key[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    xrv_eval(p, om, nm, idx, 1, xk, vx, vy, vz, row, &Y, &cnt);
+  if (!xf_valid) {  // (workgroups without LM work, or after a roll-back)
+    xch_acquire();  // behind the polls of the last evaluation's records: the forwardMatch keys of every workgroup (vm_drain)
+    if (idx < n_new) {
+      xk.key = __hip_atomic_load(&nm.fwd_key[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xf = xrv_gather(om, xk.key);
+    }
   }
+  if (idx < n_new) xrv_apply(p, nm, idx, 1, xf, xk, vx, vy, vz, row, &Y, &cnt);
   float v[28];
   {
     int k = 0;
@@ -1916,6 +2018,10 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
     if (!ga.lm) xrv_record_stamp(xrv_part + ((size_t)blockIdx.x * kChainGroups + g) * kXrvStride, k, ga.seq, stored);
   }
   RH_STAMP(14);
+  if ((int)blockIdx.x == fill_wg && tid == 0) {
+    *st_out = s;
+    if (slot) slot_sum = slot_fill(slot, s, nm.st, om.st);
+  }
   if (stamps && blockIdx.x == 0 && tid == 0) {
     stamps[15] = stamps[14];  // (no device glue in this launch: a zero-length last segment)
     stamps[0] = 1ull;
@@ -1927,7 +2033,7 @@ __device__ __forceinline__ void lm_chain_spec_body(KParams p, MapDev om, MapDev 
                                     ? (calls - 2) * (cap / kPartStride) * kPartStride / kXrvStride : 1, gw, s, bar_err, slow_poll, stamps);
     RH_STAMP(15);
   }
-  if (slot && blockIdx.x == 0 && tid == 0) {  // the slot's stamp: by the directedMatch launch with the glue's record, or here
+  if (slot && (int)blockIdx.x == fill_wg && tid == 0) {  // the slot's stamp: by the directedMatch launch with the glue's record, or here
     slot->sum = slot_sum ^ ga.seq;
     if (ga.lm && ga.stage)
       ga.stage->host_slot = slot;
