@@ -169,6 +169,7 @@ namespace {
 struct StageTimers {
   bool on = std::getenv("REBVIO_HOST_TIMERS") != nullptr;
   double t[4] = {0, 0, 0, 0};
+  double t_bias = 0;  // Core::estimateBias alone (inside t[1])
   double t_in = 0;  // from the end of a pair to the next pair's first device call (input queue, IMU pre-integration read)
   std::chrono::steady_clock::time_point pair_end;
   bool have_end = false;
@@ -194,6 +195,57 @@ struct StageTimers {
     if (on && n)
       std::fprintf(stderr, "[Rebvio] per pair (us): first half on device %.1f  acceleration + bias/scale filter %.1f  second half on device %.1f  pose + callbacks %.1f  (between pairs: input queue + IMU read %.1f)\n",
                    t[0] / n, t[1] / n, t[2] / n, t[3] / n, t_in / n);
+    const backend::FusionCounters& f = backend::t_fusion;
+    if (on && n && f.gn_calls)
+      std::fprintf(stderr, "[Rebvio]   estimateBias %.1f us per pair: %.2f Gauss-Newton iterations per call, %lu of %lu solves through the pseudo-inverse\n",
+                   t_bias / n, (double)f.gn_iterations / f.gn_calls, f.pinv_solves, f.gn_iterations);
+  }
+};
+// REBVIO_DUMP_FUSION=<file>: every Core::estimateBias call of the run as 237 raw floats - 100 inputs (sacc, facc, kP, Rot, Qg,
+// Qrot, Qbias, QKp, Rg, g_norm, Rs, Rf, Wvw), the 68 state words (X, P, g_est, b_est, Xvw) before the call, the scale it
+// returned and the state words after it. tests/golden/estimate_bias_calls.npz was recorded this way
+// (tools/record_fusion_calls.py); tests/test_fusion_math.py replays it on the CPU.
+struct FusionDump {
+  FILE* f = std::getenv("REBVIO_DUMP_FUSION") ? std::fopen(std::getenv("REBVIO_DUMP_FUSION"), "wb") : nullptr;
+  void put(float v) { std::fwrite(&v, 4, 1, f); }
+  void put3(const types::Matrix3f& m) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) put(m(i, j));
+  }
+  void state(const SABEstimator::State& s, const types::Vector6f& Xvw) {
+    for (int i = 0; i < 7; ++i) put(s.X[i]);
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) put(s.P(i, j));
+    for (int i = 0; i < 3; ++i) put(s.g_est[i]);
+    for (int i = 0; i < 3; ++i) put(s.b_est[i]);
+    for (int i = 0; i < 6; ++i) put(Xvw[i]);
+  }
+  void before(const types::Vector3f& sacc, const types::Vector3f& facc, float kP, const types::Matrix3f& Rot,
+              const SABEstimator::State& s, const types::Matrix6f& Wvw, const types::Vector6f& Xvw, float g_norm) {
+    if (!f) return;
+    for (int i = 0; i < 3; ++i) put(sacc[i]);
+    for (int i = 0; i < 3; ++i) put(facc[i]);
+    put(kP);
+    put3(Rot);
+    put3(s.Qg);
+    put3(s.Qrot);
+    put3(s.Qbias);
+    put(s.QKp);
+    put(s.Rg);
+    put(g_norm);
+    put3(s.Rs);
+    put3(s.Rv);
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) put(Wvw(i, j));
+    state(s, Xvw);
+  }
+  void after(float k, const SABEstimator::State& s, const types::Vector6f& Xvw) {
+    if (!f) return;
+    put(k);
+    state(s, Xvw);
+  }
+  ~FusionDump() {
+    if (f) std::fclose(f);
   }
 };
 }  // namespace
@@ -201,6 +253,7 @@ struct StageTimers {
 void Rebvio::stateEstimationProcess() {
   REBVIO_INFO("Starting State Estimation Process..");
   StageTimers timers;
+  FusionDump fusion_dump;
   rebvio_hip_ctx* ctx = core_.session()->ctx();
   const types::Float FMAX = std::numeric_limits<types::Float>::max();
   types::Vector3f Pos = TooN::Zeros;
@@ -380,9 +433,13 @@ void Rebvio::stateEstimationProcess() {
 
     types::Matrix3f R_second;
     if (num_frames_ > 4u + (unsigned)config_.imu_state.init_bias_frame_num) {  // rebvio.cpp:210-224
+      const auto tb0 = timers.on ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+      fusion_dump.before(imu_state_.As, imu_state_.Av, 1.0, R, sab_state_, W_Xgv, Xgva, config_.imu_state.g_norm);
       K = core_.estimateBias(imu_state_.As, imu_state_.Av, 1.0, R, sab_state_.X, sab_state_.P, sab_state_.Qg, sab_state_.Qrot,
                              sab_state_.Qbias, sab_state_.QKp, sab_state_.Rg, sab_state_.Rs, sab_state_.Rv, sab_state_.g_est,
                              sab_state_.b_est, W_Xgv, Xgva, config_.imu_state.g_norm);
+      if (timers.on) timers.t_bias += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb0).count();
+      fusion_dump.after(K, sab_state_, Xgva);
       imu_state_.dVgva = Xgva.slice<0, 3>();
       imu_state_.dWgva = Xgva.slice<3, 3>();
       const types::Matrix3f R0gva = TooN::SO3<types::Float>(imu_state_.dWgva).get_matrix();

@@ -7,8 +7,12 @@
 
 #include "../csrc/hostmath.hpp"
 #include "rebvio/core.hpp"
+#include "session.hpp"
 
 namespace rebvio {
+namespace backend {
+thread_local FusionCounters t_fusion;
+}
 
 namespace {
 template <int R, int C>
@@ -175,6 +179,7 @@ void sym_solve_d(const double* A_, const double* b_, double* x_) {
     }
   }
   if (!ok) {
+    ++backend::t_fusion.pinv_solves;
     sym_pinv_solve_d<N>(A_, b_, x_);
     return;
   }
@@ -237,73 +242,151 @@ bool SABEstimator::problem(rebvio::types::Matrix7f& JtJ_, rebvio::types::Vector7
   for (int i = 0; i < 11; ++i) dFda[i] = 0;
   for (int i = 0; i < 3; ++i) dFda[i] = -(cfg.a_s[i] + g[i]) * sa - cfg.a_v[i] * ca;
   dFda[4] = 1.0;
-  Mx<11, 6> dFdx1 = Mx<11, 6>::zeros();
+  // dF/dx1 (11 x 6) has 24 structural non-zeros - rows 0-2: ca on the diagonal; row 3: 2 g; rows 5-7: [Rb | (Rb g)x]; rows 8-10:
+  // [0 | I] - and W = blockdiag(Wz, 1 / Rg, Wp), dW/da = blockdiag(dWz, 0, 0). The reference multiplies the dense 11 x 11 /
+  // 11 x 6 matrices (sab_estimator.cpp:100-160); every term skipped below is a product with one of those exact zeros, and
+  // a sum that starts at +0 does not change when +-0 is added to it, so the sums keep their terms in the dense order and their
+  // bits (checked against recorded calls of the dense form: tests/test_fusion_math.py).
   const float Gx[3][3] = {{0.0f, Rg3[2], -Rg3[1]}, {-Rg3[2], 0.0f, Rg3[0]}, {Rg3[1], -Rg3[0], 0.0f}};
-  for (int i = 0; i < 3; ++i) dFdx1.a[i][i] = ca;
-  for (int j = 0; j < 3; ++j) dFdx1.a[3][j] = 2.0 * g[j];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      dFdx1.a[5 + i][j] = Rb.a[i][j];
-      dFdx1.a[5 + i][3 + j] = Gx[i][j];
-    }
-  for (int i = 0; i < 3; ++i) dFdx1.a[8 + i][3 + i] = 1.0f;
-  Mx<11, 11> W = Mx<11, 11>::zeros();  // P = blockdiag(Pz, Rg, Pp) itself is only needed through its 3x3 block (below)
+  float g2[3];
+  for (int j = 0; j < 3; ++j) g2[j] = 2.0 * g[j];
   Mx<3, 3> Pz;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) Pz.a[i][j] = sa * sa * cfg.Rv(i, j) + ca * ca * cfg.Rs(i, j);
-  Mx<7, 7> Pp;
-  for (int i = 0; i < 7; ++i)
-    for (int j = 0; j < 7; ++j) Pp.a[i][j] = cfg.Pp(i, j);
   const Mx<3, 3> Wz = chol_inverse<3>(Pz);
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) W.a[i][j] = Wz.a[i][j];
-  W.a[3][3] = 1.0 / cfg.Rg;
+  const float W33 = 1.0 / cfg.Rg;
   if (!Wp_valid_) {  // Cholesky<7>(Pp).get_inverse() does not depend on X: once per estimator, not once per iteration
+    Mx<7, 7> Pp;
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) Pp.a[i][j] = cfg.Pp(i, j);
     const Mx<7, 7> Wp = chol_inverse<7>(Pp);
     for (int i = 0; i < 7; ++i)
       for (int j = 0; j < 7; ++j) Wp_(i, j) = Wp.a[i][j];
     Wp_valid_ = true;
   }
+  float Wp[7][7];
   for (int i = 0; i < 7; ++i)
-    for (int j = 0; j < 7; ++j) W.a[4 + i][4 + j] = Wp_(i, j);
-  // dP/da is non-zero in the 3x3 measurement block only, so dW/da = -W dP/da W and dW/da P dW/da live there too: the
-  // products are formed on the 3x3 blocks (the dense 11x11 products add exact zeros to the same terms)
+    for (int j = 0; j < 7; ++j) Wp[i][j] = Wp_(i, j);
+  // dP/da is non-zero in the 3x3 measurement block only, so dW/da = -W dP/da W and dW/da P dW/da live there too
   Mx<3, 3> dPz;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) dPz.a[i][j] = 2.0 * sa * ca * (cfg.Rv(i, j) - cfg.Rs(i, j));
   Mx<3, 3> dWz = mul(mul(Wz, dPz), Wz);
-  Mx<11, 11> dWda = Mx<11, 11>::zeros();
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      dWz.a[i][j] = -dWz.a[i][j];
-      dWda.a[i][j] = dWz.a[i][j];
-    }
+    for (int j = 0; j < 3; ++j) dWz.a[i][j] = -dWz.a[i][j];
+  // x^T W y restricted to the non-zeros of x (rows 0-2 and row 4 of W's blocks): t = x^T W, then the dot product with y
+  float tdW[11];  // dFda^T W: columns 0-2 through Wz, column 3 is 0 (dFda[3] = 0), columns 4-10 = 1.0 * Wp[0][.]
+  for (int j = 0; j < 3; ++j) {
+    float acc = 0;
+    for (int k = 0; k < 3; ++k) acc += dFda[k] * Wz.a[k][j];
+    tdW[j] = acc;
+  }
+  tdW[3] = 0;
+  for (int j = 0; j < 7; ++j) tdW[4 + j] = dFda[4] * Wp[0][j];
   {
     const Mx<3, 3> Mz = mul(mul(dWz, Pz), dWz);
-    JtJ_(0, 0) = 0.25 * quad<3>(F, Mz, F) + quad<11>(dFda, dWda, F) + quad<11>(dFda, W, dFda);
+    float q3 = 0;  // quad<11>(dFda, W, dFda): dFda is non-zero at 0-2 and 4
+    for (int j = 0; j < 3; ++j) q3 += tdW[j] * dFda[j];
+    q3 += tdW[4] * dFda[4];
+    JtJ_(0, 0) = 0.25 * quad<3>(F, Mz, F) + quad<3>(dFda, dWz, F) + q3;
   }
-  const Mx<6, 11> dT = tr(dFdx1);
+  float t1[3], t2[11];  // dWda F (rows 0-2; the rest is 0) and W dFda
+  for (int i = 0; i < 3; ++i) {
+    float a1 = 0, a2 = 0;
+    for (int k = 0; k < 3; ++k) {
+      a1 += dWz.a[i][k] * F[k];
+      a2 += Wz.a[i][k] * dFda[k];
+    }
+    t1[i] = a1;
+    t2[i] = a2;
+  }
+  t2[3] = 0;
+  for (int i = 0; i < 7; ++i) t2[4 + i] = Wp[i][0] * dFda[4];
+  // dT v for the transpose of dF/dx1 (6 x 11): row i < 3 has ca at k = i, 2 g[i] at k = 3, Rb[k - 5][i] at k = 5-7; row 3 + i has
+  // Gx[k - 5][i] at k = 5-7 and 1 at k = 8 + i. Terms in increasing k, as the dense product meets them.
+  auto dT_times = [&](const float* v, bool v3_zero, float* out) {
+    for (int i = 0; i < 3; ++i) {
+      float acc = 0;
+      acc += ca * v[i];
+      if (!v3_zero) acc += g2[i] * v[3];
+      for (int k = 0; k < 3; ++k) acc += Rb.a[k][i] * v[5 + k];
+      out[i] = acc;
+    }
+    for (int i = 0; i < 3; ++i) {
+      float acc = 0;
+      for (int k = 0; k < 3; ++k) acc += Gx[k][i] * v[5 + k];
+      acc += 1.0f * v[8 + i];
+      out[3 + i] = acc;
+    }
+  };
   {
-    float t1[11], t2[11], c1[6], c2[6];
-    mulv(dWda, F, t1);
-    mulv(W, dFda, t2);
-    mulv(dT, t1, c1);
-    mulv(dT, t2, c2);
+    float c2[6];
+    dT_times(t2, true, c2);
     for (int i = 0; i < 6; ++i) {
-      JtJ_(1 + i, 0) = 0.5 * c1[i] + c2[i];
+      const float c1 = (i < 3) ? ca * t1[i] : 0.0f;  // dT (dWda F): only k = i < 3 contributes
+      JtJ_(1 + i, 0) = 0.5 * c1 + c2[i];
       JtJ_(0, 1 + i) = JtJ_(1 + i, 0);
     }
   }
   {
-    const Mx<6, 6> B = mul(mul(dT, W), dFdx1);
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) JtJ_(1 + i, 1 + j) = B.a[i][j];
+    // T1 = dT W (6 x 11), then B = T1 dF/dx1 (6 x 6)
+    float T1[6][11];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) T1[i][j] = ca * Wz.a[i][j];
+      T1[i][3] = g2[i] * W33;
+      for (int j = 0; j < 7; ++j) {
+        float acc = 0;
+        for (int k = 0; k < 3; ++k) acc += Rb.a[k][i] * Wp[1 + k][j];
+        T1[i][4 + j] = acc;
+      }
+    }
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 4; ++j) T1[3 + i][j] = 0;
+      for (int j = 0; j < 7; ++j) {
+        float acc = 0;
+        for (int k = 0; k < 3; ++k) acc += Gx[k][i] * Wp[1 + k][j];
+        acc += 1.0f * Wp[4 + i][j];
+        T1[3 + i][4 + j] = acc;
+      }
+    }
+    for (int i = 0; i < 6; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        float acc = 0;
+        if (i < 3) {
+          acc += T1[i][j] * ca;
+          acc += T1[i][3] * g2[j];
+        }
+        for (int k = 0; k < 3; ++k) acc += T1[i][5 + k] * Rb.a[k][j];
+        JtJ_(1 + i, 1 + j) = acc;
+      }
+      for (int j = 0; j < 3; ++j) {
+        float acc = 0;
+        for (int k = 0; k < 3; ++k) acc += T1[i][5 + k] * Gx[k][j];
+        acc += T1[i][8 + j] * 1.0f;
+        JtJ_(1 + i, 4 + j) = acc;
+      }
+    }
   }
-  JtF_[0] = 0.5 * quad<11>(F, dWda, F) + quad<11>(dFda, W, F);
   {
-    float t[11], c[6];
-    mulv(W, F, t);
-    mulv(dT, t, c);
+    float q = 0;  // quad<11>(dFda, W, F) = (dFda^T W) . F
+    for (int j = 0; j < 3; ++j) q += tdW[j] * F[j];
+    for (int j = 4; j < 11; ++j) q += tdW[j] * F[j];
+    JtF_[0] = 0.5 * quad<3>(F, dWz, F) + q;
+  }
+  {
+    float t[11], c[6];  // W F, then dT (W F)
+    for (int i = 0; i < 3; ++i) {
+      float acc = 0;
+      for (int k = 0; k < 3; ++k) acc += Wz.a[i][k] * F[k];
+      t[i] = acc;
+    }
+    t[3] = W33 * F[3];
+    for (int i = 0; i < 7; ++i) {
+      float acc = 0;
+      for (int k = 0; k < 7; ++k) acc += Wp[i][k] * F[4 + k];
+      t[4 + i] = acc;
+    }
+    dT_times(t, false, c);
     for (int i = 0; i < 6; ++i) JtF_[1 + i] = c[i];
   }
   return true;
@@ -311,7 +394,9 @@ bool SABEstimator::problem(rebvio::types::Matrix7f& JtJ_, rebvio::types::Vector7
 
 int SABEstimator::gaussNewton(rebvio::types::Vector7f& X, int iter_max, types::Float a_tol, types::Float r_tol) {
   int i = 0;
+  ++backend::t_fusion.gn_calls;
   for (; i < iter_max; ++i) {
+    ++backend::t_fusion.gn_iterations;
     types::Matrix7f JtJ;
     types::Vector7f JtF;
     problem(JtJ, JtF, X);
@@ -376,14 +461,40 @@ types::Float Core::estimateBias(const rebvio::types::Vector3f& sacc, const rebvi
       Q.a[1 + i][1 + j] = Qg2.a[i][j] + Qgm.a[i][j];
       Q.a[4 + i][4 + j] = Qbias(i, j);
     }
+  // F = blockdiag(kP, Rot^T, I): the dense products F X, (F P) F^T of core.cpp:372-376 restricted to F's non-zeros, terms in the
+  // dense order (a skipped term is a product with an exact zero, see SABEstimator::problem)
   float Xa[7], Xp[7];
   for (int i = 0; i < 7; ++i) Xa[i] = X[i];
-  mulv(F, Xa, Xp);
+  Xp[0] = F.a[0][0] * Xa[0];
+  for (int i = 1; i < 4; ++i) {
+    float acc = 0;
+    for (int k = 1; k < 4; ++k) acc += F.a[i][k] * Xa[k];
+    Xp[i] = acc;
+  }
+  for (int i = 4; i < 7; ++i) Xp[i] = F.a[i][i] * Xa[i];
   for (int i = 0; i < 7; ++i) X[i] = Xp[i];
   Mx<7, 7> Pm;
   for (int i = 0; i < 7; ++i)
     for (int j = 0; j < 7; ++j) Pm.a[i][j] = P(i, j);
-  Mx<7, 7> Ppm = mul(mul(F, Pm), tr(F));
+  Mx<7, 7> FP, Ppm;
+  for (int j = 0; j < 7; ++j) {
+    FP.a[0][j] = F.a[0][0] * Pm.a[0][j];
+    for (int i = 1; i < 4; ++i) {
+      float acc = 0;
+      for (int k = 1; k < 4; ++k) acc += F.a[i][k] * Pm.a[k][j];
+      FP.a[i][j] = acc;
+    }
+    for (int i = 4; i < 7; ++i) FP.a[i][j] = F.a[i][i] * Pm.a[i][j];
+  }
+  for (int i = 0; i < 7; ++i) {
+    Ppm.a[i][0] = FP.a[i][0] * F.a[0][0];
+    for (int j = 1; j < 4; ++j) {
+      float acc = 0;
+      for (int k = 1; k < 4; ++k) acc += FP.a[i][k] * F.a[j][k];
+      Ppm.a[i][j] = acc;
+    }
+    for (int j = 4; j < 7; ++j) Ppm.a[i][j] = FP.a[i][j] * F.a[j][j];
+  }
   types::Matrix7f Pp;
   for (int i = 0; i < 7; ++i)
     for (int j = 0; j < 7; ++j) Pp(i, j) = Ppm.a[i][j] + Q.a[i][j];
@@ -432,5 +543,6 @@ types::Float Core::estimateBias(const rebvio::types::Vector3f& sacc, const rebvi
   }
   return k;
 }
+
 
 }  // namespace rebvio

@@ -37,6 +37,12 @@ class Session {
   std::mutex mu_;
 };
 
+// REBVIO_HOST_TIMERS diagnostics of the fusion thread (sab_estimator.cpp counts, rebvio.cpp prints)
+struct FusionCounters {
+  unsigned long gn_calls = 0, gn_iterations = 0, pinv_solves = 0;
+};
+extern thread_local FusionCounters t_fusion;
+
 [[noreturn]] void fail(const char* what, int rc);
 inline void check(const char* what, int rc) {
   if (rc != 0) fail(what, rc);

@@ -6,10 +6,14 @@
 //   gbc   : X6 Wx36 Wb9 Rg9 Rb9                            -> X6 Wx36 Wb9 dg3          (Core::gyroBiasCorrection + the C-ABI's hostmath form)
 //   gpre  : W_Bg9 s_g s_b n                                 -> n x (gyro_pre's W_Bg9, gyro_bias_correction's W_Bg9)
 //   chol6 : A36                                            -> inv36
+//   bias  : n x (sacc3 facc3 kP Rot9 Qg9 Qrot9 Qbias9 QKp Rg g_norm Rs9 Rf9 Wvw36 | X7 P49 g_est3 b_est3 Xvw6)
+//                                                          -> n x (K | X7 P49 g_est3 b_est3 Xvw6)   (Core::estimateBias; the
+//           record layout of REBVIO_DUMP_FUSION, rebvio_amd/host/rebvio.cpp)
 //   so3   : w3 a3 b3                                       -> exp(w)9 ln(exp(w))3 R(a->b)9 hostmath exp(w)9
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -95,6 +99,37 @@ int main(int argc, char** argv) {
       float w9[9];
       hm::store3(W, w9);
       for (int i = 0; i < 9; ++i) out.push_back(w9[i]);
+    }
+  } else if (mode == "bias") {
+    if (in.size() % 168 != 0) return 3;
+    Core core(std::make_shared<Camera>());
+    for (size_t c = 0; c < in.size() / 168; ++c) {
+      const float* q = p + c * 168;
+      types::Matrix6f W;
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) W(i, j) = q[64 + i * 6 + j];
+      const float* s = q + 100;
+      types::Vector7f X;
+      types::Matrix7f P;
+      types::Vector3f g, b;
+      types::Vector6f Xvw;
+      for (int i = 0; i < 7; ++i) X[i] = s[i];
+      for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) P(i, j) = s[7 + i * 7 + j];
+      for (int i = 0; i < 3; ++i) {
+        g[i] = s[56 + i];
+        b[i] = s[59 + i];
+      }
+      for (int i = 0; i < 6; ++i) Xvw[i] = s[62 + i];
+      const float k = core.estimateBias(v3(q), v3(q + 3), q[6], m3(q + 7), X, P, m3(q + 16), m3(q + 25), m3(q + 34), q[43], q[44], m3(q + 46),
+                                        m3(q + 55), g, b, W, Xvw, q[45]);
+      out.push_back(k);
+      for (int i = 0; i < 7; ++i) out.push_back(X[i]);
+      for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) out.push_back(P(i, j));
+      for (int i = 0; i < 3; ++i) out.push_back(g[i]);
+      for (int i = 0; i < 3; ++i) out.push_back(b[i]);
+      for (int i = 0; i < 6; ++i) out.push_back(Xvw[i]);
     }
   } else if (mode == "chol6") {
     if (in.size() != 36) return 3;

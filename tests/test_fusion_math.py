@@ -233,3 +233,22 @@ def test_so3_exp_ln_and_two_vector_constructor(tool, w):
     axis = np.cross(ua, ub)
     assert np.abs(Rab @ axis - axis).max() <= 5e-7                              # the axis is fixed: minimal rotation
     assert abs(np.trace(Rab) - (1 + 2 * ua @ ub)) <= 1e-6                       # angle = angle between a and b
+
+
+def test_estimate_bias_replays_recorded_calls(tool):
+    """Core::estimateBias (core.cpp:350-414: covariance propagation, SABEstimator Gauss-Newton, the 6x6 fusion with the visual
+    estimate) on 188 calls recorded from a rebvio::Rebvio run on the GPU (tools/record_fusion_calls.py: the bench's 640x480 stream
+    with its synthetic IMU; the filter's start-up and every 20th call of its steady state), with the outputs the DENSE form of
+    the algebra produced - 11x11 / 11x6 / 7x7 products exactly as the reference writes them. The library forms the same sums over
+    the structural non-zeros only (dF/dx1 has 24 of 66, W and F are block diagonal); a skipped term is a product with an exact
+    zero, which leaves a sum that started at +0 unchanged, so the records have to come back BIT FOR BIT (same compiler flags,
+    same libm: the host library is built in this image)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "estimate_bias_calls.npz"))
+    inputs, want = g["inputs"], g["outputs"]
+    assert inputs.shape == (188, 168) and want.shape == (188, 69)
+    got = tool("bias", inputs.reshape(-1)).astype(np.float32).reshape(-1, 69)
+    same = got.view(np.uint32) == want.view(np.uint32)
+    bad = np.argwhere(~same)
+    assert bad.size == 0, (len(bad), [(int(g["call_index"][c]), int(w), float(got[c, w]), float(want[c, w])) for c, w in bad[:5]])
+    # the records are not trivial: the scale estimate moves and most calls change every state word
+    assert np.ptp(want[:, 0]) > 0.05 and (np.abs(want[:, 1:8] - inputs[:, 100:107]) > 0).mean() > 0.9
