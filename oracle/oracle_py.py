@@ -229,6 +229,12 @@ class Oracle:
         """DIAGNOSTIC, not the reference: accumulate the keyline sums of tryVel / extRotVel in double."""
         self.L.orc_set_wide_sums(self.h, int(bool(on)))
 
+    def set_sum_order(self, order: str):
+        """Order of the keyline sums of tryVel / extRotVel: "reference" (fp32, index order - what the reference computes),
+        or one of two DIAGNOSTICS: "wide" (double accumulation) and "device" (the fp32 terms associated as the HIP kernels
+        associate them, rebvio_oracle.cpp struct Acc: with it minimizeVel and extRotVel have to reproduce the device's bits)."""
+        self.L.orc_set_wide_sums(self.h, {"reference": 0, "wide": 1, "device": 2}[order])
+
     # --- detection -------------------------------------------------------------------------
     def scale_space(self, img):
         img, pi = _f(img)

@@ -803,6 +803,7 @@ struct orc_ctx {
   unsigned frame_count = 0;
   // DIAGNOSTIC, not the reference: 1 = the keyline sums of tryVel / extRotVel are accumulated in double (terms still
   // fp32). Used by tools/tolerance_probe.py to measure how much of the reference's own result is summation rounding.
+  // 2 = the fp32 terms added in the HIP kernels' order (struct Acc).
   int wide_sums = 0;
   // glue state (imu.hpp:171-187)
   float Bg[3];
@@ -1146,16 +1147,70 @@ int search_match(const orc_ctx* c, const orc_map* old_map, const orc_keyline& kq
   return -1;
 }
 
-// fp32 running sum in index order, as the reference adds (wide = 0); see orc_ctx::wide_sums for the diagnostic mode.
+// The keyline sums of tryVel / extRotVel. mode 0: fp32 running sum in index order, as the reference adds. Modes 1 and 2 are
+// DIAGNOSTICS, not the reference (orc_ctx::wide_sums): 1 = double accumulation; 2 = the fp32 terms associated the way the HIP
+// kernels associate them (dev_* below) - with it the oracle's sums, and everything minimizeVel / extRotVel derive from them,
+// have to equal the device's bit for bit, which isolates the order of these additions as the ONLY fp32 difference between
+// the two (tests/test_parity_gpu.py::test_lm_sums_in_device_order_are_bit_exact).
+// Device order (rebvio_amd/csrc/track.hip): keyline idx is lane idx % 64 of wave idx / 64; a wave's total is a Hillis-Steele
+// scan inside each row of 16 lanes (shifts 1, 2, 4, 8, zero fill), rows combined as (r3 + r2) + (r1 + r0) (wave_total63_f);
+// the four waves of a group of 256 keylines are added in order from 0 (do_eval / k_try_vel); tryVel's group records are dealt
+// to 16 lanes (record b to lane b % 16, added in ascending b from 0) and those lanes scanned like a row (reduce_staged_records);
+// extRotVel's group records are added in ascending order in double and rounded once (hm::sum_xrv / lm_tail_glue).
+static float dev_row16(float* s) {
+  for (int d = 1; d < 16; d <<= 1)
+    for (int i = 15; i >= 0; --i) s[i] = s[i] + (i >= d ? s[i - d] : 0.0f);
+  return s[15];
+}
+static float dev_wave64(const float* x) {
+  float r[4];
+  for (int row = 0; row < 4; ++row) {
+    float s[16];
+    for (int i = 0; i < 16; ++i) s[i] = x[row * 16 + i];
+    r[row] = dev_row16(s);
+  }
+  return (r[3] + r[2]) + (r[1] + r[0]);
+}
+static float dev_group256(const std::vector<float>& t, int b) {
+  float x[256];
+  for (int i = 0; i < 256; ++i) x[i] = ((size_t)b * 256 + i < t.size()) ? t[(size_t)b * 256 + i] : 0.0f;
+  float acc = 0.0f;
+  for (int w = 0; w < 4; ++w) acc += dev_wave64(x + 64 * w);
+  return acc;
+}
 struct Acc {
   float f = 0.0f;
   double d = 0.0;
-  bool wide = false;
-  inline void add(float x) {
-    if (wide) d += (double)x;
+  int mode = 0;
+  bool groups_in_double = false;  // mode 2: extRotVel's last stage (see above)
+  std::vector<float> terms;       // mode 2: the term of keyline idx (0 where it has none)
+  void init(int mode_, size_t n, bool groups_in_double_) {
+    mode = mode_;
+    groups_in_double = groups_in_double_;
+    if (mode == 2) terms.assign(n, 0.0f);
+  }
+  inline void add(float x, int idx) {
+    if (mode == 1) d += (double)x;
+    else if (mode == 2) terms[idx] = x;
     else f += x;
   }
-  inline float get() const { return wide ? (float)d : f; }
+  float get() const {
+    if (mode == 1) return (float)d;
+    if (mode != 2) return f;
+    const int nblocks = ((int)terms.size() + 255) / 256;
+    if (groups_in_double) {
+      double acc = 0.0;
+      for (int b = 0; b < nblocks; ++b) acc += (double)dev_group256(terms, b);
+      return (float)acc;
+    }
+    float part[16];
+    for (int j = 0; j < 16; ++j) {
+      float acc = 0.0f;
+      for (int b = j; b < nblocks; b += 16) acc += dev_group256(terms, b);
+      part[j] = acc;
+    }
+    return dev_row16(part);
+  }
 };
 
 // Core::tryVel + calculatefJ + testfk (core.cpp:39-148)
@@ -1164,7 +1219,7 @@ float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float 
   const orc_params& P = c->p;
   const orc_map* nm = c->df_map;
   Acc score, J00, J11, J22, J01, J02, J12, F0, F1, F2;
-  for (Acc* a : {&score, &J00, &J11, &J22, &J01, &J02, &J12, &F0, &F1, &F2}) a->wide = c->wide_sums != 0;
+  for (Acc* a : {&score, &J00, &J11, &J22, &J01, &J02, &J12, &F0, &F1, &F2}) a->init(c->wide_sums, map->kl.size(), false);
   float fi = 0.0f;  // reference leaves this uninitialised: carry-forward semantics (header note)
   const unsigned min_matches = std::min(P.min_match_threshold, c->frame_count);
   for (int idx = 0; idx < (int)map->kl.size(); ++idx) {
@@ -1180,7 +1235,7 @@ float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float 
     float f;
     if (z_p <= 0.0) {
       f = (1.0 / k.sigma_rho) * P.search_range * weight;
-      score.add(f * f);
+      score.add(f * f, idx);
       continue;
     }
     float rho_p = 1.0 / z_p;
@@ -1192,7 +1247,7 @@ float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float 
     int y = cvtt(p_yc + 0.5);
     if (x < 1 || y < 1 || (unsigned)x >= (unsigned)P.cols - 1 || (unsigned)y >= (unsigned)P.rows - 1) {
       f = (1.0 / k.sigma_rho) * P.search_range * weight;
-      score.add(f * f);
+      score.add(f * f, idx);
       continue;
     }
     float df_dx, df_dy;
@@ -1224,13 +1279,13 @@ float try_vel(orc_ctx* c, orc_map* map, float JtJ[9], float JtF[3], const float 
       }
     }
     f *= weight;
-    score.add(f * f);
+    score.add(f * f, idx);
     float jx = rho_p * P.fm * df_dx * weight;
     float jy = rho_p * P.fm * df_dy * weight;
     float jz = -rho_p * (p_x * df_dx + p_y * df_dy) * weight;
-    J00.add(jx * jx); J11.add(jy * jy); J22.add(jz * jz);
-    J01.add(jx * jy); J02.add(jx * jz); J12.add(jy * jz);
-    F0.add(jx * f); F1.add(jy * f); F2.add(jz * f);
+    J00.add(jx * jx, idx); J11.add(jy * jy, idx); J22.add(jz * jz, idx);
+    J01.add(jx * jy, idx); J02.add(jx * jz, idx); J12.add(jy * jz, idx);
+    F0.add(jx * f, idx); F1.add(jy * f, idx); F2.add(jz * f, idx);
     residuals[idx] = std::fabs(fi);
   }
   JtJ[0] = J00.get(); JtJ[1] = J01.get(); JtJ[2] = J02.get();
@@ -1337,8 +1392,8 @@ int ext_rot_vel(orc_ctx* c, const float vel[3], float Wx[36], float X[6], float 
   const orc_map* m = c->df_map;
   Acc JtJ[6][6], JtF[6];
   for (int i = 0; i < 6; ++i) {
-    JtF[i].wide = c->wide_sums != 0;
-    for (int j = 0; j < 6; ++j) JtJ[i][j].wide = c->wide_sums != 0;
+    JtF[i].init(c->wide_sums, m->kl.size(), true);
+    for (int j = 0; j < 6; ++j) JtJ[i][j].init(c->wide_sums, m->kl.size(), true);
   }
   for (int idx = 0; idx < (int)m->kl.size(); ++idx) {
     const orc_keyline& k = m->kl[idx];
@@ -1366,8 +1421,8 @@ int ext_rot_vel(orc_ctx* c, const float vel[3], float Wx[36], float X[6], float 
     for (int i = 0; i < 6; ++i) row[i] /= dv;
     Y /= dv;
     for (int i = 0; i < 6; ++i) {
-      for (int j = 0; j < 6; ++j) JtJ[i][j].add(row[i] * row[j]);
-      JtF[i].add(row[i] * Y);
+      for (int j = 0; j < 6; ++j) JtJ[i][j].add(row[i] * row[j], idx);
+      JtF[i].add(row[i] * Y, idx);
     }
   }
   float JtF_f[6];

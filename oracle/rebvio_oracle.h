@@ -84,7 +84,8 @@ typedef struct orc_pair_out {
 
 void orc_default_params(orc_params* p, int rows, int cols);
 orc_ctx* orc_create(const orc_params* p);
-/* DIAGNOSTIC (not the reference): accumulate the keyline sums of tryVel / extRotVel in double; default 0 = fp32 in index order. */
+/* DIAGNOSTICS (not the reference) for the keyline sums of tryVel / extRotVel: 1 = accumulated in double, 2 = the fp32 terms added
+   in the HIP kernels' order (rebvio_oracle.cpp, struct Acc); default 0 = fp32 in index order, as the reference adds. */
 void orc_set_wide_sums(orc_ctx* c, int on);
 void orc_destroy(orc_ctx* c);
 

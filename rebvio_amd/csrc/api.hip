@@ -1737,9 +1737,19 @@ int rebvio_hip_try_vel(rebvio_hip_ctx* c, rebvio_hip_map* m, const float vel[3],
   if (n > 0) HIPCHK(hipMemcpyAsync(residuals, m->d.residual, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->s_trk));
   { const int rc_ts = trk_sync(c); if (rc_ts) return rc_ts; }
   for (int k = 0; k < 10; ++k) {
-    float acc = 0.f;  // same fixed order as the device-side reducer
-    for (int b = 0; b < div_up(n, 256); ++b) acc += c->h_part[(size_t)b * kPartStride + k];
-    out10[k] = acc;
+    // the order of the device-side reducer (track.hip reduce_staged_records): record b goes to lane b % 16, a lane adds its
+    // records in ascending order from 0, the sixteen lanes are scanned with shifts 1, 2, 4, 8 (zero fill) - the sums a
+    // stand-alone tryVel reports are bit for bit the ones minimizeVel's kernels work with
+    float part[16];
+    const int nblk = div_up(n, 256);
+    for (int j = 0; j < 16; ++j) {
+      float acc = 0.f;
+      for (int b = j; b < nblk; b += 16) acc += c->h_part[(size_t)b * kPartStride + k];
+      part[j] = acc;
+    }
+    for (int d = 1; d < 16; d <<= 1)
+      for (int i = 15; i >= 0; --i) part[i] = part[i] + (i >= d ? part[i - d] : 0.0f);
+    out10[k] = part[15];
   }
   // resolve cross-workgroup carry markers (a later device call would do this in its prologue)
   float carry = 0.f;

@@ -75,7 +75,10 @@ int main(int argc, char** argv) {
   int n_odo = 0, n_edge = 0, last_keylines = 0;
   rebvio.registerOdometryCallback([&](rebvio::types::Odometry& o) {
     std::lock_guard<std::mutex> g(mu);
-    std::printf("%llu %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.5f %.5f %.5f %.7f %.7f %.7f %d\n", (unsigned long long)o.ts_us,
+    // REBVIO_EXAMPLE_PRECISE: nine significant digits, enough to give every float back bit for bit
+    static const bool precise = std::getenv("REBVIO_EXAMPLE_PRECISE") != nullptr;
+    std::printf(precise ? "%llu %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d\n"
+                        : "%llu %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.5f %.5f %.5f %.7f %.7f %.7f %d\n", (unsigned long long)o.ts_us,
                 o.orientation[0], o.orientation[1], o.orientation[2], o.position[0], o.position[1], o.position[2], o.scale,
                 o.gravity[0], o.gravity[1], o.gravity[2], o.gyro_bias[0], o.gyro_bias[1], o.gyro_bias[2], o.klm_num);
     ++n_odo;

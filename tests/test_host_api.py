@@ -235,6 +235,53 @@ def test_full_vio_config5_tracks_oracle(host_lib, tmp_path, orc_mod, dist, shape
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dist", [None, EUROC_D], ids=["config5-640x480-30Hz", "config5-640x480-30Hz-radtan"])
+def test_full_vio_config5_is_bit_identical_with_the_sums_in_one_order(host_lib, tmp_path, orc_mod, dist):
+    """BASELINE config 5 without a tolerance: rebvio::Rebvio (camera + 200 Hz IMU, front end, detection, both device halves of a
+    pair, Ls4 / mean acceleration, the scale-attitude-bias filter, gravity-aligned pose integration) against the oracle's
+    restatement of rebvio.cpp:92-293 with its keyline sums added in the kernels' order (set_sum_order("device"), a diagnostic
+    of the restatement) - orientation, position, scale, gravity, gyro bias and match count of all 29 odometry records equal as
+    32-bit floats. What test_full_vio_config5_tracks_oracle bounds by 1e-4 is therefore the association of those sums and
+    nothing else on the path, host fusion included."""
+    from rebvio_amd import synth
+    W, H, dt_us, kref, kmax, min_matches = VIO_CONFIG5
+    n = 30
+    frames, cam = synth.render_stream(W, H, n, dist=dist)
+    ts, gyro, acc = synth.imu_samples(synth.make_scene(0), n, frame_dt_us=dt_us, noise_seed=1)
+    fp, ip = tmp_path / "frames.u8", tmp_path / "imu.bin"
+    frames.tofile(fp)
+    _write_imu(ip, ts, gyro, acc)
+    env = dict(os.environ, REBVIO_EXAMPLE_FRAME_DT_US=str(dt_us), REBVIO_EXAMPLE_PRECISE="1")
+    if dist is not None:
+        env["REBVIO_EXAMPLE_DISTORTION"] = ",".join(repr(float(np.float32(v))) for v in dist)
+    r = subprocess.run([os.path.join(host_lib, "rebvio_stream_example"), str(fp), str(W), str(H), str(n), str(cam.fm), str(cam.cx), str(cam.cy),
+                        str(kref), str(kmax), str(ip), str(min_matches)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines() if ln and ln[0].isdigit()])
+    assert got.shape == (n - 1, 15)
+    orc = orc_mod.Oracle(orc_mod.default_params(H, W, fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=kref, keylines_max=kmax,
+                                                global_min_matches_threshold=min_matches))
+    orc.set_sum_order("device")
+    orc.vio_reset()
+    prev, k, want = None, 0, []
+    for i in range(n):
+        m = orc.detect_u8(frames[i], i * dt_us) if dist is None else orc.detect(orc.front_end_u8(frames[i], cam.fm, cam.fm, cam.cx, cam.cy, dist), i * dt_us)
+        while k < len(ts) and ts[k] <= i * dt_us:
+            orc.vio_add_imu(m, ts[k], gyro[k], acc[k])
+            k += 1
+        if prev is not None:
+            o = orc.vio_step(prev, m)
+            assert o.pair.status == 0
+            want.append(list(o.orientation) + list(o.position) + [o.K] + list(o.g_est) + list(o.Bg) + [o.pair.klm_num])
+        prev = m
+    want32 = np.array(want, np.float32)
+    got32 = got[:, 1:].astype(np.float32)
+    bad = np.argwhere(want32.view(np.uint32) != got32.view(np.uint32))
+    assert bad.size == 0, (len(bad), [(int(r_), int(c), float(got32[r_, c]), float(want32[r_, c])) for r_, c in bad[:6]])
+    assert want32[-1, 6] > 0 and np.abs(want32[-1, 3:6]).max() > 0.05  # the filter ran and the pose moved
+
+
+@pytest.mark.gpu
 def test_replay_asl_folder_equals_raw_stream(host_lib, tmp_path):
     """rebvio_replay over an EuRoC-layout folder (PNG frames, csv IMU) and over the same data as raw files writes the same
     odometry file, in the reference's regression format, and agrees with the ros_rebvio-style example."""

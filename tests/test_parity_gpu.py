@@ -337,6 +337,50 @@ def test_forward_match_and_ext_rot_vel(orc_mod, B, c2_stream):
     assert np.abs(eo["X"] - eg["X"]).max() <= 5e-3 * np.abs(eo["X"]).max() + 1e-6
 
 
+@pytest.mark.parametrize("config", ["c2", "c3"], ids=["c2-16k(spec kernel)", "c3-64k(chain kernel)"])
+def test_lm_sums_in_device_order_are_bit_exact(orc_mod, B, c2_stream, c3_stream, config):
+    """What the tolerances of the three tests above ARE: tryVel, minimizeVel and extRotVel reduce ten / twenty-seven fp32 sums
+    over all keylines, the reference adds them in index order, the kernels in a tree (a wave's DPP scan, the four waves of a
+    group, the groups dealt to sixteen lanes) - and nothing else differs. With the oracle's sums taken in the kernels' order
+    (set_sum_order("device"), a diagnostic of the restatement: oracle/rebvio_oracle.cpp struct Acc) every one of those outputs
+    comes back BIT FOR BIT on synced inputs: the score and the 3x3 / 3 sums of tryVel at three velocities, the whole
+    Levenberg-Marquardt run (velocity, score, covariance, accept mask, every forward match), extRotVel's 6x6 and 6 sums."""
+    frames, cam = c2_stream if config == "c2" else c3_stream
+    kw = KW_C2 if config == "c2" else KW_C3
+    P = warm(orc_mod, B, frames, cam, 3, **kw)
+    P.orc.set_sum_order("device")
+    om_old, om_new = P.om
+    gm_old, gm_new = P.gm
+    P.orc.build_distance_field(om_new)
+    P.ctx.build_distance_field(gm_new)
+    n = om_old.size()
+    assert n > (50000 if config == "c3" else 10000)
+    ro = P.orc.minimize_vel(om_old)
+    rg = P.ctx.minimize_vel(gm_old)
+    assert ro["accept_mask"] == rg["accept_mask"]
+    for k in ("vel", "F", "Rvel", "sigma_rho_min"):
+        assert _bits_equal(np.float32(ro[k]), np.float32(rg[k])), (k, ro[k], rg[k])
+    assert np.array_equal(om_old.keylines()["match_id_forward"], gm_old.keylines()["match_id_forward"])
+    P.orc.forward_match(om_old, om_new)
+    P.ctx.forward_match(gm_old, gm_new)
+    assert_keylines_equal(om_new.keylines(), gm_new.keylines(), what="forwardMatch")
+    eo = P.orc.ext_rot_vel(ro["vel"])
+    eg = P.ctx.ext_rot_vel(ro["vel"])
+    assert _bits_equal(np.float32(eo["Wx"]), np.float32(eg["Wx"])), np.abs(eo["Wx"] - eg["Wx"]).max()
+    assert _bits_equal(np.float32(eo["JtF"]), np.float32(eg["JtF"])), (eo["JtF"], eg["JtF"])
+    # single evaluations, residuals carried from one to the next on both sides
+    srm = P.orc.quantile(om_old)
+    res_o = np.zeros(n, np.float32)
+    res_g = np.zeros(n, np.float32)
+    for vel in ([0, 0, 0], [-0.011, -0.005, -0.003], [0.02, 0.01, -0.9]):
+        so, Jo, Fo = P.orc.try_vel(om_old, vel, srm, res_o)
+        sg, Jg, Fg = P.ctx.try_vel(gm_old, vel, srm, res_g)
+        assert _bits_equal(res_o, res_g)
+        assert _bits_equal(np.float32([so]), np.float32([sg])), (vel, so, sg)
+        assert _bits_equal(np.float32(Jo), np.float32(Jg)), (vel, Jo, Jg)
+        assert _bits_equal(np.float32(Fo), np.float32(Fg)), (vel, Fo, Fg)
+
+
 @pytest.fixture(scope="module")
 def c3_stream():
     """5 frames of BASELINE config 3: 1280x960, ~58k keylines of a 64 000-keyline budget."""
@@ -476,6 +520,74 @@ def test_track_pair_sequence(orc_mod, B, c2_stream):
         both = (ko["match_id"] == kg["match_id"]) & (ko["match_id"] >= 0)
         rel = np.abs(ko["rho"][both] - kg["rho"][both]) / np.abs(ko["rho"][both])
         assert np.median(rel) < 1e-3
+
+
+def _record_words(po):
+    """every field of a pair record as raw 32-bit words (floats by their bits)"""
+    out = []
+    for name, _ in type(po)._fields_:
+        v = getattr(po, name)
+        a = np.array(v) if hasattr(v, "__len__") else np.array([v])
+        out.append(a.astype(np.float32).view(np.uint32) if a.dtype.kind == "f" else a.astype(np.int64).astype(np.uint32))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("stream_id,config", [(0, "c2"), (1, "c2"), (2, "c2"), (0, "c3")],
+                         ids=["c2-stream0", "c2-stream1", "c2-stream2", "c3-1280x960-64k"])
+def test_whole_pipeline_is_bit_identical_with_the_sums_in_one_order(orc_mod, B, stream_id, config):
+    """The stateful comparison without a tolerance. Thirty frames of a 640x480 stream (BASELINE config 2; ten of config 3's
+    1280x960 with ~58k keylines), detection, tracking,
+    glue, directedMatch, regularisation and depth filter with the state carried INDEPENDENTLY on both sides - the oracle adding
+    the keyline sums of tryVel / extRotVel in the kernels' order (set_sum_order("device"); the terms, and every other operation
+    of the path, are the restatement's own). Per pair: every word of the pair record - translation and its covariance, score, the
+    visual 6-vector and its information matrix, the corrected one, rotation, sigma quantile, counters, accept mask - identical,
+    through the per-pair API and through the streaming driver (device glue, speculative LM kernel); after the last pair every
+    field of every keyline of the newest map identical. So over a whole stream the ONLY thing that separates the kernels
+    from the restatement of the reference is how 37 fp32 sums are associated - which is what the tolerances of
+    test_track_pair_sequence / test_stream_divergence_report measure, and nothing else."""
+    from rebvio_amd import synth
+    if config == "c2":
+        W, H, npairs, kw, min_klm = 640, 480, 29, KW_C2, 8000
+        frames, cam = synth.render_stream(W, H, 8, stream_id=stream_id)
+    else:  # BASELINE config 3: ~58k keylines of a 64 000 budget, the non-speculative chain kernel, <64, 1> directedMatch
+        W, H, npairs, kw, min_klm = 1280, 960, 9, KW_C3, 20000
+        frames, cam = synth.render_stream(W, H, 8, stream_id=stream_id, density=2.0)
+    order = synth.pingpong_indices(8, npairs + 1)
+    orc = orc_mod.Oracle(params_for(orc_mod, cam, **kw))
+    orc.set_sum_order("device")
+    gpu = B.Context(params_for(B, cam, **kw))
+    mo, mg, rec_o = [], [], []
+    for k, i in enumerate(order):
+        mo.append(orc.detect_u8(frames[i], k * 50000))
+        mg.append(gpu.detect_u8(frames[i], k * 50000))
+        if len(mo) > 2:
+            mo.pop(0)
+            mg.pop(0).release()
+        if k == 0:
+            continue
+        po = orc.track_pair(mo[0], mo[1])
+        pg = gpu.track_pair(mg[0], mg[1])
+        wo, wg = _record_words(po), _record_words(pg)
+        assert np.array_equal(wo, wg), (k, np.flatnonzero(wo != wg)[:8], np.array(po.Vg), np.array(pg.Vg))
+        rec_o.append(wo)
+    assert rec_o[-1][0] != 0 and po.klm_num > min_klm
+    # the map that carries the state into the next pair (the older one is dropped after its pair, rebvio.cpp:136-139)
+    assert_keylines_equal(mo[1].keylines(), mg[1].keylines(), what=f"{config} stream {stream_id}: newest map after {npairs} pairs")
+    gpu.close()
+    # the streaming driver on the same frames: device glue, persistent speculative LM kernel, pairs queued in groups
+    ctx = B.Context(params_for(B, cam, **kw))
+    dev = ctx.upload_frames(frames)
+    got = []
+    for k, i in enumerate(order):
+        out, _ = ctx.push_frame_u8_device(dev + int(i) * W * H, k * 50000)
+        if out.status >= 0:
+            got.append(_record_words(out))
+    for out, _ in ctx.flush():
+        got.append(_record_words(out))
+    ctx.close()
+    assert len(got) == len(rec_o) == npairs
+    for k, (wo, wg) in enumerate(zip(rec_o, got)):
+        assert np.array_equal(wo, wg), (k, np.flatnonzero(wo != wg)[:8])
 
 
 def test_pose_deviation_is_the_references_own_rounding_noise(orc_mod, B, c2_stream):

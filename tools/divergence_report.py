@@ -2,7 +2,9 @@
 """SURVEY.md H4's divergence report for a stream: GPU pipeline vs CPU oracle, state carried independently on both sides.
 Per pair: do the Levenberg-Marquardt accept / reject decisions agree (same path through minimizeVel, core.cpp:166-185), and how
 far apart are the translations; first pair at which a decision differs. Also against the oracle run with double-accumulated
-sums (what the translation would be without the summation rounding of either side).
+sums (what the translation would be without the summation rounding of either side), and against the oracle run with its
+keyline sums in the DEVICE's order (oracle_py.Oracle.set_sum_order("device")): what is left then is the 6x6 solve of
+extRotVel / the glue algebra, where the restatement and the library each follow the reference's SVD in their own way.
   divergence_report.py [n_frames] [stream_id ...]"""
 import os
 import sys
@@ -12,7 +14,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def run(n, sid, W=640, H=480, kref=15000, kmax=16000, density=1.0, **extra):
+def run(n, sid, W=640, H=480, kref=15000, kmax=16000, density=1.0, with_dev=False, **extra):
     import torch  # noqa: F401
     from oracle import oracle_py as O
     from rebvio_amd import backend as B, synth
@@ -20,9 +22,9 @@ def run(n, sid, W=640, H=480, kref=15000, kmax=16000, density=1.0, **extra):
     order = synth.pingpong_indices(8, n)
     kw = dict(fm=cam.fm, cx=cam.cx, cy=cam.cy, keylines_ref=kref, keylines_max=kmax, **extra)
 
-    def oracle(wide):
+    def oracle(sum_order):
         orc = O.Oracle(O.default_params(H, W, **kw))
-        orc.set_wide_sums(wide)
+        orc.set_sum_order(sum_order)
         prev, rec = None, []
         for k, i in enumerate(order):
             m = orc.detect_u8(frames[i], k * 50000)
@@ -32,7 +34,8 @@ def run(n, sid, W=640, H=480, kref=15000, kmax=16000, density=1.0, **extra):
             prev = m
         return rec
 
-    ref, wide = oracle(False), oracle(True)
+    ref, wide = oracle("reference"), oracle("wide")
+    dev_order = oracle("device") if with_dev else None
     ctx = B.Context(B.default_params(H, W, **kw))
     dev = ctx.upload_frames(frames)
     got = []
@@ -43,6 +46,8 @@ def run(n, sid, W=640, H=480, kref=15000, kmax=16000, density=1.0, **extra):
     for out, _ in ctx.flush():  # the records still on their way when the input ended
         got.append((np.array(out.Vg), out.lm_accept_mask, out.klm_num, out.status))
     ctx.close()
+    if with_dev:
+        return ref, wide, got, dev_order
     return ref, wide, got
 
 
@@ -66,7 +71,7 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     sids = [int(s) for s in sys.argv[2:]] or [0, 1, 2]
     for sid in sids:
-        ref, wide, got = run(n, sid)
+        ref, wide, got, devo = run(n, sid, with_dev=True)
         first, rows = analyse(ref, wide, got)
         print(f"stream {sid}: {len(rows)} pairs compared; first pair whose LM accept mask differs from the oracle's: {first}")
         print("  pair  mask(oracle/gpu)  |Vg gpu-oracle|/|Vg|  |Vg gpu-wide|/|Vg|  |Vg oracle-wide|/|Vg|  matches(oracle/gpu)")
@@ -79,3 +84,10 @@ if __name__ == "__main__":
         if after:
             print(f"  after the first differing decision ({len(after)} pairs): max gpu-oracle {max(r[3] for r in after):.2e}, "
                   f"max gpu-wide {max(r[4] for r in after):.2e}, max oracle-wide {max(r[5] for r in after):.2e}")
+        md = min(len(devo), len(got))
+        same = [devo[k][1] == got[k][1] and devo[k][2] == got[k][2] for k in range(md)]
+        dd = [rel(got[k][0], devo[k][0]) for k in range(md)]
+        bit = [bool(np.array_equal(np.float32(got[k][0]).view(np.uint32), np.float32(devo[k][0]).view(np.uint32))) for k in range(md)]
+        nb = next((k for k in range(md) if not bit[k]), None)
+        print(f"  against the oracle with its sums in the device's order ({md} pairs): LM masks and match counts equal on {sum(same)}, "
+              f"translation bit-identical on {sum(bit)} (first pair that is not: {nb}), max |Vg gpu-oracle|/|Vg| {max(dd):.2e}")
