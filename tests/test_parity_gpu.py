@@ -528,7 +528,12 @@ def _record_words(po):
     for name, _ in type(po)._fields_:
         v = getattr(po, name)
         a = np.array(v) if hasattr(v, "__len__") else np.array([v])
-        out.append(a.astype(np.float32).view(np.uint32) if a.dtype.kind == "f" else a.astype(np.int64).astype(np.uint32))
+        if a.dtype.kind == "f":
+            a = a.astype(np.float32)
+            a[np.isnan(a)] = np.float32(np.nan)  # (a NaN is a NaN: sign and payload of one are not part of the result)
+            out.append(a.view(np.uint32))
+        else:
+            out.append(a.astype(np.int64).astype(np.uint32))
     return np.concatenate(out)
 
 
