@@ -6,7 +6,11 @@ Bars:
     match_id_forward / residuals of tryVel, forwardMatch, directedMatch, regularize1Iter, depth EKF
     (all per-keyline fp32 arithmetic is evaluated in the reference's order, fp contraction off);
   * tolerance (stated at each assert): the fp32 sums over ~15k keylines (tryVel: score/JtJ/JtF, extRotVel:
-    JtJ/JtF) — the oracle adds sequentially in index order, the GPU uses a fixed butterfly/tree order.
+    JtJ/JtF) — the oracle adds sequentially in index order, the GPU uses a fixed butterfly/tree order;
+  * and bit-exact again, sums and everything downstream of them (the LM run, the glue, whole streams with the state
+    carried independently), once the oracle adds those sums in the kernels' order - Oracle.set_sum_order("device"), a
+    diagnostic of the restatement: test_lm_sums_in_device_order_are_bit_exact,
+    test_whole_pipeline_is_bit_identical_with_the_sums_in_one_order. The tolerances above are that order and nothing else.
 """
 import os
 
