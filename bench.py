@@ -606,10 +606,21 @@ def host_class_rate(frames, cam, cfg, n=4000):
         rec = np.zeros(len(ts), dtype=[("ts", "<i8"), ("gyro", "<f4", 3), ("acc", "<f4", 3)])
         rec["ts"], rec["gyro"], rec["acc"] = ts, gyro * 0, acc  # ping-pong replay: a still gyro
         rec.tofile(os.path.join(d, "imu.bin"))
-        r = subprocess.run([exe, "--raw", os.path.join(d, "f.u8"), "--size", str(cam.width), str(cam.height), "--imu", os.path.join(d, "imu.bin"),
-                            "--camera", str(cam.fm), str(cam.cx), str(cam.cy), "--keylines", str(cfg["keylines_ref"]), str(cfg["keylines_max"]),
-                            "--out", os.path.join(d, "o.txt")], capture_output=True, text=True, env=dict(os.environ, REBVIO_HOST_TIMERS="1"),
-                           timeout=300)
+        # three runs, the median one is reported (a run is 0.35 s of three host threads beside a GPU-bound chain: one preemption of
+        # the fusion thread shows as hundreds of frames/s; all three rates are listed)
+        runs = []
+        for _ in range(3):
+            r = subprocess.run([exe, "--raw", os.path.join(d, "f.u8"), "--size", str(cam.width), str(cam.height), "--imu", os.path.join(d, "imu.bin"),
+                                "--camera", str(cam.fm), str(cam.cx), str(cam.cy), "--keylines", str(cfg["keylines_ref"]), str(cfg["keylines_max"]),
+                                "--out", os.path.join(d, "o.txt")], capture_output=True, text=True, env=dict(os.environ, REBVIO_HOST_TIMERS="1"),
+                               timeout=300)
+            w = re.search(r"\[replay\] (\d+) odometry records in ([0-9.]+) s = ([0-9.]+) frames/s", r.stderr)
+            if r.returncode != 0 or not w:
+                raise RuntimeError(r.stderr[-400:])
+            runs.append((float(w.group(3)), r))
+        runs.sort(key=lambda t: t[0])
+        all_fps = [t[0] for t in runs]
+        r = runs[1][1]
     m = re.search(r"per pair \(us\): first half on device ([0-9.]+)\s+acceleration \+ bias/scale filter ([0-9.]+)\s+second half on device "
                   r"([0-9.]+)\s+pose \+ callbacks ([0-9.]+)\s+\(between pairs: input queue \+ IMU read ([0-9.]+)\)", r.stderr)
     w = re.search(r"\[replay\] (\d+) odometry records in ([0-9.]+) s = ([0-9.]+) frames/s", r.stderr)
@@ -617,7 +628,8 @@ def host_class_rate(frames, cam, cfg, n=4000):
     if r.returncode != 0 or not m or not w:
         raise RuntimeError(r.stderr[-400:])
     st = [float(v) for v in m.groups()]
-    return {"fps": float(w.group(3)), "basis": "wall clock between the first and the last odometry record, %d records" % int(w.group(1)),
+    return {"fps": float(w.group(3)), "runs_fps": all_fps,
+            "basis": "wall clock between the first and the last odometry record, %d records; median of three runs" % int(w.group(1)),
             "fusion_thread_us_per_pair": {"first_half_on_device": st[0], "acceleration_bias_scale_filter": st[1], "second_half_on_device": st[2],
                                           "pose_callbacks": st[3], "between_pairs": st[4]},
             "acquisition_thread_us_per_frame": float(a.group(1)) if a else None}
