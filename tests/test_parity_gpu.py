@@ -1465,6 +1465,50 @@ def test_batched_lanes_equal_stand_alone_streams(B, c2_stream, monkeypatch, L, e
     assert got[0] != got[1]  # different scenes per lane
 
 
+@pytest.mark.parametrize("lens", [None, EUROC_D], ids=["pinhole", "radtan-front-end"])
+def test_batched_lanes_are_bit_identical_to_the_oracle_with_the_sums_in_one_order(orc_mod, B, c2_stream, lens):
+    """The batch driver against the restatement directly (not through the stand-alone contexts of the tests around it): four
+    lanes, four scenes, 16 frames, the oracle adding its keyline sums in the kernels' order - every word of every lane's pair
+    records identical; with the EuRoC lens model the frames pass through the batched device front end (x3 + undistort) on one
+    side and the oracle's on the other."""
+    from rebvio_amd import synth
+    cam = c2_stream[1]
+    L, n = 4, 16
+    streams = [synth.render_stream(cam.width, cam.height, 8, stream_id=10 + s, dist=lens)[0] for s in range(L)]
+    order = synth.pingpong_indices(8, n)
+    npx = cam.width * cam.height
+    bat = B.Batch(params_for(B, cam, **KW_C2), L)
+    if lens is not None:
+        for lane in bat.lanes:
+            lane.set_undistort(cam.fm, cam.fm, cam.cx, cam.cy, lens)
+    devs = [bat.lanes[s].upload_frames(streams[s]) for s in range(L)]
+    got = [[] for _ in range(L)]
+    for k, i in enumerate(order):
+        outs, _ = bat.push_u8_device([d + int(i) * npx for d in devs], k * 50000)
+        for s in range(L):
+            if outs[s].status >= 0:
+                got[s].append(_record_words(outs[s]))
+    for outs, _ in bat.flush():
+        for s in range(L):
+            got[s].append(_record_words(outs[s]))
+    bat.close()
+    for s in range(L):
+        orc = orc_mod.Oracle(params_for(orc_mod, cam, **KW_C2))
+        orc.set_sum_order("device")
+        prev, want = None, []
+        for k, i in enumerate(order):
+            if lens is None:
+                m = orc.detect_u8(streams[s][i], k * 50000)
+            else:
+                m = orc.detect(orc.front_end_u8(streams[s][i], cam.fm, cam.fm, cam.cx, cam.cy, lens), k * 50000)
+            if prev is not None:
+                want.append(_record_words(orc.track_pair(prev, m)))
+            prev = m
+        assert len(got[s]) == len(want) == n - 1
+        for k, (wo, wg) in enumerate(zip(want, got[s])):
+            assert np.array_equal(wo, wg), (s, k, np.flatnonzero(wo != wg)[:8])
+
+
 def test_batched_lanes_with_the_euroc_lens_model(B, c2_stream):
     """A batch takes the reference's own camera (camera.hpp:25-45: rad-tan distortion): with a lens model on every lane the
     batched front end (k_front_end_u8_b: x3 + undistort, rebvio.cpp:43-47) runs ahead of the scans, and every lane's records
