@@ -230,6 +230,39 @@ def test_tracking_recovers_translation_direction(orc_mod, small_stream):
     assert np.std(v[:, 0]) < 0.5 * np.abs(np.mean(v[:, 0]))
 
 
+def test_sum_orders_differ_by_rounding_only(orc_mod, small_stream):
+    """The keyline sums of tryVel / extRotVel in the restatement's three orders - the reference's (fp32, index order), the
+    double-accumulating diagnostic, the HIP kernels' tree (set_sum_order("device"): what the bit-for-bit GPU tests run the
+    oracle with) - are sums of the SAME fp32 terms: a single tryVel's score and 3x3 / 3 sums agree to the rounding of a
+    few-thousand-term fp32 sum, every per-keyline output (residuals, forward matches) is identical, and the association is a
+    real one (the fp32 orders do not give the same bits). CPU only: the tree itself is pinned against the device by
+    tests/test_parity_gpu.py::test_lm_sums_in_device_order_are_bit_exact."""
+    frames, cam = small_stream
+    got = {}
+    for order in ("reference", "wide", "device"):
+        orc = orc_mod.Oracle(params_for(orc_mod, cam, global_min_matches_threshold=50))
+        prev = orc.detect_u8(frames[0])
+        for i in range(1, 4):  # realistic depths / matches in the reference's order, then ONE evaluation in the order under test
+            m = orc.detect_u8(frames[i], i * 50000)
+            orc.track_pair(prev, m)
+            prev = m
+        m = orc.detect_u8(frames[4], 4 * 50000)
+        orc.build_distance_field(m)
+        orc.set_sum_order(order)
+        res = np.zeros(prev.size(), np.float32)
+        score, J, F = orc.try_vel(prev, [-0.01, -0.004, 0.002], orc.quantile(prev), res)
+        got[order] = (np.float64(score), np.asarray(J, np.float64), np.asarray(F, np.float64), res.copy(), prev.keylines()["match_id_forward"].copy())
+    ref, wide, dev = got["reference"], got["wide"], got["device"]
+    assert (ref[4] >= 0).sum() > 500
+    for other in (wide, dev):
+        assert np.array_equal(ref[3].view(np.uint32), other[3].view(np.uint32)) and np.array_equal(ref[4], other[4])
+        assert abs(other[0] - ref[0]) <= 2e-4 * abs(ref[0])
+        assert np.abs(other[1] - ref[1]).max() <= 2e-4 * np.abs(np.diag(ref[1])).max()
+        assert np.abs(other[2] - ref[2]).max() <= 2e-4 * np.sqrt(ref[0] * np.abs(np.diag(ref[1])).max())
+    assert abs(dev[0] - wide[0]) <= abs(ref[0] - wide[0]) + 1e-6 * abs(wide[0])  # a tree is no worse than the running sum
+    assert np.float32(dev[0]) != np.float32(ref[0]) or not np.array_equal(np.float32(dev[1]), np.float32(ref[1]))
+
+
 # ---- front end (SURVEY.md N1): convertTo(CV_32F, 3.0) + cv::undistort -------------------------------------------------
 EUROC_D = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]  # camera.hpp:31-35
 
